@@ -1,0 +1,104 @@
+"""Depth-classifier weight blob ("FHW1"): fixed-point integer weights of the three conv layers and the three
+FC heads.  The same bytes feed the HIP library (fhevc_cfg.weights_path) and, in tests,
+the CPU oracle.
+
+Layout after the 8-byte header (magic "FHW1", uint32 version = 1), all little-endian, no padding:
+  int32 shift[3]
+  int8 w1[16][3][3]         int32 b1[16]
+  int8 w2[32][16][3][3]     int32 b2[32]
+  int8 w3[64][32][3][3]     int32 b3[64]
+  int8 wh64[2][8][8][64]    int32 bh64[2]
+  int8 wh32[2][8][8][64]    int32 bh32[2]
+  int8 wh16[2][4][4][64]    int32 bh16[2]
+"""
+import numpy as np
+
+MAGIC = b"FHW1"
+FIELDS = [
+    ("shift", np.int32, (3,)),
+    ("w1", np.int8, (16, 3, 3)), ("b1", np.int32, (16,)),
+    ("w2", np.int8, (32, 16, 3, 3)), ("b2", np.int32, (32,)),
+    ("w3", np.int8, (64, 32, 3, 3)), ("b3", np.int32, (64,)),
+    ("wh64", np.int8, (2, 8, 8, 64)), ("bh64", np.int32, (2,)),
+    ("wh32", np.int8, (2, 8, 8, 64)), ("bh32", np.int32, (2,)),
+    ("wh16", np.int8, (2, 4, 4, 64)), ("bh16", np.int32, (2,)),
+]
+BIAS_LIMIT = 1 << 22  # keeps |bias + sum(w*a)| < 2^24 so fp32 accumulation of bf16 operands is exact
+BLOB_BYTES = 8 + sum(int(np.prod(s)) * np.dtype(t).itemsize for _, t, s in FIELDS)
+
+
+def validate(w):
+    for name, dt, shape in FIELDS:
+        a = np.asarray(w[name])
+        if a.shape != shape or a.dtype != dt:
+            raise ValueError(f"{name}: expected {dt} {shape}, got {a.dtype} {a.shape}")
+    for k in ("w1", "w2", "w3", "wh64", "wh32", "wh16"):
+        if np.any(w[k] == -128):
+            raise ValueError(f"{k}: -128 is not allowed (weights are symmetric int8, |w| <= 127)")
+    for k in ("b1", "b2", "b3"):
+        if np.any(np.abs(w[k].astype(np.int64)) > BIAS_LIMIT):
+            raise ValueError(f"{k}: |bias| must be <= 2^22")
+    if np.any(w["shift"] < 0) or np.any(w["shift"] > 24):
+        raise ValueError("shift out of range")
+
+
+def pack(w):
+    validate(w)
+    parts = [MAGIC, np.uint32(1).tobytes()]
+    for name, dt, _ in FIELDS:
+        parts.append(np.ascontiguousarray(w[name], dtype=dt).tobytes())
+    blob = b"".join(parts)
+    assert len(blob) == BLOB_BYTES
+    return blob
+
+
+def unpack(blob):
+    if len(blob) != BLOB_BYTES or blob[:4] != MAGIC:
+        raise ValueError("not an FHW1 weight blob")
+    if int(np.frombuffer(blob[4:8], np.uint32)[0]) != 1:
+        raise ValueError("unsupported FHW1 version")
+    off, out = 8, {}
+    for name, dt, shape in FIELDS:
+        n = int(np.prod(shape)) * np.dtype(dt).itemsize
+        out[name] = np.frombuffer(blob[off:off + n], dt).reshape(shape).copy()
+        off += n
+    validate(out)
+    return out
+
+
+def save(path, w):
+    with open(path, "wb") as f:
+        f.write(pack(w))
+
+
+def load(path):
+    with open(path, "rb") as f:
+        return unpack(f.read())
+
+
+def random_weights(seed=0, extreme=False):
+    """Random-init weights of the right architecture (bench/test use; no training implied).
+    extreme=True: maximum-magnitude weights, to probe the 2^24 exactness bound."""
+    rng = np.random.default_rng(seed)
+    w = {}
+    if extreme:
+        for name, dt, shape in FIELDS:
+            if dt == np.int8:
+                w[name] = rng.choice(np.array([-127, 127], np.int8), size=shape)
+            elif name == "shift":
+                w[name] = np.array([4, 12, 13], np.int32)
+            else:
+                w[name] = rng.integers(-1000, 1000, size=shape).astype(np.int32)
+        return w
+    w["shift"] = np.array([6, 7, 8], np.int32)
+    w["w1"] = rng.integers(-64, 65, size=(16, 3, 3)).astype(np.int8)
+    w["b1"] = rng.integers(-2000, 2000, size=16).astype(np.int32)
+    w["w2"] = rng.integers(-32, 33, size=(32, 16, 3, 3)).astype(np.int8)
+    w["b2"] = rng.integers(-6000, 6000, size=32).astype(np.int32)
+    w["w3"] = rng.integers(-32, 33, size=(64, 32, 3, 3)).astype(np.int8)
+    w["b3"] = rng.integers(-9000, 9000, size=64).astype(np.int32)
+    for k, shape in (("wh64", (2, 8, 8, 64)), ("wh32", (2, 8, 8, 64)), ("wh16", (2, 4, 4, 64))):
+        w[k] = rng.integers(-64, 65, size=shape).astype(np.int8)
+    for k in ("bh64", "bh32", "bh16"):
+        w[k] = rng.integers(-50000, 50000, size=2).astype(np.int32)
+    return w

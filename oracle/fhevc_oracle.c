@@ -1,0 +1,623 @@
+/*
+ * fhevc_oracle.c -- CPU restatement of the CU-partition fast-decision hot path (plain C).
+ * TEST INFRASTRUCTURE ONLY -- see fhevc_oracle.h.  Nothing under fasthevc_amd/ links or loads this.
+ * Citations are relative to /root/reference.
+ */
+#include "fhevc_oracle.h"
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+
+#define CTU 64
+#define UNITS 16 /* 4x4 units per CTU side */
+
+static inline int iabs(int v) { return v < 0 ? -v : v; }
+static inline int imin(int a, int b) { return a < b ? a : b; }
+static inline int imax(int a, int b) { return a > b ? a : b; }
+static inline int clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* ------------------------------------------------------------------------------------------
+ * A14: scan tables.  TComRom.cpp:290-308 fills g_auiZscanToRaster by a 4-way recursion
+ * (TL, TR, BL, BR) over a 16x16 grid, i.e. z-index = Morton interleave with x in the even
+ * bits and y in the odd bits; initRasterToZscan (:310-323) inverts it.
+ * ------------------------------------------------------------------------------------------ */
+static void zscan_rec(int max_depth, int depth, unsigned start, uint16_t** cur)
+{
+  int stride = 1 << (max_depth - 1);
+  if (depth == max_depth) { *(*cur)++ = (uint16_t)start; return; }
+  int step = stride >> depth;
+  zscan_rec(max_depth, depth + 1, start, cur);
+  zscan_rec(max_depth, depth + 1, start + step, cur);
+  zscan_rec(max_depth, depth + 1, start + step * stride, cur);
+  zscan_rec(max_depth, depth + 1, start + step * stride + step, cur);
+}
+
+void fho_init_scan_tables(uint16_t raster_to_zscan[256], uint16_t zscan_to_raster[256])
+{
+  uint16_t* p = zscan_to_raster;
+  zscan_rec(5, 1, 0, &p); /* TEncCu.cpp:126-128: initZscanToRaster(maxTotalDepth+1 = 5, 1, 0, ..) */
+  for (int i = 0; i < 256; i++) raster_to_zscan[zscan_to_raster[i]] = (uint16_t)i;
+}
+
+static uint16_t g_r2z[256], g_z2r[256];
+static int g_tables_ready = 0;
+static void ensure_tables(void)
+{
+  if (!g_tables_ready) { fho_init_scan_tables(g_r2z, g_z2r); g_tables_ready = 1; }
+}
+
+void fho_depth_raster_to_zorder(const uint8_t raster[256], uint8_t zorder[256])
+{
+  ensure_tables();
+  for (int r = 0; r < 256; r++) zorder[g_r2z[r]] = raster[r];
+}
+void fho_depth_zorder_to_raster(const uint8_t zorder[256], uint8_t raster[256])
+{
+  ensure_tables();
+  for (int r = 0; r < 256; r++) raster[r] = zorder[g_r2z[r]];
+}
+
+/* TComSysuCuMDTools.cpp:24-38: pre-order; "0" when the node's first unit has depth == node depth
+ * (this includes the always-0 flag of an 8x8 node), "1" + four children otherwise. */
+static int write_flags(const uint8_t* z, int len, int depth, uint8_t* flags, int n)
+{
+  if (z[0] == depth) { flags[n++] = 0; return n; }
+  flags[n++] = 1;
+  for (int i = 0; i < 4; i++) n = write_flags(z + len / 4 * i, len / 4, depth + 1, flags, n);
+  return n;
+}
+int fho_depth_to_split_flags(const uint8_t depth_raster[256], uint8_t flags[85])
+{
+  uint8_t z[256];
+  fho_depth_raster_to_zorder(depth_raster, z);
+  return write_flags(z, 256, 0, flags, 0);
+}
+/* TComSysuCuMDTools.cpp:121-135 */
+static int read_flags(const uint8_t* flags, int nflags, int pos, uint8_t* z, int len, int depth)
+{
+  if (pos >= nflags) return -1;
+  if (flags[pos++] == 0) { memset(z, depth, (size_t)len); return pos; }
+  for (int i = 0; i < 4; i++) {
+    pos = read_flags(flags, nflags, pos, z + len / 4 * i, len / 4, depth + 1);
+    if (pos < 0) return -1;
+  }
+  return pos;
+}
+int fho_split_flags_to_depth(const uint8_t* flags, int nflags, uint8_t depth_raster[256])
+{
+  uint8_t z[256];
+  int used = read_flags(flags, nflags, 0, z, 256, 0);
+  if (used < 0) return -1;
+  fho_depth_zorder_to_raster(z, depth_raster);
+  return used;
+}
+int fho_compare_split_mode(const uint8_t a[256], const uint8_t b[256])
+{
+  int d = 0;
+  for (int i = 0; i < 256; i++) d += iabs((int)a[i] - (int)b[i]);
+  return d;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A5: SATD.  The butterflies of TComRdCost.cpp:1527-1750 compute an un-normalised 2-D
+ * Walsh-Hadamard transform of (org - cur); the sum of |coefficients| does not depend on the
+ * order the reference emits them in, so the transform is restated as a separable in-place WHT.
+ * Rounding: 2x2 none (:1540-1546), 4x4 (s+1)>>1 (:1640), 8x8 (s+2)>>2 (:1747).
+ * ------------------------------------------------------------------------------------------ */
+static void wht_inplace(int* v, int n, int stride)
+{
+  for (int h = 1; h < n; h <<= 1)
+    for (int i = 0; i < n; i += h << 1)
+      for (int j = i; j < i + h; j++) {
+        int a = v[j * stride], b = v[(j + h) * stride];
+        v[j * stride] = a + b;
+        v[(j + h) * stride] = a - b;
+      }
+}
+static uint32_t had_nxn(const int16_t* org, int so, const int16_t* cur, int sc, int n, int* dc_out)
+{
+  int d[64];
+  for (int y = 0; y < n; y++)
+    for (int x = 0; x < n; x++) d[y * n + x] = (int)org[y * so + x] - (cur ? (int)cur[y * sc + x] : 0);
+  for (int y = 0; y < n; y++) wht_inplace(d + y * n, n, 1);
+  for (int x = 0; x < n; x++) wht_inplace(d + x, n, n);
+  uint32_t s = 0;
+  for (int i = 0; i < n * n; i++) s += (uint32_t)iabs(d[i]);
+  if (dc_out) *dc_out = d[0];
+  return s;
+}
+uint32_t fho_had2x2(const int16_t* org, int so, const int16_t* cur, int sc) { return had_nxn(org, so, cur, sc, 2, 0); }
+uint32_t fho_had4x4(const int16_t* org, int so, const int16_t* cur, int sc) { return (had_nxn(org, so, cur, sc, 4, 0) + 1) >> 1; }
+uint32_t fho_had8x8(const int16_t* org, int so, const int16_t* cur, int sc) { return (had_nxn(org, so, cur, sc, 8, 0) + 2) >> 2; }
+
+/* TComRdCost.cpp:297-334 (calcHAD) and :1753-1824 (xGetHADs): tile choice and the final
+ * >> DISTORTION_PRECISION_ADJUSTMENT(bitDepth-8) (TypeDef.h:138-146, FULL_NBIT = 0). */
+uint32_t fho_satd(const int16_t* org, int so, const int16_t* cur, int sc, int w, int h, int bit_depth)
+{
+  uint32_t sum = 0;
+  int t = ((w % 8) == 0 && (h % 8) == 0) ? 8 : (((w % 4) == 0 && (h % 4) == 0) ? 4 : 2);
+  for (int y = 0; y < h; y += t)
+    for (int x = 0; x < w; x += t) {
+      const int16_t* o = org + y * so + x;
+      const int16_t* c = cur + y * sc + x;
+      sum += (t == 8) ? fho_had8x8(o, so, c, sc) : (t == 4) ? fho_had4x4(o, so, c, sc) : fho_had2x2(o, so, c, sc);
+    }
+  return sum >> (bit_depth - 8);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A6: xCalcHADs8x8_ISlice (TEncCu.cpp:1230-1322): Hadamard of the source block itself,
+ * sum |coef| minus |DC| (:1319), (s+2)>>2 (:1320).  updateCtuDataISlice (:1324-1343) sums it
+ * over every WHOLE 8x8 block inside width x height.
+ * ------------------------------------------------------------------------------------------ */
+int32_t fho_had8x8_src(const int16_t* org, int stride)
+{
+  int dc;
+  int s = (int)had_nxn(org, stride, 0, 0, 8, &dc);
+  s -= iabs(dc);
+  return (s + 2) >> 2;
+}
+int32_t fho_ctu_src_hadamard(const int16_t* ctu_org, int stride, int w, int h)
+{
+  int32_t sum = 0;
+  for (int y = 0; y + 8 <= h; y += 8)
+    for (int x = 0; x + 8 <= w; x += 8) sum += fho_had8x8_src(ctu_org + y * stride + x, stride);
+  return sum;
+}
+void fho_frame_src_hadamard(const int16_t* luma, int stride, int width, int height, int32_t* out)
+{
+  int cw = (width + CTU - 1) / CTU, ch = (height + CTU - 1) / CTU;
+  for (int cy = 0; cy < ch; cy++)
+    for (int cx = 0; cx < cw; cx++)
+      out[cy * cw + cx] = fho_ctu_src_hadamard(luma + (cy * CTU) * stride + cx * CTU, stride,
+                                                imin(CTU, width - cx * CTU), imin(CTU, height - cy * CTU));
+}
+
+/* A11: TEncSlice.cpp:433-527 with GOPSize 1 (no B frames), I slice, lambda modifiers 1.0,
+ * FULL_NBIT 0 (bitdepth_luma_qp_scale = 0): lambda = 0.57 * 2^((qp-12)/3). */
+double fho_lambda_intra(int qp, int bit_depth)
+{
+  (void)bit_depth;
+  return 0.57 * pow(2.0, ((double)qp - 12.0) / 3.0);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A7: reference samples.
+ * ------------------------------------------------------------------------------------------ */
+/* fillReferenceSamples (TComPattern.cpp:322-539) on a flag array in HM's order:
+ * flags[0 .. L-1] = left/below-left units bottom-to-top (flags[0] = lowest below-left),
+ * flags[L] = above-left, flags[L+1 .. L+A] = above/above-right units left-to-right, with
+ * L = A = 2N/4 units of 4 samples.  roi_origin points at the block's top-left sample. */
+void fho_fill_ref_flags(const int16_t* roi, int ps, const uint8_t* flags, int n, int bit_depth, int16_t* ref)
+{
+  const int U = 4;
+  const int L = 2 * n / U, A = 2 * n / U, total = L + A + 1;
+  const int dc = 1 << (bit_depth - 1);
+  int navail = 0;
+  for (int i = 0; i < total; i++) navail += flags[i] ? 1 : 0;
+  int16_t line[5 * CTU]; /* same linearisation as piIntraLine: left part bottom->top, TL unit, above */
+  const int nline = L * U + (A + 1) * U;
+  if (navail == 0) { /* :343-354 */
+    for (int i = 0; i < 4 * n + 1; i++) ref[i] = (int16_t)dc;
+    return;
+  }
+  for (int i = 0; i < nline; i++) line[i] = (int16_t)dc;
+  /* top-left (:399-414): replicated over one unit */
+  if (flags[L]) for (int i = 0; i < U; i++) line[L * U + i] = roi[-ps - 1];
+  /* left & below-left, downwards (:416-436): unit j (0 = adjacent to TL) sample i -> line[L*U-1 - (j*U+i)] */
+  for (int j = 0; j < L; j++)
+    if (flags[L - 1 - j])
+      for (int i = 0; i < U; i++) line[L * U - 1 - (j * U + i)] = roi[(j * U + i) * ps - 1];
+  /* above & above-right (:438-459) */
+  for (int j = 0; j < A; j++)
+    if (flags[L + 1 + j])
+      for (int i = 0; i < U; i++) line[L * U + U + j * U + i] = roi[-ps + j * U + i];
+  /* padding (:461-524) */
+  int cur = 0;
+  int16_t* p = line;
+  if (!flags[0]) {
+    int next = 1;
+    while (next < total && !flags[next]) next++;
+    const int16_t v = line[next * U]; /* unitWidth == unitHeight == 4 so both branches of :473 agree */
+    while (cur < next) { for (int i = 0; i < U; i++) p[i] = v; p += U; cur++; }
+  }
+  while (cur < total) {
+    if (!flags[cur]) { const int16_t v = p[-1]; for (int i = 0; i < U; i++) p[i] = v; }
+    p += U; cur++;
+  }
+  /* copy out (:526-537): our ref[] keeps the line order; TL = first sample of the TL unit's
+   * replicated run that the reference copies (piIntraLine + uiHeight + unitWidth - 2). */
+  /* left part: ref[2N-1-j] = left sample j = line[L*U-1-j] */
+  for (int j = 0; j < 2 * n; j++) ref[2 * n - 1 - j] = line[L * U - 1 - j];
+  ref[2 * n] = line[L * U + U - 1];
+  for (int i = 0; i < 2 * n; i++) ref[2 * n + 1 + i] = line[L * U + U + i];
+}
+
+/* coding-order availability of the 4x4 unit at picture position (ux,uy) [in samples] for a
+ * block whose top-left sample is (x0,y0): inside the picture and earlier in (CTU raster,
+ * z-order) order.  Equivalent to TComPattern.cpp:568-746 + TComDataCU::getPU* for one slice/tile,
+ * constrained intra prediction off. */
+static int unit_available(int ux, int uy, int x0, int y0, int width, int height)
+{
+  if (ux < 0 || uy < 0 || ux >= width || uy >= height) return 0;
+  ensure_tables();
+  int cw = (width + CTU - 1) / CTU;
+  int ca = (uy / CTU) * cw + ux / CTU, cb = (y0 / CTU) * cw + x0 / CTU;
+  if (ca != cb) return ca < cb;
+  int za = g_r2z[((uy % CTU) / 4) * UNITS + (ux % CTU) / 4];
+  int zb = g_r2z[((y0 % CTU) / 4) * UNITS + (x0 % CTU) / 4];
+  return za < zb;
+}
+
+void fho_fill_ref(const int16_t* luma, int stride, int width, int height,
+                  int x0, int y0, int n, int bit_depth, int16_t* ref)
+{
+  const int L = 2 * n / 4, A = 2 * n / 4;
+  uint8_t flags[2 * 32 + 1];
+  for (int j = 0; j < L; j++) /* flags[L-1-j] = left unit j counted downwards from the top */
+    flags[L - 1 - j] = (uint8_t)unit_available(x0 - 4, y0 + 4 * j, x0, y0, width, height);
+  flags[L] = (uint8_t)unit_available(x0 - 4, y0 - 4, x0, y0, width, height);
+  for (int j = 0; j < A; j++)
+    flags[L + 1 + j] = (uint8_t)unit_available(x0 + 4 * j, y0 - 4, x0, y0, width, height);
+  fho_fill_ref_flags(luma + y0 * stride + x0, stride, flags, n, bit_depth, ref);
+}
+
+/* TComPattern.cpp:196-295.  Ends (bottom-left, far right) are copied unfiltered. */
+void fho_filter_ref(const int16_t* ref, int n, int bit_depth, int strong_enabled, int16_t* out)
+{
+  const int last = 4 * n;
+  const int bl = ref[0], tl = ref[2 * n], tr = ref[4 * n];
+  int strong = 0;
+  if (strong_enabled && n >= 32) {
+    const int thr = 1 << (bit_depth - 5);
+    const int bil_left = iabs(bl + tl - 2 * ref[n]) < thr;
+    const int bil_above = iabs(tl + tr - 2 * ref[3 * n]) < thr;
+    strong = bil_left && bil_above;
+  }
+  out[0] = ref[0];
+  out[last] = ref[last];
+  if (strong) {
+    /* left column, bottom to top (:240-246): i = 1..2N-1 from the bottom-left corner */
+    const int shift = 0; (void)shift;
+    int lg = 0; while ((1 << lg) < 2 * n) lg++;
+    for (int i = 1; i < 2 * n; i++) out[i] = (int16_t)(((2 * n - i) * bl + i * tl + n) >> lg);
+    out[2 * n] = ref[2 * n];
+    for (int i = 1; i < 2 * n; i++) out[2 * n + i] = (int16_t)(((2 * n - i) * tl + i * tr + n) >> lg);
+  } else {
+    for (int i = 1; i < last; i++) out[i] = (int16_t)((ref[i - 1] + 2 * ref[i] + ref[i + 1] + 2) >> 2);
+  }
+}
+
+/* TComPattern.cpp:541-566 with m_aucIntraFilter[luma] = {10,7,1,0,10} (TComPrediction.cpp:50-58) */
+int fho_use_filtered_ref(int mode, int n)
+{
+  static const int thr[5] = { 10, 7, 1, 0, 10 };
+  if (mode == 1) return 0; /* DC */
+  int idx = 0; while ((4 << idx) < n) idx++;
+  int diff = imin(iabs(mode - 10), iabs(mode - 26));
+  return diff > thr[idx];
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A8: predictors.  Our ref line maps to HM's 2-D buffer as top[k] = ref[2N+k] (k = 0..2N,
+ * top[0] = TL) and left[k] = ref[2N-k] (left[0] = TL).
+ * ------------------------------------------------------------------------------------------ */
+static void pred_planar(const int16_t* ref, int n, int16_t* pred) /* TComPrediction.cpp:731-792 */
+{
+  const int16_t* top = ref + 2 * n + 1; /* top[k] = above sample k */
+  int lg = 0; while ((1 << lg) < n) lg++;
+  int leftc[CTU + 1], topr[CTU + 1], bot[CTU], right[CTU];
+  for (int k = 0; k < n + 1; k++) topr[k] = top[k];
+  for (int k = 0; k < n + 1; k++) leftc[k] = ref[2 * n - 1 - k];
+  const int bottom_left = leftc[n], top_right = topr[n];
+  for (int k = 0; k < n; k++) { bot[k] = bottom_left - topr[k]; topr[k] <<= lg; }
+  for (int k = 0; k < n; k++) { right[k] = top_right - leftc[k]; leftc[k] <<= lg; }
+  for (int y = 0; y < n; y++) {
+    int hor = leftc[y] + n;
+    for (int x = 0; x < n; x++) {
+      hor += right[y];
+      topr[x] += bot[x];
+      pred[y * n + x] = (int16_t)((hor + topr[x]) >> (lg + 1));
+    }
+  }
+}
+
+static void pred_ang(const int16_t* ref, int n, int mode, int bit_depth, int16_t* pred) /* :229-388 */
+{
+  static const int ang_table[9] = { 0, 2, 5, 9, 13, 17, 21, 26, 32 };
+  static const int inv_ang_table[9] = { 0, 4096, 1638, 910, 630, 482, 390, 315, 256 };
+  if (mode == 1) { /* DC (:244-255, predIntraGetPredValDC :183-201) + xDCPredFiltering (:794-818) */
+    int sum = 0;
+    for (int i = 0; i < n; i++) sum += ref[2 * n + 1 + i];
+    for (int i = 0; i < n; i++) sum += ref[2 * n - 1 - i];
+    const int dc = (sum + n) / (2 * n);
+    for (int i = 0; i < n * n; i++) pred[i] = (int16_t)dc;
+    if (n <= 16) {
+      pred[0] = (int16_t)((ref[2 * n + 1] + ref[2 * n - 1] + 2 * dc + 2) >> 2);
+      for (int x = 1; x < n; x++) pred[x] = (int16_t)((ref[2 * n + 1 + x] + 3 * dc + 2) >> 2);
+      for (int y = 1; y < n; y++) pred[y * n] = (int16_t)((ref[2 * n - 1 - y] + 3 * dc + 2) >> 2);
+    }
+    return;
+  }
+  const int is_ver = mode >= 18;
+  const int ang_mode = is_ver ? mode - 26 : -(mode - 10);
+  const int abs_mode = iabs(ang_mode);
+  const int sign = ang_mode < 0 ? -1 : 1;
+  const int edge = n <= 16;
+  const int inv_angle = inv_ang_table[abs_mode];
+  const int angle = sign * ang_table[abs_mode];
+  int16_t ref_above[2 * CTU + 1 + CTU], ref_left[2 * CTU + 1 + CTU];
+  int16_t *main_ref, *side_ref;
+  if (angle < 0) {
+    const int off = n - 1;
+    for (int x = 0; x < n + 1; x++) ref_above[x + off] = ref[2 * n + x];
+    for (int y = 0; y < n + 1; y++) ref_left[y + off] = ref[2 * n - y];
+    main_ref = (is_ver ? ref_above : ref_left) + off;
+    side_ref = (is_ver ? ref_left : ref_above) + off;
+    int inv_sum = 128;
+    for (int k = -1; k > ((n * angle) >> 5); k--) { /* refMainOffsetPreScale+1 == n for square blocks */
+      inv_sum += inv_angle;
+      main_ref[k] = side_ref[inv_sum >> 8];
+    }
+  } else {
+    for (int x = 0; x < 2 * n + 1; x++) ref_above[x] = ref[2 * n + x];
+    for (int y = 0; y < 2 * n + 1; y++) ref_left[y] = ref[2 * n - y];
+    main_ref = is_ver ? ref_above : ref_left;
+    side_ref = is_ver ? ref_left : ref_above;
+  }
+  int16_t tmp[CTU * CTU];
+  int16_t* dst = is_ver ? pred : tmp;
+  if (angle == 0) {
+    for (int y = 0; y < n; y++)
+      for (int x = 0; x < n; x++) dst[y * n + x] = main_ref[x + 1];
+    if (edge)
+      for (int y = 0; y < n; y++)
+        dst[y * n] = (int16_t)clip3(0, (1 << bit_depth) - 1, dst[y * n] + ((side_ref[y + 1] - side_ref[0]) >> 1));
+  } else {
+    int delta_pos = angle;
+    for (int y = 0; y < n; y++, delta_pos += angle) {
+      const int di = delta_pos >> 5, df = delta_pos & 31;
+      if (df) {
+        for (int x = 0; x < n; x++)
+          dst[y * n + x] = (int16_t)(((32 - df) * main_ref[x + di + 1] + df * main_ref[x + di + 2] + 16) >> 5);
+      } else {
+        for (int x = 0; x < n; x++) dst[y * n + x] = main_ref[x + di + 1];
+      }
+    }
+  }
+  if (!is_ver)
+    for (int y = 0; y < n; y++)
+      for (int x = 0; x < n; x++) pred[x * n + y] = tmp[y * n + x];
+}
+
+void fho_pred_intra(const int16_t* ref_unf, const int16_t* ref_filt, int n, int mode, int bit_depth, int16_t* pred)
+{
+  const int16_t* r = fho_use_filtered_ref(mode, n) ? ref_filt : ref_unf;
+  if (mode == 0) pred_planar(r, n, pred);
+  else pred_ang(r, n, mode, bit_depth, pred);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A4: first pass (TEncSearch.cpp:2233-2295).
+ * ------------------------------------------------------------------------------------------ */
+static int mode_bits_default_mpm(int mode)
+{
+  if (mode == 0) return 2;               /* flag + 1 bypass (MPM idx 0) */
+  if (mode == 1 || mode == 26) return 3; /* flag + 2 bypass (MPM idx 1, 2) */
+  return 6;                              /* flag + 5 bypass */
+}
+
+void fho_first_pass_node(const int16_t* luma, int stride, int width, int height,
+                         int x0, int y0, int n, int bit_depth, double sqrt_lambda,
+                         fho_node_cost* best, uint32_t satd_all[35])
+{
+  int16_t ref[4 * CTU + 1], reff[4 * CTU + 1];
+  static int16_t pred[CTU * CTU]; /* not re-entrant: test infrastructure */
+  fho_fill_ref(luma, stride, width, height, x0, y0, n, bit_depth, ref);
+  fho_filter_ref(ref, n, bit_depth, 1, reff);
+  best->cost = 1e300; best->mode = 0; best->satd = 0;
+  for (int m = 0; m < 35; m++) {
+    fho_pred_intra(ref, reff, n, m, bit_depth, pred);
+    uint32_t s = fho_satd(luma + y0 * stride + x0, stride, pred, n, n, n, bit_depth);
+    if (satd_all) satd_all[m] = s;
+    double c = (double)s + (double)mode_bits_default_mpm(m) * sqrt_lambda;
+    if (c < best->cost) { best->cost = c; best->mode = (uint32_t)m; best->satd = s; }
+  }
+}
+
+void fho_first_pass_ctu(const int16_t* luma, int stride, int width, int height,
+                        int ctu_x, int ctu_y, int bit_depth, double sqrt_lambda, fho_node_cost out[85])
+{
+  int idx = 0;
+  for (int lvl = 0; lvl < 4; lvl++) {
+    int n = CTU >> lvl, cnt = 1 << lvl;
+    for (int by = 0; by < cnt; by++)
+      for (int bx = 0; bx < cnt; bx++, idx++) {
+        int x0 = ctu_x * CTU + bx * n, y0 = ctu_y * CTU + by * n;
+        if (x0 + n > width || y0 + n > height) {
+          out[idx].satd = 0xFFFFFFFFu; out[idx].mode = 255; out[idx].cost = -1.0;
+        } else {
+          fho_first_pass_node(luma, stride, width, height, x0, y0, n, bit_depth, sqrt_lambda, &out[idx], 0);
+        }
+      }
+  }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A15: depth classifier (integer-valued).
+ * ------------------------------------------------------------------------------------------ */
+static inline uint8_t requant(int32_t acc, int shift)
+{
+  int32_t v = acc >> shift; /* arithmetic shift == floor(acc / 2^shift) */
+  return (uint8_t)clip3(0, 255, v);
+}
+
+void fho_cnn_ctu_debug(const fho_weights* w, const int8_t* ctu, uint8_t* a1o, uint8_t* a2o, uint8_t* a3o,
+                       int32_t logits[21][2])
+{
+  static uint8_t a1[32 * 32 * 16], a2[16 * 16 * 32], a3[16 * 16 * 64];
+  /* conv1 3x3 pad 1 on 64x64x1 -> maxpool 2x2 -> requant : [32][32][16] */
+  for (int py = 0; py < 32; py++)
+    for (int px = 0; px < 32; px++)
+      for (int oc = 0; oc < 16; oc++) {
+        int32_t best = INT32_MIN;
+        for (int sy = 0; sy < 2; sy++)
+          for (int sx = 0; sx < 2; sx++) {
+            int y = 2 * py + sy, x = 2 * px + sx;
+            int32_t acc = w->b1[oc];
+            for (int ky = 0; ky < 3; ky++)
+              for (int kx = 0; kx < 3; kx++) {
+                int yy = y + ky - 1, xx = x + kx - 1;
+                if (yy < 0 || yy >= 64 || xx < 0 || xx >= 64) continue;
+                acc += (int32_t)w->w1[oc * 9 + ky * 3 + kx] * (int32_t)ctu[yy * 64 + xx];
+              }
+            if (acc > best) best = acc;
+          }
+        a1[(py * 32 + px) * 16 + oc] = requant(best, w->shift[0]);
+      }
+  /* conv2 on 32x32x16 -> maxpool -> requant : [16][16][32] */
+  for (int py = 0; py < 16; py++)
+    for (int px = 0; px < 16; px++)
+      for (int oc = 0; oc < 32; oc++) {
+        int32_t best = INT32_MIN;
+        for (int sy = 0; sy < 2; sy++)
+          for (int sx = 0; sx < 2; sx++) {
+            int y = 2 * py + sy, x = 2 * px + sx;
+            int32_t acc = w->b2[oc];
+            for (int ky = 0; ky < 3; ky++)
+              for (int kx = 0; kx < 3; kx++) {
+                int yy = y + ky - 1, xx = x + kx - 1;
+                if (yy < 0 || yy >= 32 || xx < 0 || xx >= 32) continue;
+                const uint8_t* a = &a1[(yy * 32 + xx) * 16];
+                for (int ic = 0; ic < 16; ic++)
+                  acc += (int32_t)w->w2[((oc * 16 + ic) * 3 + ky) * 3 + kx] * (int32_t)a[ic];
+              }
+            if (acc > best) best = acc;
+          }
+        a2[(py * 16 + px) * 32 + oc] = requant(best, w->shift[1]);
+      }
+  /* conv3 on 16x16x32 -> requant (no pool) : [16][16][64] */
+  for (int y = 0; y < 16; y++)
+    for (int x = 0; x < 16; x++)
+      for (int oc = 0; oc < 64; oc++) {
+        int32_t acc = w->b3[oc];
+        for (int ky = 0; ky < 3; ky++)
+          for (int kx = 0; kx < 3; kx++) {
+            int yy = y + ky - 1, xx = x + kx - 1;
+            if (yy < 0 || yy >= 16 || xx < 0 || xx >= 16) continue;
+            const uint8_t* a = &a2[(yy * 16 + xx) * 32];
+            for (int ic = 0; ic < 32; ic++)
+              acc += (int32_t)w->w3[((oc * 32 + ic) * 3 + ky) * 3 + kx] * (int32_t)a[ic];
+          }
+        a3[(y * 16 + x) * 64 + oc] = requant(acc, w->shift[2]);
+      }
+  /* heads */
+  for (int cls = 0; cls < 2; cls++) {
+    /* 64-level: FC over maxpool2x2(a3) = [8][8][64] */
+    int32_t acc = w->bh64[cls];
+    for (int y = 0; y < 8; y++)
+      for (int x = 0; x < 8; x++)
+        for (int c = 0; c < 64; c++) {
+          int m = 0;
+          for (int sy = 0; sy < 2; sy++)
+            for (int sx = 0; sx < 2; sx++) m = imax(m, a3[((2 * y + sy) * 16 + 2 * x + sx) * 64 + c]);
+          acc += (int32_t)w->wh64[cls * 4096 + (y * 8 + x) * 64 + c] * m;
+        }
+    logits[0][cls] = acc;
+    /* 32-level: FC(8*8*64 -> 2) on each quadrant of a3 (the reference's classifier, Train...m:75-96) */
+    for (int q = 0; q < 4; q++) {
+      int qy = q >> 1, qx = q & 1;
+      acc = w->bh32[cls];
+      for (int y = 0; y < 8; y++)
+        for (int x = 0; x < 8; x++)
+          for (int c = 0; c < 64; c++)
+            acc += (int32_t)w->wh32[cls * 4096 + (y * 8 + x) * 64 + c] * a3[((qy * 8 + y) * 16 + qx * 8 + x) * 64 + c];
+      logits[1 + q][cls] = acc;
+    }
+    /* 16-level: FC(4*4*64 -> 2) on each 4x4 window */
+    for (int b = 0; b < 16; b++) {
+      int by = b >> 2, bx = b & 3;
+      acc = w->bh16[cls];
+      for (int y = 0; y < 4; y++)
+        for (int x = 0; x < 4; x++)
+          for (int c = 0; c < 64; c++)
+            acc += (int32_t)w->wh16[cls * 1024 + (y * 4 + x) * 64 + c] * a3[((by * 4 + y) * 16 + bx * 4 + x) * 64 + c];
+      logits[5 + b][cls] = acc;
+    }
+  }
+  if (a1o) memcpy(a1o, a1, sizeof a1);
+  if (a2o) memcpy(a2o, a2, sizeof a2);
+  if (a3o) memcpy(a3o, a3, sizeof a3);
+}
+
+void fho_cnn_ctu(const fho_weights* w, const int8_t* ctu, int32_t logits[21][2])
+{
+  fho_cnn_ctu_debug(w, ctu, 0, 0, 0, logits);
+}
+
+/* split decision: class 1 ("div", sortToDirLabels.m:11-19) wins only on a strict majority. */
+static inline int is_split(const int32_t l[2]) { return l[1] > l[0]; }
+
+void fho_depth_from_logits(const int32_t logits[21][2], int vw, int vh, uint8_t depth[256])
+{
+  memset(depth, 0, 256);
+  const int s64 = (vw < 64 || vh < 64) ? 1 : is_split(logits[0]);
+  for (int q = 0; q < 4; q++) {
+    const int qx = (q & 1) * 32, qy = (q >> 1) * 32;
+    if (qx >= vw || qy >= vh) continue; /* quadrant entirely outside the picture */
+    int d32;
+    if (!s64) d32 = 0;
+    else {
+      const int cross = (qx + 32 > vw) || (qy + 32 > vh);
+      d32 = (cross || is_split(logits[1 + q])) ? 2 : 1;
+    }
+    for (int b = 0; b < 4; b++) {
+      const int bx = qx + (b & 1) * 16, by = qy + (b >> 1) * 16;
+      if (bx >= vw || by >= vh) continue;
+      int d = d32;
+      if (d32 == 2) {
+        const int cross = (bx + 16 > vw) || (by + 16 > vh);
+        const int bi = (by / 16) * 4 + bx / 16;
+        d = (cross || is_split(logits[5 + bi])) ? 3 : 2;
+      }
+      for (int uy = 0; uy < 4; uy++)
+        for (int ux = 0; ux < 4; ux++) {
+          const int x = bx + ux * 4, y = by + uy * 4;
+          if (x < vw && y < vh) depth[(y / 4) * 16 + x / 4] = (uint8_t)d;
+        }
+    }
+  }
+}
+
+void fho_load_ctu(const int16_t* luma, int stride, int width, int height, int ctu_x, int ctu_y,
+                  int bit_depth, int8_t ctu[64 * 64])
+{
+  const int sh = bit_depth - 8;
+  for (int y = 0; y < 64; y++)
+    for (int x = 0; x < 64; x++) {
+      const int px = ctu_x * 64 + x, py = ctu_y * 64 + y;
+      int v = 0;
+      if (px < width && py < height) {
+        int p = luma[py * stride + px];
+        if (sh > 0) p = imin(255, (p + (1 << (sh - 1))) >> sh);
+        v = clip3(0, 255, p) - 128;
+      }
+      ctu[y * 64 + x] = (int8_t)v;
+    }
+}
+
+void fho_predict_frame(const fho_weights* w, const int16_t* luma, int stride, int width, int height,
+                       int bit_depth, uint8_t* depth_map, int32_t* logits_out)
+{
+  const int cw = (width + 63) / 64, ch = (height + 63) / 64;
+  int8_t ctu[64 * 64];
+  int32_t logits[21][2];
+  for (int cy = 0; cy < ch; cy++)
+    for (int cx = 0; cx < cw; cx++) {
+      const int a = cy * cw + cx;
+      fho_load_ctu(luma, stride, width, height, cx, cy, bit_depth, ctu);
+      fho_cnn_ctu(w, ctu, logits);
+      fho_depth_from_logits(logits, imin(64, width - cx * 64), imin(64, height - cy * 64), depth_map + a * 256);
+      if (logits_out) memcpy(logits_out + a * 42, logits, sizeof logits);
+    }
+}

@@ -1,0 +1,117 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/ref_vectors.npz by running the REFERENCE's own functions
+(oracle/_ref/libhmref.so = objects compiled from /root/reference + oracle/ref_harness.cpp).
+
+Run in the build container only (needs /root/reference):  make -C oracle ref && python oracle/gen_golden.py
+The fixture holds inputs and expected outputs (data), never reference source.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from oracle import oracle_py as op  # noqa: E402
+from fasthevc_amd import frames  # noqa: E402
+
+
+def main():
+    ref = op.load_ref()
+    out = {"hm_version": np.frombuffer(ref.href_version(), np.uint8)}
+    rng = np.random.default_rng(20261004)
+
+    # --- scan tables (A14)
+    r2z = np.zeros(256, np.uint32)
+    z2r = np.zeros(256, np.uint32)
+    ref.href_scan_tables(r2z, z2r)
+    out["raster_to_zscan"], out["zscan_to_raster"] = r2z, z2r
+
+    # --- SATD (A5): calcHAD and xGetHADs, 8- and 10-bit, square and rectangular
+    shapes = [(4, 4), (8, 8), (16, 16), (32, 32), (64, 64), (8, 4), (4, 8), (16, 8), (8, 16), (32, 8), (16, 4), (2, 2), (6, 6)]
+    satd_a, satd_b, satd_meta, satd_calc, satd_get = [], [], [], [], []
+    for bd in (8, 10):
+        for (w, h) in shapes:
+            for rep in range(3):
+                hi = (1 << bd) - 1
+                if rep == 2:  # extremes: exercises the largest intermediates
+                    a = rng.choice(np.array([0, hi], np.int16), size=(64, 64))
+                    b = rng.choice(np.array([0, hi], np.int16), size=(64, 64))
+                else:
+                    a = rng.integers(0, hi + 1, size=(64, 64)).astype(np.int16)
+                    b = np.clip(a + rng.normal(0, 12 * (1 << (bd - 8)), size=(64, 64)), 0, hi).astype(np.int16)
+                g = ref.href_get_hads(bd, op.ptr(a), 64, op.ptr(b), 64, w, h)
+                c = ref.href_calc_had(bd, op.ptr(a), 64, op.ptr(b), 64, w, h) if (w % 4 == 0 and h % 4 == 0) else 0xFFFFFFFF
+                satd_a.append(a); satd_b.append(b); satd_meta.append((bd, w, h)); satd_calc.append(c); satd_get.append(g)
+    out["satd_a"] = np.stack(satd_a); out["satd_b"] = np.stack(satd_b)
+    out["satd_meta"] = np.array(satd_meta, np.int32)
+    out["satd_calchad"] = np.array(satd_calc, np.uint32); out["satd_gethads"] = np.array(satd_get, np.uint32)
+
+    # --- source Hadamard (A6): single blocks + per-CTU sums of the pinned synthetic frames
+    blk = rng.integers(0, 1024, size=(16, 8, 8)).astype(np.int16)
+    out["islice_blocks"] = blk
+    out["islice_expected"] = np.array([ref.href_had8x8_islice(op.ptr(np.ascontiguousarray(b)), 8) for b in blk], np.int32)
+    for name, (w, h, bd) in {"t16_416x240_8": (416, 240, 8), "t16_416x240_10": (416, 240, 10), "t16_1920x1080_8": (1920, 1080, 8)}.items():
+        luma = frames.texture16_luma(w, h)
+        buf, org, stride = frames.to_pel_plane(luma, bd)
+        flat = buf.reshape(-1)
+        cw, ch = frames.ctu_grid(w, h)
+        vals = np.zeros(cw * ch, np.int32)
+        for cy in range(ch):
+            for cx in range(cw):
+                vals[cy * cw + cx] = ref.href_ctu_src_hadamard(op.ptr(flat, org + cy * 64 * stride + cx * 64), stride,
+                                                               min(64, w - cx * 64), min(64, h - cy * 64))
+        out["ctu_had_" + name] = vals
+
+    # --- reference-sample fill (A7) on random availability patterns
+    fr_roi, fr_flags, fr_n, fr_bd, fr_out = [], [], [], [], []
+    for n in (4, 8, 16, 32, 64):
+        for rep in range(6):
+            bd = 8 if rep % 2 == 0 else 10
+            pic = rng.integers(0, 1 << bd, size=(2 * n + 8, 2 * n + 8)).astype(np.int16)
+            units = 2 * n // 4
+            if rep == 0:
+                flags = np.ones(2 * units + 1, np.uint8)
+            elif rep == 1:
+                flags = np.zeros(2 * units + 1, np.uint8)
+            else:
+                flags = (rng.random(2 * units + 1) < (0.3 + 0.2 * rep / 6)).astype(np.uint8)
+                if rep == 5:
+                    flags[:units] = 0  # nothing below/left available -> exercises the "search upward" padding
+            roi = np.zeros((2 * n + 1) * (2 * n + 1), np.int16)
+            stride = pic.shape[1]
+            ref.href_fill_ref(bd, op.ptr(pic.reshape(-1), 4 * stride + 4), stride, flags, n, roi)
+            full = np.zeros((129, 129), np.int16)
+            full[:2 * n + 1, :2 * n + 1] = roi.reshape(2 * n + 1, 2 * n + 1)
+            padded = np.zeros((136, 136), np.int16)
+            padded[:pic.shape[0], :pic.shape[1]] = pic
+            fl = np.zeros(65, np.uint8); fl[:flags.size] = flags
+            fr_roi.append(padded); fr_flags.append(fl); fr_n.append(n); fr_bd.append(bd); fr_out.append(full)
+    out["fill_pic"] = np.stack(fr_roi); out["fill_flags"] = np.stack(fr_flags)
+    out["fill_n"] = np.array(fr_n, np.int32); out["fill_bd"] = np.array(fr_bd, np.int32); out["fill_out"] = np.stack(fr_out)
+
+    # --- filter decision table (A7) and the 35 predictors (A8)
+    out["use_filtered"] = np.array([[ref.href_use_filtered(m, n) for m in range(35)] for n in (4, 8, 16, 32, 64)], np.uint8)
+    for n in (4, 8, 16, 32, 64):
+        reps = 2 if n <= 32 else 1
+        for rep in range(reps):
+            bd = 8 if rep == 0 else 10
+            line = np.clip(rng.integers(0, 1 << bd, size=4 * n + 1) * (0.5 + 0.5 * rng.random()), 0, (1 << bd) - 1).astype(np.int16)
+            if rep == 1:
+                line[::7] = (1 << bd) - 1  # saturating samples for the edge-filter clip
+            roi = np.ascontiguousarray(op.ref_line_to_roi(line, n).reshape(-1))
+            preds = np.zeros((35, n, n), np.int16)
+            for m in range(35):
+                p = np.zeros(n * n, np.int16)
+                ref.href_pred_intra(roi, n, m, bd, p)
+                preds[m] = p.reshape(n, n)
+            out[f"pred_line_n{n}_bd{bd}"] = line
+            out[f"pred_out_n{n}_bd{bd}"] = preds
+
+    dst = os.path.join(os.path.dirname(HERE), "tests", "golden", "ref_vectors.npz")
+    np.savez_compressed(dst, **out)
+    print("wrote", dst, os.path.getsize(dst), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,150 @@
+"""ctypes bindings for oracle/libfhevc_oracle.so (the CPU restatement) and, when present,
+oracle/_ref/libhmref.so (the reference's own objects behind oracle/ref_harness.cpp).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg.  Nothing under fasthevc_amd/ imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_SO = os.path.join(HERE, "libfhevc_oracle.so")
+REF_SO = os.path.join(HERE, "_ref", "libhmref.so")
+
+_i16p = np.ctypeslib.ndpointer(dtype=np.int16, flags="C_CONTIGUOUS")
+_u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+_i8p = np.ctypeslib.ndpointer(dtype=np.int8, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+_u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+_u16p = np.ctypeslib.ndpointer(dtype=np.uint16, flags="C_CONTIGUOUS")
+
+
+class NodeCost(C.Structure):
+    _fields_ = [("satd", C.c_uint32), ("mode", C.c_uint32), ("cost", C.c_double)]
+
+
+class Weights(C.Structure):
+    """Mirror of fho_weights (oracle/fhevc_oracle.h)."""
+    _fields_ = [
+        ("shift", C.c_int32 * 3),
+        ("w1", C.c_int8 * (16 * 9)), ("b1", C.c_int32 * 16),
+        ("w2", C.c_int8 * (32 * 16 * 9)), ("b2", C.c_int32 * 32),
+        ("w3", C.c_int8 * (64 * 32 * 9)), ("b3", C.c_int32 * 64),
+        ("wh64", C.c_int8 * (2 * 4096)), ("bh64", C.c_int32 * 2),
+        ("wh32", C.c_int8 * (2 * 4096)), ("bh32", C.c_int32 * 2),
+        ("wh16", C.c_int8 * (2 * 1024)), ("bh16", C.c_int32 * 2),
+    ]
+
+
+def build_oracle():
+    subprocess.check_call(["make", "-s", "-C", HERE, "oracle"])
+
+
+def load_oracle():
+    if not os.path.exists(ORACLE_SO):
+        build_oracle()
+    lib = C.CDLL(ORACLE_SO)
+    lib.fho_init_scan_tables.argtypes = [_u16p, _u16p]
+    lib.fho_depth_to_split_flags.argtypes = [_u8p, _u8p]
+    lib.fho_depth_to_split_flags.restype = C.c_int
+    lib.fho_split_flags_to_depth.argtypes = [_u8p, C.c_int, _u8p]
+    lib.fho_split_flags_to_depth.restype = C.c_int
+    lib.fho_compare_split_mode.argtypes = [_u8p, _u8p]
+    lib.fho_compare_split_mode.restype = C.c_int
+    lib.fho_depth_raster_to_zorder.argtypes = [_u8p, _u8p]
+    lib.fho_depth_zorder_to_raster.argtypes = [_u8p, _u8p]
+    for name in ("fho_had2x2", "fho_had4x4", "fho_had8x8"):
+        f = getattr(lib, name)
+        f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        f.restype = C.c_uint32
+    lib.fho_satd.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.fho_satd.restype = C.c_uint32
+    lib.fho_had8x8_src.argtypes = [C.c_void_p, C.c_int]
+    lib.fho_had8x8_src.restype = C.c_int32
+    lib.fho_ctu_src_hadamard.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    lib.fho_ctu_src_hadamard.restype = C.c_int32
+    lib.fho_frame_src_hadamard.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _i32p]
+    lib.fho_lambda_intra.argtypes = [C.c_int, C.c_int]
+    lib.fho_lambda_intra.restype = C.c_double
+    lib.fho_fill_ref.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _i16p]
+    lib.fho_fill_ref_flags.argtypes = [C.c_void_p, C.c_int, _u8p, C.c_int, C.c_int, _i16p]
+    lib.fho_filter_ref.argtypes = [_i16p, C.c_int, C.c_int, C.c_int, _i16p]
+    lib.fho_use_filtered_ref.argtypes = [C.c_int, C.c_int]
+    lib.fho_use_filtered_ref.restype = C.c_int
+    lib.fho_pred_intra.argtypes = [_i16p, _i16p, C.c_int, C.c_int, C.c_int, _i16p]
+    lib.fho_first_pass_node.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_double, C.POINTER(NodeCost), C.c_void_p]
+    lib.fho_first_pass_ctu.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_double, C.POINTER(NodeCost)]
+    lib.fho_cnn_ctu.argtypes = [C.POINTER(Weights), _i8p, _i32p]
+    lib.fho_cnn_ctu_debug.argtypes = [C.POINTER(Weights), _i8p, _u8p, _u8p, _u8p, _i32p]
+    lib.fho_depth_from_logits.argtypes = [_i32p, C.c_int, C.c_int, _u8p]
+    lib.fho_load_ctu.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _i8p]
+    lib.fho_predict_frame.argtypes = [C.POINTER(Weights), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _u8p, C.c_void_p]
+    return lib
+
+
+def have_ref():
+    return os.path.exists(REF_SO)
+
+
+def load_ref():
+    """Open oracle/_ref/libhmref.so with RTLD_LAZY (one never-called reference symbol stays unresolved:
+    see oracle/Makefile)."""
+    libdl = C.CDLL(None)
+    libdl.dlopen.restype = C.c_void_p
+    libdl.dlopen.argtypes = [C.c_char_p, C.c_int]
+    handle = libdl.dlopen(REF_SO.encode(), os.RTLD_LAZY | os.RTLD_LOCAL)
+    if not handle:
+        raise OSError("cannot dlopen " + REF_SO)
+    lib = C.CDLL(REF_SO, handle=handle)
+    lib.href_version.restype = C.c_char_p
+    for name in ("href_calc_had", "href_get_hads"):
+        f = getattr(lib, name)
+        f.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        f.restype = C.c_uint32
+    lib.href_had8x8_islice.argtypes = [C.c_void_p, C.c_int]
+    lib.href_had8x8_islice.restype = C.c_int32
+    lib.href_ctu_src_hadamard.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    lib.href_ctu_src_hadamard.restype = C.c_int32
+    lib.href_scan_tables.argtypes = [_u32p, _u32p]
+    lib.href_fill_ref.argtypes = [C.c_int, C.c_void_p, C.c_int, _u8p, C.c_int, _i16p]
+    lib.href_use_filtered.argtypes = [C.c_int, C.c_int]
+    lib.href_use_filtered.restype = C.c_int
+    lib.href_pred_intra.argtypes = [_i16p, C.c_int, C.c_int, C.c_int, _i16p]
+    return lib
+
+
+def ptr(a, offset_elems=0):
+    """Raw pointer into a numpy array (keeps no reference: the caller holds the array)."""
+    return C.c_void_p(a.ctypes.data + offset_elems * a.itemsize)
+
+
+def weights_from_arrays(d):
+    """dict of numpy arrays (fasthevc_amd.weights layout) -> Weights struct."""
+    w = Weights()
+    for k in ("shift", "w1", "b1", "w2", "b2", "w3", "b3", "wh64", "bh64", "wh32", "bh32", "wh16", "bh16"):
+        arr = np.ascontiguousarray(d[k]).reshape(-1)
+        field = getattr(w, k)
+        assert len(field) == arr.size, (k, len(field), arr.size)
+        C.memmove(field, arr.ctypes.data, arr.nbytes)
+    return w
+
+
+def ref_line_to_roi(ref, n):
+    """our 4N+1 reference line -> HM's (2N+1)x(2N+1) ROI buffer (row 0 = TL+above, col 0 = TL+left)."""
+    sw = 2 * n + 1
+    roi = np.zeros((sw, sw), np.int16)
+    roi[0, :] = ref[2 * n:]
+    roi[1:, 0] = ref[:2 * n][::-1]
+    return roi
+
+
+def roi_to_ref_line(roi, n):
+    ref = np.zeros(4 * n + 1, np.int16)
+    ref[2 * n:] = roi[0, :]
+    ref[:2 * n] = roi[1:, 0][::-1]
+    return ref
