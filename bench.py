@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""bench.py -- CTU depth decisions/s of the MI355X fast-decision path (BASELINE.json metric).
+
+One step = one pass of the hot path (CTU load -> source Hadamard -> depth CNN -> depth map in HBM) over one GOP of
+synthetic 1080p luma already resident in HBM.  N > 1: one process per GPU (torch.distributed, "nccl" = RCCL over
+xGMI), every rank owns its own GOP (frames dealt to ranks: weak scaling) and the step ends with the single
+all-gather of the depth maps.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic work per CTU: MACs of the three conv layers + the three FC heads
+MAC_PER_CTU = 4096 * 9 * 16 + 1024 * 144 * 32 + 256 * 288 * 64 + (4096 + 4 * 4096 + 16 * 1024) * 2
+FLOP_PER_CTU = 2 * MAC_PER_CTU
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline(width, height, bit_depth, w, seconds=12.0):
+    """The oracle (CPU restatement, 1 thread) on a bounded sample of the same workload."""
+    from oracle import oracle_py as op
+    from fasthevc_amd import frames
+    oracle = op.load_oracle()
+    ws = op.weights_from_arrays(w)
+    luma = frames.hetero_luma(width, height)
+    buf, org, stride = frames.to_pel_plane(luma, bit_depth)
+    cw, ch = frames.ctu_grid(width, height)
+    ctu = np.zeros(64 * 64, np.int8)
+    logits = np.zeros(42, np.int32)
+    depth = np.zeros(256, np.uint8)
+    done, t0 = 0, time.perf_counter()
+    order = np.random.default_rng(0).permutation(cw * ch)
+    for a in order:
+        cx, cy = int(a % cw), int(a // cw)
+        oracle.fho_load_ctu(op.ptr(buf.reshape(-1), org), stride, width, height, cx, cy, bit_depth, ctu)
+        oracle.fho_cnn_ctu(ws, ctu, logits)
+        oracle.fho_depth_from_logits(logits, min(64, width - cx * 64), min(64, height - cy * 64), depth)
+        oracle.fho_ctu_src_hadamard(op.ptr(buf.reshape(-1), org + cy * 64 * stride + cx * 64), stride,
+                                    min(64, width - cx * 64), min(64, height - cy * 64))
+        done += 1
+        if time.perf_counter() - t0 > seconds:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "CTU depth decisions/s", "cores": 1, "kind": "port",
+            "sample": f"{done} CTUs of the same 1080p hetero frame through oracle/fhevc_oracle.c "
+                      f"(depth CNN + source Hadamard, 1 thread, {dt:.1f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=64, help="frames per GOP (per rank)")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--bit-depth", type=int, default=8)
+    ap.add_argument("--sample-bytes", type=int, default=2, help="2 = int16 Pel planes as HM holds them, 1 = uint8")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from fasthevc_amd import bands, capi, frames, weights
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    W, H, NF, bd = args.width, args.height, args.frames, args.bit_depth
+    w = weights.random_weights(0)   # random-init weights of the shipped architecture (synthetic bench)
+    ctx = capi.Context(W, H, bd, w, device=local, max_frames=NF)
+    cw, ch, n_ctus = ctx.ctus_x, ctx.ctus_y, ctx.num_ctus
+
+    # synthetic GOP resident in HBM: the pinned "hetero" frame, panned 3 px per frame, per-rank phase
+    base = torch.from_numpy(frames.hetero_luma(W, H).astype(np.int16)).to(dev) << (bd - 8)
+    if args.sample_bytes == 2:
+        margin = frames.HM_MARGIN
+        stride, rows = W + 2 * margin, H + 2 * margin
+        gop = torch.zeros((NF, rows, stride), dtype=torch.int16, device=dev)
+        for f in range(NF):
+            gop[f, margin:margin + H, margin:margin + W] = torch.roll(base, shifts=3 * (f + NF * rank), dims=1)
+        origin, frame_stride = margin * stride + margin, rows * stride
+        luma_ptr = gop.data_ptr() + 2 * origin
+    else:
+        assert bd == 8
+        stride, frame_stride = W, W * H
+        gop = torch.stack([torch.roll(base, shifts=3 * (f + NF * rank), dims=1) for f in range(NF)]).to(torch.uint8).contiguous()
+        luma_ptr = gop.data_ptr()
+
+    gathered = torch.zeros((world, NF, n_ctus, 256), dtype=torch.uint8, device=dev)
+    had = torch.zeros((NF, n_ctus), dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        ctx.predict_frames_device(luma_ptr, args.sample_bytes, stride, frame_stride, NF, gathered[rank].data_ptr(),
+                                  had.data_ptr(), None, stream=stream)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered.view(-1), gathered[rank].view(-1))
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ctx.enable_kernel_timing(True)
+    ctx.kernel_timing(0, reset=True)
+    ctx.kernel_timing(1, reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    cnn_ms, cnn_n = ctx.kernel_timing(0)
+    had_ms, had_n = ctx.kernel_timing(1)
+    ctx.enable_kernel_timing(False)
+
+    if rank == 0:
+        ctus_per_step = world * NF * n_ctus
+        value = ctus_per_step * args.steps / dt
+        flop_per_launch = FLOP_PER_CTU * NF * n_ctus
+        sample_b = args.sample_bytes
+        bytes_per_launch_had = NF * (W * H * sample_b + n_ctus * 4)
+        roof = {"bound": "mfma", "kernel": "fhevc_cnn_depth_kernel", "achieved": flop_per_launch / (cnn_ms * 1e-3) / 1e12 if cnn_ms else None,
+                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "traffic": None,
+                "avg_launch_ms": cnn_ms, "launches": cnn_n, "flop_per_ctu": FLOP_PER_CTU}
+        roof["frac"] = roof["achieved"] / roof["peak"] if roof["achieved"] else None
+        hbm = {"bound": "hbm", "kernel": "fhevc_src_hadamard_kernel", "achieved": bytes_per_launch_had / (had_ms * 1e-3) / 1e9 if had_ms else None,
+               "peak": PEAK_HBM_GBS, "unit": "GB/s", "traffic": None, "avg_launch_ms": had_ms, "launches": had_n,
+               "bytes_per_launch": bytes_per_launch_had}
+        hbm["frac"] = hbm["achieved"] / hbm["peak"] if hbm["achieved"] else None
+        line = {
+            "metric": "CTU depth decisions/sec at 1080p all-intra", "value": value, "unit": "CTU/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16 operands / f32 accumulate (fixed-point valued, exact)", "data": "synthetic",
+            "config": {"workload": f"BQTerrace geometry {W}x{H} all-intra QP32, GOP of {NF} synthetic 'hetero' frames per GPU "
+                                   f"({'int16 Pel planes, HM stride/margins' if sample_b == 2 else 'uint8 planes'}) resident in HBM, "
+                                   f"source Hadamard + CTU-batched CNN depth predictor, random-init weights",
+                       "frames_per_gpu": NF, "ctus_per_frame": n_ctus, "bit_depth": bd,
+                       "sharding": "frames dealt to ranks + one all-gather of the depth maps" if world > 1 else "single GPU"},
+            "roofline": roof, "roofline_hbm_kernel": hbm,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(W, H, bd, w)
+        print(json.dumps(line), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,172 @@
+"""ctypes mirror of include/fasthevc.h -- the host-side view of the C ABI used by tests, the trainer and bench.py.
+
+There is no fallback: if the HIP library is missing or no gfx950 device is usable, calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import weights as _weights
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libfasthevc_hip.so")
+
+OK, E_INVALID, E_NO_DEVICE, E_HIP, E_WEIGHTS, E_NOMEM, E_STATE = 0, -1, -2, -3, -4, -5, -6
+BACKEND_HIP = 1
+NODES_PER_CTU = 85
+LOGITS_PER_CTU = 42
+
+# every symbol include/fasthevc.h declares (tests/test_capi_symbols.py checks header <-> this list <-> the .so)
+SYMBOLS = [
+    "fhevc_create", "fhevc_destroy", "fhevc_set_weights", "fhevc_predict_frame", "fhevc_satd",
+    "fhevc_intra_first_pass", "fhevc_predict_frames_device", "fhevc_band", "fhevc_kernel_timing",
+    "fhevc_enable_kernel_timing", "fhevc_get_stats", "fhevc_last_error", "fhevc_version",
+]
+
+
+class Cfg(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("bit_depth", C.c_int), ("ctu_size", C.c_int),
+                ("max_depth", C.c_int), ("num_devices", C.c_int), ("device_ids", C.POINTER(C.c_int)),
+                ("weights_path", C.c_char_p), ("backend", C.c_int), ("max_frames", C.c_int)]
+
+
+class NodeCost(C.Structure):
+    _fields_ = [("satd", C.c_uint32), ("mode", C.c_uint32), ("cost", C.c_double)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("frames", C.c_uint64), ("ctus", C.c_uint64), ("bytes_h2d", C.c_uint64), ("bytes_d2h", C.c_uint64),
+                ("kernels_launched", C.c_uint64), ("ms_h2d", C.c_double), ("ms_kernels", C.c_double),
+                ("ms_d2h", C.c_double), ("last_cnn_ms", C.c_double), ("last_hadamard_ms", C.c_double),
+                ("last_first_pass_ms", C.c_double)]
+
+
+NODE_DTYPE = np.dtype([("satd", np.uint32), ("mode", np.uint32), ("cost", np.float64)])
+
+
+class FastHevcError(RuntimeError):
+    def __init__(self, code, text=""):
+        super().__init__(f"fasthevc error {code}: {text}")
+        self.code = code
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen the in-tree HIP library; raises if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(f"{LIB_PATH} not built: run `python -m fasthevc_amd.build` (or __graft_entry__.build())")
+    lib = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    lib.fhevc_create.argtypes = [C.POINTER(vp), C.POINTER(Cfg)]
+    lib.fhevc_destroy.argtypes = [vp]
+    lib.fhevc_destroy.restype = None
+    lib.fhevc_set_weights.argtypes = [vp, C.c_char_p, C.c_size_t]
+    lib.fhevc_predict_frame.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]
+    lib.fhevc_satd.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32)]
+    lib.fhevc_intra_first_pass.argtypes = [vp, vp, C.c_int, C.c_int, vp]
+    lib.fhevc_predict_frames_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_int,
+                                                vp, vp, vp, vp]
+    lib.fhevc_band.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.fhevc_kernel_timing.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    lib.fhevc_enable_kernel_timing.argtypes = [vp, C.c_int]
+    lib.fhevc_get_stats.argtypes = [vp, vp, C.c_size_t]
+    lib.fhevc_last_error.argtypes = [vp]
+    lib.fhevc_last_error.restype = C.c_char_p
+    lib.fhevc_version.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def band(ctu_rows, rank, world):
+    b, e = C.c_int(), C.c_int()
+    rc = load_library().fhevc_band(ctu_rows, rank, world, C.byref(b), C.byref(e))
+    if rc != OK:
+        raise FastHevcError(rc, "fhevc_band")
+    return b.value, e.value
+
+
+class Context:
+    """One fhevc_ctx: one picture geometry on one MI355X."""
+
+    def __init__(self, width, height, bit_depth=8, weights=None, device=0, max_frames=1):
+        self.lib = load_library()
+        self.width, self.height, self.bit_depth = width, height, bit_depth
+        self.ctus_x, self.ctus_y = (width + 63) // 64, (height + 63) // 64
+        self.num_ctus = self.ctus_x * self.ctus_y
+        dev = (C.c_int * 1)(device)
+        cfg = Cfg(width, height, bit_depth, 64, 3, 1, dev, None, BACKEND_HIP, max_frames)
+        h = C.c_void_p()
+        rc = self.lib.fhevc_create(C.byref(h), C.byref(cfg))
+        if rc != OK:
+            raise FastHevcError(rc, "fhevc_create (no gfx950 device?)" if rc == E_NO_DEVICE else "fhevc_create")
+        self.h = h
+        if weights is not None:
+            self.set_weights(weights)
+
+    def _check(self, rc):
+        if rc != OK:
+            raise FastHevcError(rc, self.lib.fhevc_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.fhevc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def set_weights(self, w):
+        blob = w if isinstance(w, (bytes, bytearray)) else _weights.pack(w)
+        self._check(self.lib.fhevc_set_weights(self.h, bytes(blob), len(blob)))
+
+    def predict_frame(self, plane, origin=0, stride=None, qp=32, slice_type=2, want_hadamard=True):
+        """plane: int16 numpy buffer holding a Pel plane; origin = element offset of sample (0,0)."""
+        flat = np.ascontiguousarray(plane).reshape(-1)
+        assert flat.dtype == np.int16
+        stride = stride if stride is not None else plane.shape[-1]
+        depth = np.zeros(self.num_ctus * 256, np.uint8)
+        had = np.zeros(self.num_ctus, np.int32) if want_hadamard else None
+        self._check(self.lib.fhevc_predict_frame(self.h, flat.ctypes.data + 2 * origin, stride, qp, slice_type,
+                                                 depth.ctypes.data, had.ctypes.data if want_hadamard else None))
+        return depth.reshape(self.num_ctus, 256), had
+
+    def satd(self, org, cur, w, h, bit_depth=8, org_stride=None, cur_stride=None):
+        org = np.ascontiguousarray(org, np.int16)
+        cur = np.ascontiguousarray(cur, np.int16)
+        out = C.c_uint32()
+        self._check(self.lib.fhevc_satd(self.h, org.ctypes.data, org_stride or org.shape[-1], cur.ctypes.data,
+                                        cur_stride or cur.shape[-1], w, h, bit_depth, C.byref(out)))
+        return out.value
+
+    def intra_first_pass(self, plane, origin=0, stride=None, qp=32):
+        flat = np.ascontiguousarray(plane).reshape(-1)
+        stride = stride if stride is not None else plane.shape[-1]
+        out = np.zeros(self.num_ctus * NODES_PER_CTU, NODE_DTYPE)
+        self._check(self.lib.fhevc_intra_first_pass(self.h, flat.ctypes.data + 2 * origin, stride, qp, out.ctypes.data))
+        return out.reshape(self.num_ctus, NODES_PER_CTU)
+
+    def predict_frames_device(self, d_luma, sample_bytes, stride, frame_stride, num_frames, d_depth, d_hadamard=None,
+                              d_logits=None, rows=None, stream=None):
+        """All pointers are raw device addresses (e.g. torch.Tensor.data_ptr()); asynchronous."""
+        rb, re = rows if rows is not None else (0, self.ctus_y)
+        self._check(self.lib.fhevc_predict_frames_device(self.h, d_luma, sample_bytes, stride, frame_stride, num_frames,
+                                                         rb, re, d_depth, d_hadamard, d_logits, stream))
+
+    def enable_kernel_timing(self, on=True):
+        self._check(self.lib.fhevc_enable_kernel_timing(self.h, 1 if on else 0))
+
+    def kernel_timing(self, which, reset=False):
+        ms, n = C.c_double(), C.c_uint64()
+        self._check(self.lib.fhevc_kernel_timing(self.h, which, 1 if reset else 0, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def stats(self):
+        s = Stats()
+        self._check(self.lib.fhevc_get_stats(self.h, C.byref(s), C.sizeof(s)))
+        return {k: getattr(s, k) for k, _ in Stats._fields_}

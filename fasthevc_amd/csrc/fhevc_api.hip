@@ -1,0 +1,425 @@
+// fhevc_api.hip -- the C ABI of include/fasthevc.h: context, weight image, staging buffers, launches.
+// Host-side C++ only; all device work is in k_cnn.hip / k_hadamard.hip / k_firstpass.hip.
+#include "../../include/fasthevc.h"
+#include "fhevc_internal.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct TimedLaunch { hipEvent_t start, stop; int which; };
+
+}  // namespace
+
+struct fhevc_ctx {
+  fhevc_cfg cfg{};
+  int device = 0, num_cus = 256;
+  hipStream_t stream = nullptr;
+  int ctus_x = 0, ctus_y = 0, num_ctus = 0;
+  int dev_stride = 0;  // samples, staging plane
+  // weight image
+  bool have_weights = false;
+  uint4* d_frag = nullptr; float* d_bias = nullptr; uint8_t* d_whead = nullptr; int32_t* d_bhead = nullptr;
+  float scale[3] = { 1, 1, 1 };
+  // staging for the host-buffer entry points
+  int16_t* d_luma = nullptr; uint8_t* d_depth = nullptr; int32_t* d_had = nullptr; FhevcNodeCost* d_nodes = nullptr;
+  int16_t* d_satd = nullptr; uint32_t* d_satd_out = nullptr;
+  hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
+  // kernel timing
+  bool timing = false;
+  std::vector<TimedLaunch> pending;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+  double sum_ms[3] = { 0, 0, 0 };
+  uint64_t launches[3] = { 0, 0, 0 };
+  fhevc_stats stats{};
+  std::string err;
+};
+
+namespace {
+
+int fail(fhevc_ctx* c, int code, const char* what, hipError_t e = hipSuccess)
+{
+  if (c) {
+    c->err = what;
+    if (e != hipSuccess) { c->err += ": "; c->err += hipGetErrorString(e); }
+  }
+  return code;
+}
+
+#define HIP_TRY(c, call)                                                   \
+  do {                                                                     \
+    hipError_t e_ = (call);                                                \
+    if (e_ != hipSuccess) return fail((c), FHEVC_E_HIP, #call, e_);        \
+  } while (0)
+
+inline uint16_t bf16_of_small_int(int v)  // |v| <= 256: exact
+{
+  float f = (float)v;
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  return (uint16_t)(u >> 16);
+}
+
+// FHW1 blob layout (fasthevc_amd/weights.py)
+struct BlobView {
+  const int32_t* shift;
+  const int8_t* w1; const int32_t* b1;
+  const int8_t* w2; const int32_t* b2;
+  const int8_t* w3; const int32_t* b3;
+  const int8_t* wh64; const int32_t* bh64;
+  const int8_t* wh32; const int32_t* bh32;
+  const int8_t* wh16; const int32_t* bh16;
+};
+constexpr size_t kBlobBytes = 8 + 12 + 144 + 64 + 4608 + 128 + 18432 + 256 + 8192 + 8 + 8192 + 8 + 2048 + 8;
+
+bool parse_blob(const uint8_t* p, size_t n, BlobView& v, std::vector<uint8_t>& aligned)
+{
+  if (n != kBlobBytes || std::memcmp(p, "FHW1", 4) != 0) return false;
+  uint32_t ver;
+  std::memcpy(&ver, p + 4, 4);
+  if (ver != 1) return false;
+  // copy the int32 sections out to aligned storage: the blob packs int8 and int32 arrays back to back
+  aligned.assign(p, p + n);
+  size_t off = 8;
+  auto take = [&](size_t bytes) { const uint8_t* q = aligned.data() + off; off += bytes; return q; };
+  v.shift = reinterpret_cast<const int32_t*>(take(12));
+  v.w1 = reinterpret_cast<const int8_t*>(take(144));   v.b1 = reinterpret_cast<const int32_t*>(take(64));
+  v.w2 = reinterpret_cast<const int8_t*>(take(4608));  v.b2 = reinterpret_cast<const int32_t*>(take(128));
+  v.w3 = reinterpret_cast<const int8_t*>(take(18432)); v.b3 = reinterpret_cast<const int32_t*>(take(256));
+  v.wh64 = reinterpret_cast<const int8_t*>(take(8192)); v.bh64 = reinterpret_cast<const int32_t*>(take(8));
+  v.wh32 = reinterpret_cast<const int8_t*>(take(8192)); v.bh32 = reinterpret_cast<const int32_t*>(take(8));
+  v.wh16 = reinterpret_cast<const int8_t*>(take(2048)); v.bh16 = reinterpret_cast<const int32_t*>(take(8));
+  return off == n;
+}
+
+inline int32_t rd32(const int32_t* p, int i)  // unaligned-safe read
+{
+  int32_t v;
+  std::memcpy(&v, reinterpret_cast<const uint8_t*>(p) + 4 * (size_t)i, 4);
+  return v;
+}
+
+// Build the device weight image: MFMA A-operand fragments in lane order (k_cnn.hip header comment).
+int build_weight_image(fhevc_ctx* c, const BlobView& b)
+{
+  for (int l = 0; l < 3; ++l) {
+    const int s = rd32(b.shift, l);
+    if (s < 0 || s > 24) return fail(c, FHEVC_E_WEIGHTS, "shift out of range");
+    c->scale[l] = std::ldexp(1.0f, -s);
+  }
+  std::vector<uint16_t> frag((size_t)FHEVC_FRAG_TOTAL * 8, 0);
+  auto put = [&](int frag_idx, int lane, int j, int v) { frag[((size_t)frag_idx + lane) * 8 + j] = bf16_of_small_int(v); };
+  for (int lane = 0; lane < 64; ++lane) {
+    const int r = lane & 31, h = lane >> 5;
+    for (int j = 0; j < 8; ++j) {
+      const int k = 8 * h + j;
+      // conv1: row r = out channel (16 valid), k = tap (9 valid)
+      if (r < 16 && k < 9) put(FHEVC_FRAG_CONV1, lane, j, b.w1[r * 9 + k]);
+      // conv2: K-step s = tap, k = input channel
+      for (int s = 0; s < 9; ++s) put(FHEVC_FRAG_CONV2 + s * 64, lane, j, b.w2[((r * 16 + k) * 9) + s]);
+      // conv3: tile t = 32 output channels; K-step s: tap = s>>1, input channel = 16*(s&1) + k
+      for (int t = 0; t < 2; ++t)
+        for (int s = 0; s < 18; ++s) {
+          const int oc = 32 * t + r, ic = 16 * (s & 1) + k, tap = s >> 1;
+          put(FHEVC_FRAG_CONV3 + (t * 18 + s) * 64, lane, j, b.w3[(oc * 32 + ic) * 9 + tap]);
+        }
+    }
+  }
+  std::vector<float> bias(112);
+  for (int i = 0; i < 16; ++i) bias[i] = (float)rd32(b.b1, i);
+  for (int i = 0; i < 32; ++i) bias[16 + i] = (float)rd32(b.b2, i);
+  for (int i = 0; i < 64; ++i) bias[48 + i] = (float)rd32(b.b3, i);
+  for (float v : bias) if (std::fabs(v) > 4194304.0f) return fail(c, FHEVC_E_WEIGHTS, "|bias| > 2^22");
+  std::vector<uint8_t> whead(4 * 4096 + 2 * 1024);
+  for (int i = 0; i < 8192; ++i) whead[i] = (uint8_t)((int)b.wh64[i] + 128);
+  for (int i = 0; i < 8192; ++i) whead[8192 + i] = (uint8_t)((int)b.wh32[i] + 128);
+  for (int i = 0; i < 2048; ++i) whead[16384 + i] = (uint8_t)((int)b.wh16[i] + 128);
+  int32_t bhead[6] = { rd32(b.bh64, 0), rd32(b.bh64, 1), rd32(b.bh32, 0), rd32(b.bh32, 1), rd32(b.bh16, 0), rd32(b.bh16, 1) };
+
+  if (!c->d_frag) {
+    HIP_TRY(c, hipMalloc(&c->d_frag, frag.size() * 2));
+    HIP_TRY(c, hipMalloc(&c->d_bias, bias.size() * 4));
+    HIP_TRY(c, hipMalloc(&c->d_whead, whead.size()));
+    HIP_TRY(c, hipMalloc(&c->d_bhead, sizeof bhead));
+  }
+  HIP_TRY(c, hipMemcpy(c->d_frag, frag.data(), frag.size() * 2, hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(c->d_bias, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(c->d_whead, whead.data(), whead.size(), hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(c->d_bhead, bhead, sizeof bhead, hipMemcpyHostToDevice));
+  c->have_weights = true;
+  return FHEVC_OK;
+}
+
+FhevcCnnWeights cnn_weights(const fhevc_ctx* c)
+{
+  FhevcCnnWeights w;
+  w.frag = c->d_frag; w.bias = c->d_bias; w.whead = c->d_whead; w.bhead = c->d_bhead;
+  w.scale[0] = c->scale[0]; w.scale[1] = c->scale[1]; w.scale[2] = c->scale[2];
+  return w;
+}
+
+void time_begin(fhevc_ctx* c, hipStream_t s, int which)
+{
+  if (!c->timing) return;
+  TimedLaunch t;
+  if (!c->pool.empty()) { t.start = c->pool.back().first; t.stop = c->pool.back().second; c->pool.pop_back(); }
+  else { hipEventCreate(&t.start); hipEventCreate(&t.stop); }
+  t.which = which;
+  hipEventRecord(t.start, s);
+  c->pending.push_back(t);
+}
+void time_end(fhevc_ctx* c, hipStream_t s)
+{
+  if (!c->timing) return;
+  hipEventRecord(c->pending.back().stop, s);
+}
+void time_resolve(fhevc_ctx* c)
+{
+  for (auto& t : c->pending) {
+    float ms = 0;
+    if (hipEventSynchronize(t.stop) == hipSuccess && hipEventElapsedTime(&ms, t.start, t.stop) == hipSuccess) {
+      c->sum_ms[t.which] += ms;
+      c->launches[t.which] += 1;
+      if (t.which == 0) c->stats.last_cnn_ms = ms;
+      if (t.which == 1) c->stats.last_hadamard_ms = ms;
+      if (t.which == 2) c->stats.last_first_pass_ms = ms;
+    }
+    c->pool.emplace_back(t.start, t.stop);
+  }
+  c->pending.clear();
+}
+
+FhevcFrames frames_of(const fhevc_ctx* c, const void* d_luma, int sample_bytes, int stride, long long frame_stride,
+                      int num_frames, int row_begin, int row_end)
+{
+  FhevcFrames f;
+  f.luma = d_luma; f.sample_bytes = sample_bytes; f.stride = stride; f.frame_stride = frame_stride;
+  f.width = c->cfg.width; f.height = c->cfg.height; f.bit_depth = c->cfg.bit_depth;
+  f.ctus_x = c->ctus_x; f.ctus_y = c->ctus_y; f.num_frames = num_frames; f.row_begin = row_begin; f.row_end = row_end;
+  return f;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* fhevc_version(void) { return "fasthevc_amd 0.1.0 (gfx950)"; }
+
+const char* fhevc_last_error(fhevc_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int fhevc_band(int ctu_rows, int rank, int world, int* begin, int* end)
+{
+  if (ctu_rows < 0 || world <= 0 || rank < 0 || rank >= world || !begin || !end) return FHEVC_E_INVALID;
+  *begin = (int)(((long long)rank * ctu_rows) / world);
+  *end = (int)(((long long)(rank + 1) * ctu_rows) / world);
+  return FHEVC_OK;
+}
+
+int fhevc_create(fhevc_ctx** out, const fhevc_cfg* cfg)
+{
+  if (!out || !cfg) return FHEVC_E_INVALID;
+  *out = nullptr;
+  if (cfg->width <= 0 || cfg->height <= 0 || cfg->width > 16384 || cfg->height > 16384) return FHEVC_E_INVALID;
+  if (cfg->ctu_size != FHEVC_CTU || cfg->max_depth != 3) return FHEVC_E_INVALID;
+  if (cfg->bit_depth < 8 || cfg->bit_depth > 12) return FHEVC_E_INVALID;
+  if (cfg->backend != FHEVC_BACKEND_HIP) return FHEVC_E_INVALID;  // there is no CPU backend
+  if (cfg->num_devices > 1) return FHEVC_E_INVALID;               // one device per context / process
+  fhevc_ctx* c = new (std::nothrow) fhevc_ctx();
+  if (!c) return FHEVC_E_NOMEM;
+  c->cfg = *cfg;
+  c->cfg.weights_path = nullptr;
+  c->cfg.device_ids = nullptr;
+  if (c->cfg.max_frames < 1) c->cfg.max_frames = 1;
+  c->device = (cfg->device_ids && cfg->num_devices >= 1) ? cfg->device_ids[0] : 0;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || c->device >= ndev) { delete c; return FHEVC_E_NO_DEVICE; }
+  hipDeviceProp_t prop;
+  if (hipSetDevice(c->device) != hipSuccess || hipGetDeviceProperties(&prop, c->device) != hipSuccess) { delete c; return FHEVC_E_NO_DEVICE; }
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) { delete c; return FHEVC_E_NO_DEVICE; }  // code object is gfx950-only
+  c->num_cus = prop.multiProcessorCount;
+  c->ctus_x = (cfg->width + 63) / 64;
+  c->ctus_y = (cfg->height + 63) / 64;
+  c->num_ctus = c->ctus_x * c->ctus_y;
+  c->dev_stride = c->ctus_x * 64;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return FHEVC_E_NO_DEVICE; }
+  bool ok = true;
+  ok &= hipMalloc(&c->d_luma, (size_t)c->dev_stride * c->ctus_y * 64 * sizeof(int16_t)) == hipSuccess;
+  ok &= hipMalloc(&c->d_depth, (size_t)c->num_ctus * 256) == hipSuccess;
+  ok &= hipMalloc(&c->d_had, (size_t)c->num_ctus * 4) == hipSuccess;
+  ok &= hipMalloc(&c->d_nodes, (size_t)c->num_ctus * FHEVC_NODES_PER_CTU * sizeof(FhevcNodeCost)) == hipSuccess;
+  ok &= hipMalloc(&c->d_satd, 2 * 64 * 64 * sizeof(int16_t)) == hipSuccess;
+  ok &= hipMalloc(&c->d_satd_out, 4) == hipSuccess;
+  for (auto& e : c->ev) ok &= hipEventCreate(&e) == hipSuccess;
+  if (!ok) { fhevc_destroy(c); return FHEVC_E_NOMEM; }
+  hipMemset(c->d_luma, 0, (size_t)c->dev_stride * c->ctus_y * 64 * sizeof(int16_t));
+  if (cfg->weights_path) {
+    FILE* fp = std::fopen(cfg->weights_path, "rb");
+    if (!fp) { fhevc_destroy(c); return FHEVC_E_WEIGHTS; }
+    std::vector<uint8_t> buf(kBlobBytes + 1);
+    const size_t n = std::fread(buf.data(), 1, buf.size(), fp);
+    std::fclose(fp);
+    const int rc = fhevc_set_weights(c, buf.data(), n);
+    if (rc != FHEVC_OK) { fhevc_destroy(c); return rc; }
+  }
+  *out = c;
+  return FHEVC_OK;
+}
+
+void fhevc_destroy(fhevc_ctx* c)
+{
+  if (!c) return;
+  hipSetDevice(c->device);
+  if (c->stream) hipStreamSynchronize(c->stream);
+  time_resolve(c);
+  for (auto& p : c->pool) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+  for (auto& e : c->ev) if (e) hipEventDestroy(e);
+  hipFree(c->d_frag); hipFree(c->d_bias); hipFree(c->d_whead); hipFree(c->d_bhead);
+  hipFree(c->d_luma); hipFree(c->d_depth); hipFree(c->d_had); hipFree(c->d_nodes); hipFree(c->d_satd); hipFree(c->d_satd_out);
+  if (c->stream) hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int fhevc_set_weights(fhevc_ctx* c, const void* blob, size_t bytes)
+{
+  if (!c || !blob) return FHEVC_E_INVALID;
+  BlobView v;
+  std::vector<uint8_t> copy;
+  if (!parse_blob(static_cast<const uint8_t*>(blob), bytes, v, copy)) return fail(c, FHEVC_E_WEIGHTS, "not an FHW1 blob");
+  const struct { const int8_t* p; size_t n; } i8s[6] = { { v.w1, 144 }, { v.w2, 4608 }, { v.w3, 18432 }, { v.wh64, 8192 }, { v.wh32, 8192 }, { v.wh16, 2048 } };
+  for (const auto& a : i8s)
+    for (size_t i = 0; i < a.n; ++i) if (a.p[i] == -128) return fail(c, FHEVC_E_WEIGHTS, "weight -128 not allowed");
+  hipSetDevice(c->device);
+  return build_weight_image(c, v);
+}
+
+int fhevc_enable_kernel_timing(fhevc_ctx* c, int on)
+{
+  if (!c) return FHEVC_E_INVALID;
+  if (!on) time_resolve(c);
+  c->timing = on != 0;
+  return FHEVC_OK;
+}
+
+int fhevc_kernel_timing(fhevc_ctx* c, int which, int reset, double* avg_ms, uint64_t* launches)
+{
+  if (!c || which < 0 || which > 2) return FHEVC_E_INVALID;
+  time_resolve(c);
+  if (avg_ms) *avg_ms = c->launches[which] ? c->sum_ms[which] / (double)c->launches[which] : 0.0;
+  if (launches) *launches = c->launches[which];
+  if (reset) { c->sum_ms[which] = 0; c->launches[which] = 0; }
+  return FHEVC_OK;
+}
+
+int fhevc_predict_frames_device(fhevc_ctx* c, const void* d_luma, int sample_bytes, int stride_samples,
+                                long long frame_stride_samples, int num_frames, int ctu_row_begin, int ctu_row_end,
+                                uint8_t* d_depth_map, int32_t* d_hadamard, int32_t* d_logits, void* stream)
+{
+  if (!c || !d_luma || !d_depth_map) return FHEVC_E_INVALID;
+  if (!c->have_weights) return fail(c, FHEVC_E_STATE, "weights not set");
+  if ((sample_bytes != 1 && sample_bytes != 2) || stride_samples < c->cfg.width || num_frames < 1) return fail(c, FHEVC_E_INVALID, "bad frame layout");
+  if (sample_bytes == 1 && c->cfg.bit_depth != 8) return fail(c, FHEVC_E_INVALID, "uint8 samples need bit_depth 8");
+  if (ctu_row_begin < 0 || ctu_row_end > c->ctus_y || ctu_row_begin > ctu_row_end) return fail(c, FHEVC_E_INVALID, "bad CTU-row band");
+  if (num_frames > 1 && frame_stride_samples < (long long)stride_samples * (c->cfg.height - 1) + c->cfg.width) return fail(c, FHEVC_E_INVALID, "frames overlap");
+  if (ctu_row_begin == ctu_row_end) return FHEVC_OK;
+  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
+  const FhevcFrames fr = frames_of(c, d_luma, sample_bytes, stride_samples, frame_stride_samples, num_frames, ctu_row_begin, ctu_row_end);
+  if (d_hadamard) {
+    time_begin(c, s, 1);
+    HIP_TRY(c, fhevc_launch_src_hadamard(fr, d_hadamard, s));
+    time_end(c, s);
+    c->stats.kernels_launched++;
+  }
+  time_begin(c, s, 0);
+  HIP_TRY(c, fhevc_launch_cnn(fr, cnn_weights(c), d_depth_map, d_logits, c->num_cus, s));
+  time_end(c, s);
+  c->stats.kernels_launched++;
+  c->stats.frames += (uint64_t)num_frames;
+  c->stats.ctus += (uint64_t)num_frames * (uint64_t)(ctu_row_end - ctu_row_begin) * (uint64_t)c->ctus_x;
+  return FHEVC_OK;
+}
+
+// upload one host picture (Pel plane with stride) into the context's staging plane
+static int upload_frame(fhevc_ctx* c, const int16_t* luma, int stride_samples)
+{
+  HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+  HIP_TRY(c, hipMemcpy2DAsync(c->d_luma, (size_t)c->dev_stride * 2, luma, (size_t)stride_samples * 2,
+                              (size_t)c->cfg.width * 2, (size_t)c->cfg.height, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+  c->stats.bytes_h2d += (uint64_t)c->cfg.width * c->cfg.height * 2;
+  return FHEVC_OK;
+}
+
+int fhevc_predict_frame(fhevc_ctx* c, const int16_t* luma, int stride_samples, int qp, int slice_type,
+                        uint8_t* depth_map, int32_t* ctu_src_hadamard)
+{
+  (void)qp; (void)slice_type;
+  if (!c || !luma || !depth_map || stride_samples < c->cfg.width) return FHEVC_E_INVALID;
+  if (!c->have_weights) return fail(c, FHEVC_E_STATE, "weights not set");
+  hipSetDevice(c->device);
+  int rc = upload_frame(c, luma, stride_samples);
+  if (rc != FHEVC_OK) return rc;
+  rc = fhevc_predict_frames_device(c, c->d_luma, 2, c->dev_stride, 0, 1, 0, c->ctus_y, c->d_depth,
+                                   ctu_src_hadamard ? c->d_had : nullptr, nullptr, c->stream);
+  if (rc != FHEVC_OK) return rc;
+  HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
+  HIP_TRY(c, hipMemcpyAsync(depth_map, c->d_depth, (size_t)c->num_ctus * 256, hipMemcpyDeviceToHost, c->stream));
+  if (ctu_src_hadamard) HIP_TRY(c, hipMemcpyAsync(ctu_src_hadamard, c->d_had, (size_t)c->num_ctus * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipEventRecord(c->ev[3], c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->stats.ms_h2d += ms;
+  if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) c->stats.ms_kernels += ms;
+  if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) c->stats.ms_d2h += ms;
+  c->stats.bytes_d2h += (uint64_t)c->num_ctus * (256 + (ctu_src_hadamard ? 4 : 0));
+  return FHEVC_OK;
+}
+
+int fhevc_satd(fhevc_ctx* c, const int16_t* org, int org_stride, const int16_t* cur, int cur_stride,
+               int w, int h, int bit_depth, uint32_t* out)
+{
+  if (!c || !org || !cur || !out) return FHEVC_E_INVALID;
+  if (w < 2 || h < 2 || w > 64 || h > 64 || (w & 1) || (h & 1) || bit_depth < 8 || bit_depth > 12) return fail(c, FHEVC_E_INVALID, "bad SATD block");
+  if (org_stride < w || cur_stride < w) return fail(c, FHEVC_E_INVALID, "bad SATD stride");
+  hipSetDevice(c->device);
+  HIP_TRY(c, hipMemcpy2DAsync(c->d_satd, 64 * 2, org, (size_t)org_stride * 2, (size_t)w * 2, (size_t)h, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpy2DAsync(c->d_satd + 64 * 64, 64 * 2, cur, (size_t)cur_stride * 2, (size_t)w * 2, (size_t)h, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, fhevc_launch_satd(c->d_satd, 64, c->d_satd + 64 * 64, 64, w, h, bit_depth, c->d_satd_out, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(out, c->d_satd_out, 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->stats.kernels_launched++;
+  return FHEVC_OK;
+}
+
+int fhevc_intra_first_pass(fhevc_ctx* c, const int16_t* luma, int stride_samples, int qp, fhevc_node_cost* out)
+{
+  if (!c || !luma || !out || stride_samples < c->cfg.width || qp < 0 || qp > 51) return FHEVC_E_INVALID;
+  hipSetDevice(c->device);
+  int rc = upload_frame(c, luma, stride_samples);
+  if (rc != FHEVC_OK) return rc;
+  // lambda = 0.57 * 2^((qp-12)/3): TEncSlice::calculateLambda, all-intra path (TEncSlice.cpp:433-527)
+  const double sqrt_lambda = std::sqrt(0.57 * std::pow(2.0, ((double)qp - 12.0) / 3.0));
+  const FhevcFrames fr = frames_of(c, c->d_luma, 2, c->dev_stride, 0, 1, 0, c->ctus_y);
+  time_begin(c, c->stream, 2);
+  HIP_TRY(c, fhevc_launch_first_pass(fr, sqrt_lambda, c->d_nodes, c->stream));
+  time_end(c, c->stream);
+  static_assert(sizeof(fhevc_node_cost) == sizeof(FhevcNodeCost), "node cost layout");
+  HIP_TRY(c, hipMemcpyAsync(out, c->d_nodes, (size_t)c->num_ctus * FHEVC_NODES_PER_CTU * sizeof(FhevcNodeCost), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->stats.kernels_launched++;
+  return FHEVC_OK;
+}
+
+int fhevc_get_stats(fhevc_ctx* c, void* out, size_t size)
+{
+  if (!c || !out) return FHEVC_E_INVALID;
+  time_resolve(c);
+  std::memcpy(out, &c->stats, size < sizeof(fhevc_stats) ? size : sizeof(fhevc_stats));
+  return FHEVC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,48 @@
+// fhevc_internal.h -- shared declarations between the C-ABI layer (fhevc_api.hip) and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define FHEVC_CTU 64
+
+// ---- depth CNN (k_cnn.hip) -------------------------------------------------------------------------------
+// Packed weight image in HBM, built once by fhevc_set_weights (fhevc_api.hip: build_weight_image):
+//   frag  : MFMA A-operand fragments, one uint4 (8 bf16) per lane: conv1 [64], conv2 [9][64], conv3 [2][18][64]
+//   bias  : float b1[16], b2[32], b3[64]
+//   whead : uint8 (w + 128): wh64[2][4096], wh32[2][4096], wh16[2][1024]
+//   bhead : int32 bh64[2], bh32[2], bh16[2], then sum-correction is done in-kernel
+#define FHEVC_FRAG_CONV1 0
+#define FHEVC_FRAG_CONV2 64
+#define FHEVC_FRAG_CONV3 (64 + 9 * 64)
+#define FHEVC_FRAG_TOTAL (64 + 9 * 64 + 2 * 18 * 64)
+
+struct FhevcFrames {
+  const void* luma;          // device pointer to sample (0,0) of frame 0
+  int sample_bytes;          // 1 or 2
+  int stride;                // samples
+  long long frame_stride;    // samples
+  int width, height, bit_depth;
+  int ctus_x, ctus_y;
+  int num_frames;
+  int row_begin, row_end;    // CTU-row band processed by this launch
+};
+
+struct FhevcCnnWeights {
+  const uint4* frag;
+  const float* bias;
+  const uint8_t* whead;
+  const int32_t* bhead;
+  float scale[3];            // 2^-shift per conv layer
+};
+
+hipError_t fhevc_launch_cnn(const FhevcFrames& fr, const FhevcCnnWeights& w, uint8_t* d_depth, int32_t* d_logits,
+                            int num_cus, hipStream_t stream);
+
+// ---- source Hadamard + SATD (k_hadamard.hip) ---------------------------------------------------------------
+hipError_t fhevc_launch_src_hadamard(const FhevcFrames& fr, int32_t* d_out, hipStream_t stream);
+hipError_t fhevc_launch_satd(const int16_t* d_org, int org_stride, const int16_t* d_cur, int cur_stride,
+                             int w, int h, int bit_depth, uint32_t* d_out, hipStream_t stream);
+
+// ---- 35-mode first pass (k_firstpass.hip) ------------------------------------------------------------------
+struct FhevcNodeCost { uint32_t satd; uint32_t mode; double cost; };
+hipError_t fhevc_launch_first_pass(const FhevcFrames& fr, double sqrt_lambda, FhevcNodeCost* d_out, hipStream_t stream);

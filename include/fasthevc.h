@@ -1,0 +1,125 @@
+/*
+ * fasthevc.h -- C ABI of the MI355X-native CU-partition fast-decision path.
+ *
+ * This is the drop-in boundary for HM's source/Lib/TLibEncoder (reference: omricarmi/FastHEVC, an HM-16.14
+ * fork).  The reference has no plugin/FFI layer: the boundary the path sits behind is HM's own C++ class
+ * surface, TEncSlice::compressSlice -> TEncCu::compressCtu -> TEncCu::xCompressCU (TEncSlice.cpp:698-983,
+ * TEncCu.cpp:252-288, 496-1058).  A patched TEncSlice/TEncCu (hm_patch/) calls these entry
+ * points from three places; everything else in HM stays untouched.  Plain pointers and sizes only.
+ *
+ * Conventions:
+ *   - return 0 on success, a negative FHEVC_E_* code on failure; the caller falls back to stock full RDO for
+ *     that picture -- the library never aborts the encode.  (HM itself reports errors by assert/exit:
+ *     TEncCu.cpp:1055-1057.)
+ *   - all buffers are caller-owned; calls are synchronous from the single encoder thread unless the entry
+ *     point takes a stream; a context is not thread-safe (HM is not re-entrant either: TEncCu.cpp:50,126-131).
+ *   - there is NO CPU backend: fhevc_create fails with FHEVC_E_NO_DEVICE when no gfx950 device is usable.
+ *
+ * Depth-map convention: per CTU 256 bytes, raster 16x16 of 4x4 luma units, value = CU depth 0..3
+ * (0 = 64x64 ... 3 = 8x8); equals TComDataCU::getDepth(g_auiRasterToZscan[r]) (TComDataCU.h:86,207-211,
+ * TComRom.cpp:284-287).  Units outside the picture carry 0; CUs that cross the picture edge are marked split,
+ * as HM forces them to be (TEncCu.cpp:574, 894, 915).
+ */
+#ifndef FASTHEVC_H
+#define FASTHEVC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FHEVC_OK               0
+#define FHEVC_E_INVALID       -1   /* bad argument / unsupported geometry */
+#define FHEVC_E_NO_DEVICE     -2   /* no usable gfx950 device, or HIP runtime error at create */
+#define FHEVC_E_HIP           -3   /* HIP runtime error during a call (fhevc_last_error has the text) */
+#define FHEVC_E_WEIGHTS       -4   /* weight blob missing / malformed */
+#define FHEVC_E_NOMEM         -5
+#define FHEVC_E_STATE         -6   /* call not valid in this state (e.g. predict before weights are set) */
+
+#define FHEVC_BACKEND_HIP      1
+
+#define FHEVC_NODES_PER_CTU   85   /* 1 + 4 + 16 + 64 CU nodes of sizes 64, 32, 16, 8 */
+#define FHEVC_LOGITS_PER_CTU  42   /* 21 split decisions x 2 classes */
+
+typedef struct fhevc_ctx fhevc_ctx; /* opaque: device buffers, streams, weights, timing events */
+
+typedef struct {
+  int width, height;        /* luma picture size (TComPicYuv::getWidth/getHeight(COMPONENT_Y)) */
+  int bit_depth;            /* sps.getBitDepth(CHANNEL_TYPE_LUMA): 8..12 */
+  int ctu_size;             /* 64 (the reference's dumper hard-codes it: HARP_Defines.h:28-29) */
+  int max_depth;            /* 3: 8x8 leaves (MaxPartitionDepth 4) */
+  int num_devices;          /* 1 per process; ranks of a node shard CTU-row bands (see fhevc_band) */
+  const int* device_ids;    /* HIP device ordinals, NULL = {0} */
+  const char* weights_path; /* FHW1 blob (fasthevc_amd/weights.py), or NULL and call fhevc_set_weights */
+  int backend;              /* FHEVC_BACKEND_HIP */
+  int max_frames;           /* frames per batched call the context sizes its staging buffers for (>= 1) */
+} fhevc_cfg;
+
+/* per-node result of the 35-mode first pass (twin of TEncSearch::estIntraPredLumaQT's first pass,
+ * TEncSearch.cpp:2271-2295, with reference samples taken from the ORIGINAL plane) */
+typedef struct {
+  uint32_t satd;            /* SATD of the cheapest mode (TComRdCost::xGetHADs) */
+  uint32_t mode;            /* its intra mode 0..34; 255 when the node crosses the picture edge */
+  double   cost;            /* satd + modeBits * sqrt(lambda); -1 for skipped nodes */
+} fhevc_node_cost;
+
+typedef struct {
+  uint64_t frames;          /* frames processed since create */
+  uint64_t ctus;            /* CTU depth decisions delivered */
+  uint64_t bytes_h2d, bytes_d2h;
+  uint64_t kernels_launched;
+  double   ms_h2d, ms_kernels, ms_d2h;   /* accumulated, HIP-event timed (host-buffer entry points only) */
+  double   last_cnn_ms, last_hadamard_ms, last_first_pass_ms; /* last launch of each kernel */
+} fhevc_stats;
+
+int  fhevc_create(fhevc_ctx** out, const fhevc_cfg* cfg);
+void fhevc_destroy(fhevc_ctx* ctx);
+/* weights from memory instead of cfg.weights_path (same FHW1 bytes) */
+int  fhevc_set_weights(fhevc_ctx* ctx, const void* blob, size_t bytes);
+
+/* One picture, host buffers, synchronous.  Called once per picture before the CTU loop of
+ * TEncSlice::compressSlice (TEncSlice.cpp:792) with pcPic->getPicYuvOrg()->getAddr(COMPONENT_Y) / getStride
+ * (TComPicYuv.h:121-147).  depth_map: numCtus*256 bytes.  ctu_src_hadamard: optional, numCtus values equal to
+ * TEncCu::updateCtuDataISlice(ctu, w, h) (TEncCu.cpp:1324-1343) -- what TEncSlice::calCostSliceI sums
+ * (TEncSlice.cpp:663-695).  qp / slice_type are the slice's (the intra classifier ignores them, like the
+ * reference's MATLAB pipeline does: CShow_PredResiReco.h:93 stores QP, nothing reads it). */
+int  fhevc_predict_frame(fhevc_ctx* ctx, const int16_t* luma, int stride_samples, int qp, int slice_type,
+                         uint8_t* depth_map, int32_t* ctu_src_hadamard);
+
+/* == TComRdCost::calcHAD(bitDepth, org, strideOrg, cur, strideCur, w, h) (TComRdCost.cpp:297-334) and
+ * xGetHADs (:1753-1824); host buffers, w,h <= 64.  Parity entry point. */
+int  fhevc_satd(fhevc_ctx* ctx, const int16_t* org, int org_stride, const int16_t* cur, int cur_stride,
+                int w, int h, int bit_depth, uint32_t* out);
+
+/* 35-mode first pass for every CU node of every CTU of one picture (host buffers).  out: numCtus * 85 entries,
+ * node order 64x64, 32x32 (raster), 16x16 (raster), 8x8 (raster).  lambda as TEncSlice::calculateLambda
+ * (TEncSlice.cpp:433-527) would give it for qp; pass qp. */
+int  fhevc_intra_first_pass(fhevc_ctx* ctx, const int16_t* luma, int stride_samples, int qp, fhevc_node_cost* out);
+
+/* Device-resident batch: num_frames pictures already in HBM, CTU rows [ctu_row_begin, ctu_row_end) of each.
+ * d_luma: sample_bytes = 2 -> int16 Pel plane(s) as HM lays them out, 1 -> uint8 (8-bit content);
+ * frame f starts at d_luma + f * frame_stride_samples.  Outputs are device pointers, compact over the band:
+ * entry ((f * band_rows + (row - ctu_row_begin)) * ctus_per_row + col).  d_hadamard / d_logits may be NULL.
+ * stream: hipStream_t (NULL = the context's stream).  Asynchronous with respect to the host. */
+int  fhevc_predict_frames_device(fhevc_ctx* ctx, const void* d_luma, int sample_bytes, int stride_samples,
+                                 long long frame_stride_samples, int num_frames, int ctu_row_begin, int ctu_row_end,
+                                 uint8_t* d_depth_map, int32_t* d_hadamard, int32_t* d_logits, void* stream);
+
+/* CTU-row band of rank `rank` out of `world`: rows [begin, end) */
+int  fhevc_band(int ctu_rows, int rank, int world, int* begin, int* end);
+
+/* average duration in ms of the dominant kernels over launches since the last reset, measured with HIP
+ * events on the launch stream; which: 0 = depth CNN, 1 = source Hadamard, 2 = first pass */
+int  fhevc_kernel_timing(fhevc_ctx* ctx, int which, int reset, double* avg_ms, uint64_t* launches);
+int  fhevc_enable_kernel_timing(fhevc_ctx* ctx, int on);
+
+int  fhevc_get_stats(fhevc_ctx* ctx, void* out, size_t size); /* copies min(size, sizeof(fhevc_stats)) */
+const char* fhevc_last_error(fhevc_ctx* ctx);
+const char* fhevc_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,155 @@
+"""GPU parity: every entry point of the C ABI (include/fasthevc.h) against the CPU oracle and the golden vectors
+produced by the reference's own functions.  Bit-exact: all of this path is integer arithmetic."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle_py as op
+from fasthevc_amd import capi, frames, weights
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    return torch
+
+
+def _oracle_frame(oracle, w, luma_u8, bd):
+    h, wd = luma_u8.shape
+    buf, org, stride = frames.to_pel_plane(luma_u8, bd)
+    cw, ch = frames.ctu_grid(wd, h)
+    depth = np.zeros(cw * ch * 256, np.uint8)
+    logits = np.zeros(cw * ch * 42, np.int32)
+    oracle.fho_predict_frame(op.weights_from_arrays(w), op.ptr(buf.reshape(-1), org), stride, wd, h, bd, depth,
+                             C.c_void_p(logits.ctypes.data))
+    had = np.zeros(cw * ch, np.int32)
+    oracle.fho_frame_src_hadamard(op.ptr(buf.reshape(-1), org), stride, wd, h, had)
+    return buf, org, stride, depth.reshape(-1, 256), logits.reshape(-1, 42), had
+
+
+def test_satd_matches_reference_golden(golden):
+    ctx = capi.Context(64, 64, 8)
+    a, b, meta = golden["satd_a"], golden["satd_b"], golden["satd_meta"]
+    for i in range(len(meta)):
+        bd, w, h = (int(v) for v in meta[i])
+        got = ctx.satd(a[i], b[i], w, h, bd, 64, 64)
+        assert got == int(golden["satd_gethads"][i]), (bd, w, h)
+    ctx.close()
+
+
+def test_satd_random_vs_oracle(oracle):
+    ctx = capi.Context(64, 64, 8)
+    rng = np.random.default_rng(3)
+    for _ in range(40):
+        bd = int(rng.choice([8, 10, 12]))
+        w, h = int(rng.choice([4, 8, 16, 32, 64])), int(rng.choice([4, 8, 16, 32, 64]))
+        a = rng.integers(0, 1 << bd, size=(64, 64)).astype(np.int16)
+        b = rng.integers(0, 1 << bd, size=(64, 64)).astype(np.int16)
+        assert ctx.satd(a, b, w, h, bd, 64, 64) == oracle.fho_satd(op.ptr(a), 64, op.ptr(b), 64, w, h, bd)
+    ctx.close()
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+@pytest.mark.parametrize("seed,extreme", [(0, False), (7, True)])
+def test_predict_frame_416x240(oracle, golden, bd, seed, extreme):
+    """config 1 geometry (7x4 CTUs, last column 32 px wide, last row 48 px tall), host-buffer entry point."""
+    w = weights.random_weights(seed, extreme=extreme)
+    luma = frames.texture16_luma(416, 240)
+    buf, org, stride, depth_ref, _, had_ref = _oracle_frame(oracle, w, luma, bd)
+    ctx = capi.Context(416, 240, bd, w)
+    depth, had = ctx.predict_frame(buf, org, stride)
+    assert np.array_equal(had, had_ref)
+    assert np.array_equal(had, golden[f"ctu_had_t16_416x240_{bd}"])  # == the reference's updateCtuDataISlice
+    bad = np.nonzero((depth != depth_ref).any(axis=1))[0]
+    assert bad.size == 0, f"CTUs with a differing depth map: {bad[:10]}"
+    s = ctx.stats()
+    assert s["ctus"] == 28 and s["frames"] == 1
+    ctx.close()
+
+
+def test_predict_frame_1080p_hetero(oracle, golden):
+    """config 2 geometry, the heterogeneous content: 510 CTUs, last row 56 px tall."""
+    w = weights.random_weights(1)
+    luma = frames.hetero_luma(1920, 1080)
+    buf, org, stride, depth_ref, _, had_ref = _oracle_frame(oracle, w, luma, 8)
+    ctx = capi.Context(1920, 1080, 8, w)
+    depth, had = ctx.predict_frame(buf, org, stride)
+    assert np.array_equal(had, had_ref)
+    assert np.array_equal(depth, depth_ref)
+    assert len(np.unique(depth)) == 4  # all four depths occur, so the comparison is not vacuous
+    buf2, org2, stride2 = frames.to_pel_plane(frames.texture16_luma(1920, 1080), 8)
+    _, had2 = ctx.predict_frame(buf2, org2, stride2)
+    assert np.array_equal(had2, golden["ctu_had_t16_1920x1080_8"])
+    ctx.close()
+
+
+def test_device_batch_logits_and_bands(oracle, torch_cuda):
+    """Device-resident batch entry point: 3 frames, uint8 and int16 sample layouts, logits, CTU-row bands."""
+    torch = torch_cuda
+    w = weights.random_weights(2)
+    W, H, NF = 416, 240, 3
+    lumas = [frames.texture16_luma(W, H, seed=100 + f) for f in range(NF)]
+    refs = [_oracle_frame(oracle, w, y, 8) for y in lumas]
+    ctx = capi.Context(W, H, 8, w)
+    dev = torch.device("cuda:0")
+    n = ctx.num_ctus
+    # uint8, tightly packed
+    d8 = torch.from_numpy(np.stack(lumas)).to(dev)
+    depth = torch.zeros((NF, n, 256), dtype=torch.uint8, device=dev)
+    had = torch.zeros((NF, n), dtype=torch.int32, device=dev)
+    logits = torch.zeros((NF, n, 42), dtype=torch.int32, device=dev)
+    ctx.predict_frames_device(d8.data_ptr(), 1, W, W * H, NF, depth.data_ptr(), had.data_ptr(), logits.data_ptr())
+    torch.cuda.synchronize()
+    for f in range(NF):
+        assert np.array_equal(depth[f].cpu().numpy(), refs[f][3])
+        assert np.array_equal(logits[f].cpu().numpy(), refs[f][4])
+        assert np.array_equal(had[f].cpu().numpy(), refs[f][5])
+    # int16 Pel planes with HM's stride and margins, band [1, 3) of the 4 CTU rows only
+    planes = np.stack([frames.to_pel_plane(y, 8)[0] for y in lumas])
+    _, org, stride = frames.to_pel_plane(lumas[0], 8)
+    d16 = torch.from_numpy(planes).to(dev)
+    band = torch.full((NF, 2 * ctx.ctus_x, 256), 255, dtype=torch.uint8, device=dev)
+    ctx.predict_frames_device(d16.data_ptr() + 2 * org, 2, stride, planes.shape[1] * planes.shape[2], NF,
+                              band.data_ptr(), None, None, rows=(1, 3), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for f in range(NF):
+        assert np.array_equal(band[f].cpu().numpy(), refs[f][3][ctx.ctus_x:3 * ctx.ctus_x])
+    ctx.close()
+
+
+def test_first_pass_vs_oracle(oracle):
+    luma = frames.texture16_luma(416, 240)
+    for bd in (8, 10):
+        buf, org, stride = frames.to_pel_plane(luma, bd)
+        ctx = capi.Context(416, 240, bd)
+        got = ctx.intra_first_pass(buf, org, stride, qp=32)
+        sl = oracle.fho_lambda_intra(32, bd) ** 0.5
+        exp = (op.NodeCost * 85)()
+        for cy in range(4):
+            for cx in range(7):
+                oracle.fho_first_pass_ctu(op.ptr(buf.reshape(-1), org), stride, 416, 240, cx, cy, bd, sl, exp)
+                e = np.frombuffer(exp, dtype=capi.NODE_DTYPE)
+                g = got[cy * 7 + cx]
+                assert np.array_equal(g["satd"], e["satd"]), (bd, cx, cy)
+                assert np.array_equal(g["mode"], e["mode"]), (bd, cx, cy)
+                assert np.array_equal(g["cost"], e["cost"]), (bd, cx, cy)
+        ctx.close()
+
+
+def test_errors_are_status_codes():
+    ctx = capi.Context(416, 240, 8)
+    buf, org, stride = frames.to_pel_plane(frames.texture16_luma(416, 240), 8)
+    with pytest.raises(capi.FastHevcError) as e:
+        ctx.predict_frame(buf, org, stride)          # weights not set
+    assert e.value.code == capi.E_STATE
+    with pytest.raises(capi.FastHevcError) as e:
+        ctx.set_weights(b"nope")
+    assert e.value.code == capi.E_WEIGHTS
+    ctx.close()
+    with pytest.raises(capi.FastHevcError):
+        capi.Context(416, 240, 7)

@@ -1,0 +1,84 @@
+"""CPU tests of the host-side logic: synthetic frames, weight blob, band arithmetic, C-ABI surface."""
+import hashlib
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from fasthevc_amd import bands, capi, frames, weights
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_synthetic_frames_are_pinned():
+    # md5 of the 4:2:0 files, SURVEY.md section 8(d)
+    assert hashlib.md5(frames.texture16_yuv420(416, 240)).hexdigest() == "913977ec4bc414503cefc9e5a8d0bcc3"
+    assert hashlib.md5(frames.hetero_yuv420(1920, 1080)).hexdigest() == "d2a7dee5ef67252b527b2f66fcaed0ca"
+
+
+def test_pel_plane_layout():
+    y = frames.texture16_luma(416, 240)
+    buf, org, stride = frames.to_pel_plane(y, 10)
+    assert stride == 416 + 160 and org == 80 * stride + 80  # TComPicYuv.cpp:94-103
+    assert buf.reshape(-1)[org] == int(y[0, 0]) << 2 and buf[80 + 239, 80 + 415] == int(y[239, 415]) << 2
+
+
+def test_weight_blob_roundtrip(tmp_path):
+    w = weights.random_weights(3)
+    blob = weights.pack(w)
+    assert len(blob) == weights.BLOB_BYTES
+    back = weights.unpack(blob)
+    for k in w:
+        assert np.array_equal(w[k], back[k])
+    p = tmp_path / "w.fhw"
+    weights.save(p, w)
+    assert weights.pack(weights.load(p)) == blob
+    bad = dict(w)
+    bad["w2"] = w["w2"].copy()
+    bad["w2"][0, 0, 0, 0] = -128
+    with pytest.raises(ValueError):
+        weights.pack(bad)
+    with pytest.raises(ValueError):
+        weights.unpack(blob[:-1])
+
+
+def test_band_partition_covers_rows():
+    for rows in (4, 17, 34):
+        for world in (1, 2, 3, 4, 8):
+            prev = 0
+            for r in range(world):
+                b, e = bands.band(rows, r, world)
+                assert b == prev and e >= b
+                prev = e
+                assert (b, e) == capi.band(rows, r, world)  # same arithmetic behind the C ABI
+            assert prev == rows
+    assert bands.max_band_rows(34, 8) == 5 and bands.max_band_rows(17, 8) == 3
+
+
+def test_c_abi_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "fasthevc.h")).read()
+    declared = sorted(set(re.findall(r"\b(fhevc_[a-z_0-9]+)\s*\(", header)))
+    assert declared == sorted(capi.SYMBOLS)
+    assert os.path.exists(capi.LIB_PATH), "HIP library not built (run __graft_entry__.build())"
+    exported = subprocess.check_output(["nm", "-D", "--defined-only", capi.LIB_PATH]).decode()
+    lib = capi.load_library()
+    for sym in declared:
+        assert re.search(rf"\bT {sym}\b", exported), sym
+        assert getattr(lib, sym) is not None
+    assert b"gfx950" in lib.fhevc_version()
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")
+def test_no_cpu_fallback():
+    # the product path must fail loudly without a gfx950 device
+    with pytest.raises(capi.FastHevcError) as e:
+        capi.Context(416, 240, 8, weights.random_weights(0))
+    assert e.value.code == capi.E_NO_DEVICE
+
+
+def test_struct_sizes_match_header():
+    assert capi.NODE_DTYPE.itemsize == 16
+    import ctypes
+    assert ctypes.sizeof(capi.NodeCost) == 16

@@ -1,0 +1,104 @@
+"""The oracle's integer depth classifier against an independent float64 torch restatement of the same network
+(parity for this part is "unpinned" w.r.t. the reference: it ships no inference code or weights)."""
+import numpy as np
+import torch
+import torch.nn.functional as Fn
+
+from oracle import oracle_py as op
+from fasthevc_amd import frames, weights
+
+
+def torch_cnn(w, ctu):
+    """ctu: int8 [64,64] centred.  Exact in float64: every intermediate is an integer < 2^53."""
+    t = lambda a: torch.from_numpy(np.asarray(a).astype(np.float64))
+    x = t(ctu).reshape(1, 1, 64, 64)
+    acts = []
+    for wk, bk, sh, pool in ((w["w1"].reshape(16, 1, 3, 3), w["b1"], w["shift"][0], True),
+                             (w["w2"], w["b2"], w["shift"][1], True), (w["w3"], w["b3"], w["shift"][2], False)):
+        x = Fn.conv2d(x, t(wk), t(bk), padding=1)
+        if pool:
+            x = Fn.max_pool2d(x, 2)
+        x = torch.clamp(torch.floor(x / float(1 << int(sh))), 0, 255)
+        acts.append(x[0].permute(1, 2, 0).numpy().astype(np.uint8))
+    a3 = x[0].permute(1, 2, 0)  # [16,16,64]
+    logits = np.zeros((21, 2), np.int64)
+    pooled = Fn.max_pool2d(x, 2)[0].permute(1, 2, 0)  # [8,8,64]
+    for cls in range(2):
+        logits[0, cls] = int((pooled * t(w["wh64"][cls])).sum()) + int(w["bh64"][cls])
+        for q in range(4):
+            qy, qx = q >> 1, q & 1
+            logits[1 + q, cls] = int((a3[qy * 8:qy * 8 + 8, qx * 8:qx * 8 + 8] * t(w["wh32"][cls])).sum()) + int(w["bh32"][cls])
+        for b in range(16):
+            by, bx = b >> 2, b & 3
+            logits[5 + b, cls] = int((a3[by * 4:by * 4 + 4, bx * 4:bx * 4 + 4] * t(w["wh16"][cls])).sum()) + int(w["bh16"][cls])
+    return acts, logits
+
+
+def test_oracle_cnn_matches_torch_float64(oracle):
+    rng = np.random.default_rng(11)
+    luma = frames.texture16_luma(416, 240)
+    for seed, extreme in ((0, False), (1, False), (2, True)):
+        w = weights.random_weights(seed, extreme=extreme)
+        ws = op.weights_from_arrays(w)
+        for trial in range(3):
+            if trial == 0:
+                ctu = (luma[64:128, 128:192].astype(np.int16) - 128).astype(np.int8)
+            elif trial == 1:
+                ctu = rng.integers(-128, 128, size=(64, 64)).astype(np.int8)
+            else:
+                ctu = rng.choice(np.array([-128, 127], np.int8), size=(64, 64))
+            ctu = np.ascontiguousarray(ctu)
+            a1 = np.zeros(32 * 32 * 16, np.uint8)
+            a2 = np.zeros(16 * 16 * 32, np.uint8)
+            a3 = np.zeros(16 * 16 * 64, np.uint8)
+            logits = np.zeros(42, np.int32)
+            oracle.fho_cnn_ctu_debug(ws, ctu.reshape(-1), a1, a2, a3, logits)
+            acts, ref_logits = torch_cnn(w, ctu)
+            assert np.array_equal(a1.reshape(32, 32, 16), acts[0])
+            assert np.array_equal(a2.reshape(16, 16, 32), acts[1])
+            assert np.array_equal(a3.reshape(16, 16, 64), acts[2])
+            assert np.array_equal(logits.reshape(21, 2).astype(np.int64), ref_logits)
+
+
+def test_exactness_bound_for_fp32_accumulation():
+    # |bias| <= 2^22 and K*255*127 keep every conv accumulator below 2^24,
+    # so fp32 accumulation of the bf16 products on the GPU is exact in any order
+    assert 9 * 128 * 127 + weights.BIAS_LIMIT < 1 << 24
+    assert 144 * 255 * 127 + weights.BIAS_LIMIT < 1 << 24
+    assert 288 * 255 * 127 + weights.BIAS_LIMIT < 1 << 24
+
+
+def test_depth_from_logits_rules(oracle):
+    lg = np.zeros((21, 2), np.int32)
+    d = np.zeros(256, np.uint8)
+    oracle.fho_depth_from_logits(lg.reshape(-1), 64, 64, d)
+    assert d.max() == 0  # ties -> no split (class 1 must win strictly)
+    lg[0] = (0, 1)
+    oracle.fho_depth_from_logits(lg.reshape(-1), 64, 64, d)
+    assert set(d.tolist()) == {1}
+    lg[1 + 3] = (0, 5)       # bottom-right 32x32 splits
+    lg[5 + 15] = (-1, 0)     # its bottom-right 16x16 splits to 8x8
+    oracle.fho_depth_from_logits(lg.reshape(-1), 64, 64, d)
+    m = d.reshape(16, 16)
+    assert (m[:8, :] == 1).all() and (m[8:, :8] == 1).all() and (m[8:12, 8:] == 2).all() and (m[12:, 12:] == 3).all()
+    # picture edge: a 64x64 CTU of which only 32x48 is inside -> 64 and the crossing 32s are forced to split
+    lg[:] = 0
+    oracle.fho_depth_from_logits(lg.reshape(-1), 32, 48, d)
+    m = d.reshape(16, 16)
+    assert (m[:8, :8] == 1).all()             # top-left 32x32 inside: no forced split, logits say no
+    assert (m[8:12, :8] == 2).all()           # bottom-left 32x32 crosses the bottom edge -> split to 16x16
+    assert (m[12:, :] == 0).all() and (m[:, 8:] == 0).all()  # outside the picture
+
+
+def test_predict_frame_edge_ctus(oracle):
+    w = weights.random_weights(5)
+    ws = op.weights_from_arrays(w)
+    luma = frames.texture16_luma(416, 240)
+    buf, org, stride = frames.to_pel_plane(luma, 8)
+    depth = np.zeros(28 * 256, np.uint8)
+    oracle.fho_predict_frame(ws, op.ptr(buf.reshape(-1), org), stride, 416, 240, 8, depth, None)
+    depth = depth.reshape(4, 7, 16, 16)
+    assert (depth[:, 6, :, 8:] == 0).all()     # last CTU column is 32 px wide
+    assert (depth[3, :, 12:, :] == 0).all()    # last CTU row is 48 px tall
+    assert (depth[3, :6, 8:12, :] >= 2).all()  # 32x32 blocks crossing the bottom edge are split
+    assert (depth[:3, 6, :, :8] >= 1).all()    # CTUs crossing the right edge are split at 64
