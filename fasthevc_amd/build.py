@@ -12,6 +12,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libfasthevc_hip.so")
 SOURCES = ["fhevc_api.hip", "k_cnn.hip", "k_hadamard.hip", "k_firstpass.hip"]
+# per-source extra flags: the CNN kernel holds only finite integers in fp32, so the NaN-canonicalising v_max can go
+EXTRA = {"k_cnn.hip": ["-ffinite-math-only", "-fno-signed-zeros"]}
 # -ffp-contract=off: the first-pass cost is compared bit-for-bit with the CPU oracle's double arithmetic
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
 
@@ -33,7 +35,7 @@ def build_hip(force=False, verbose=False):
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         if force or _newer(o, [s] + headers):
-            jobs.append(["hipcc"] + FLAGS + ["-c", s, "-o", o])
+            jobs.append(["hipcc"] + FLAGS + EXTRA.get(src, []) + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:

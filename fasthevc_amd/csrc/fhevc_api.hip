@@ -118,8 +118,13 @@ int build_weight_image(fhevc_ctx* c, const BlobView& b)
     const int r = lane & 31, h = lane >> 5;
     for (int j = 0; j < 8; ++j) {
       const int k = 8 * h + j;
-      // conv1: row r = out channel (16 valid), k = tap (9 valid)
-      if (r < 16 && k < 9) put(FHEVC_FRAG_CONV1, lane, j, b.w1[r * 9 + k]);
+      // conv1: rows 0-15 = filter c on picture row y, rows 16-31 = filter c on row y+1; K slot k < 12 addresses the
+      // 4x3 input window: column dx = k >> 2, window row wr = 2 * ((k >> 1) & 1) + (k & 1) (row-pair dwords)
+      if (k < 12) {
+        const int dxi = k >> 2, wr = 2 * ((k >> 1) & 1) + (k & 1);
+        const int c = r & 15, ky = (r < 16) ? wr : wr - 1;
+        if (ky >= 0 && ky <= 2) put(FHEVC_FRAG_CONV1, lane, j, b.w1[c * 9 + ky * 3 + dxi]);
+      }
       // conv2: K-step s = tap, k = input channel
       for (int s = 0; s < 9; ++s) put(FHEVC_FRAG_CONV2 + s * 64, lane, j, b.w2[((r * 16 + k) * 9) + s]);
       // conv3: tile t = 32 output channels; K-step s: tap = s>>1, input channel = 16*(s&1) + k
@@ -411,6 +416,31 @@ int fhevc_intra_first_pass(fhevc_ctx* c, const int16_t* luma, int stride_samples
   HIP_TRY(c, hipMemcpyAsync(out, c->d_nodes, (size_t)c->num_ctus * FHEVC_NODES_PER_CTU * sizeof(FhevcNodeCost), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->stats.kernels_launched++;
+  return FHEVC_OK;
+}
+
+// Diagnostic (not part of include/fasthevc.h): run the stamped instantiation of the depth kernel over a
+// device-resident batch and return per-phase cycle sums averaged over workgroups (P0..P5) + CTUs per workgroup.
+int fhevc_debug_cnn_phase_cycles(fhevc_ctx* c, const void* d_luma, int sample_bytes, int stride_samples,
+                                 long long frame_stride_samples, int num_frames, uint8_t* d_depth_map, double* out8)
+{
+  if (!c || !d_luma || !d_depth_map || !out8 || !c->have_weights) return FHEVC_E_INVALID;
+  hipSetDevice(c->device);
+  const FhevcFrames fr = frames_of(c, d_luma, sample_bytes, stride_samples, frame_stride_samples, num_frames, 0, c->ctus_y);
+  unsigned long long* d_st = nullptr;
+  const int max_grid = 2 * c->num_cus;
+  HIP_TRY(c, hipMalloc(&d_st, (size_t)max_grid * 8 * sizeof(unsigned long long)));
+  HIP_TRY(c, hipMemset(d_st, 0, (size_t)max_grid * 8 * sizeof(unsigned long long)));
+  int grid = 0;
+  HIP_TRY(c, fhevc_launch_cnn_stamped(fr, cnn_weights(c), d_depth_map, c->num_cus, d_st, &grid, c->stream));
+  std::vector<unsigned long long> h((size_t)max_grid * 8);
+  HIP_TRY(c, hipMemcpyAsync(h.data(), d_st, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  hipFree(d_st);
+  for (int k = 0; k < 8; ++k) out8[k] = 0;
+  for (int b = 0; b < grid; ++b) for (int k = 0; k < 6; ++k) out8[k] += (double)h[(size_t)b * 8 + k] / grid;
+  out8[6] = (double)num_frames * c->num_ctus / grid;
+  out8[7] = grid;
   return FHEVC_OK;
 }
 

@@ -38,6 +38,9 @@ struct FhevcCnnWeights {
 hipError_t fhevc_launch_cnn(const FhevcFrames& fr, const FhevcCnnWeights& w, uint8_t* d_depth, int32_t* d_logits,
                             int num_cus, hipStream_t stream);
 
+hipError_t fhevc_launch_cnn_stamped(const FhevcFrames& fr, const FhevcCnnWeights& w, uint8_t* d_depth, int num_cus,
+                                    unsigned long long* d_stamps, int* grid_out, hipStream_t stream);
+
 // ---- source Hadamard + SATD (k_hadamard.hip) ---------------------------------------------------------------
 hipError_t fhevc_launch_src_hadamard(const FhevcFrames& fr, int32_t* d_out, hipStream_t stream);
 hipError_t fhevc_launch_satd(const int16_t* d_org, int org_stride, const int16_t* d_cur, int cur_stride,

@@ -15,7 +15,10 @@
 //   * operands are fixed-point integers (|w| <= 127, activations 0..255, |acc| < 2^24) so the fp32
 //     accumulation is exact in any order -> the integer depth map is bit-exact against the CPU oracle;
 //   * ReLU/requant/max-pool are fused into the MFMA epilogue (in-lane max for the vertical pair,
-//     DPP quad_perm for the horizontal pair), FC heads run on v_dot4_u32_u8.
+//     DPP quad_perm for the horizontal pair), FC heads run on v_dot4_u32_u8 with weights resident in LDS;
+//   * conv1 packs two output rows into one MFMA: A rows 0-15 = the 16 filters applied to row y, rows 16-31 =
+//     the same filters shifted one row down, K = the 4x3 input window (12 of 16 slots), read as row-pair dwords;
+//   * the next CTU's samples are prefetched into registers while the heads of the current one run.
 #include "fhevc_internal.h"
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
@@ -35,20 +38,23 @@ constexpr int A2_PITCH = 18;                      // conv2 output 16x16 + halo
 constexpr int A2_PLANE = 18 * 18 * 16;            // 5184
 constexpr int R2_OFF = R1_OFF + R1_BYTES;         // R2: input CTU bf16 [66][68]; later A2 (4 planes)
 constexpr int R2_BYTES = 4 * A2_PLANE;            // 20736
-constexpr int IN_PITCH = 68;                      // bf16 elements per input row (66 used)
+constexpr int IN_PITCH = 68;                      // dwords per input row PAIR (66 used): lo = row 2j, hi = row 2j+1
 constexpr int BIAS_OFF = R2_OFF + R2_BYTES;       // float b1[16] b2[32] b3[64]
 constexpr int LOGIT_OFF = BIAS_OFF + 112 * 4;     // int logits[21][2]
-constexpr int LDS_BYTES = LOGIT_OFF + 48 * 4;     // 58368 -> two workgroups per CU
-static_assert(66 * IN_PITCH * 2 <= R2_BYTES, "input tile must fit the A2 region");
+constexpr int HEADW_OFF = LOGIT_OFF + 48 * 4;     // uint8 head weights (w+128): wh64, wh32, wh16 = 18432 B
+constexpr int LDS_BYTES = HEADW_OFF + 18432;      // 76800 -> two workgroups per CU (153.6 of 160 KiB)
+static_assert(33 * IN_PITCH * 4 <= R2_BYTES, "input tile must fit the A2 region");
+static_assert(HEADW_OFF % 16 == 0, "head weights are read with ds_read_b128");
 static_assert(P3_OFF + 4096 <= R1_OFF + R1_BYTES, "pooled map must fit R1");
 
 constexpr int HEAD64_OFF = 0, HEAD32_OFF = 2 * 4096, HEAD16_OFF = 4 * 4096;  // into whead (uint8, w+128)
 
-__device__ __forceinline__ float dpp_xor1(float v)  // value of the horizontally adjacent lane (quad_perm [1,0,3,2])
+// max(v, value of the horizontally adjacent lane): with old = 0 and bound_ctrl the DPP move folds into ONE
+// v_max_f32_dpp quad_perm:[1,0,3,2] (the (v, v, bound_ctrl = 0) form costs v_mov + v_mov_dpp + v_max)
+__device__ __forceinline__ float max_with_xor1(float v)
 {
-  int i = __builtin_bit_cast(int, v);
-  i = __builtin_amdgcn_update_dpp(i, i, 0xB1, 0xF, 0xF, false);
-  return __builtin_bit_cast(float, i);
+  const int o = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true);
+  return fmaxf(v, __builtin_bit_cast(float, o));
 }
 // two fp32 holding integers 0..255 -> two bf16 (exact: the low 16 mantissa bits are zero)
 __device__ __forceinline__ unsigned pack_bf16(float a, float b)
@@ -59,6 +65,11 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b)
 __device__ __forceinline__ float requant(float acc, float scale)
 {
   return __builtin_amdgcn_fmed3f(floorf(acc * scale), 0.0f, 255.0f);
+}
+// same with the bias folded in: (acc + b) * 2^-s == fma(acc, 2^-s, b * 2^-s), every term exact in fp32
+__device__ __forceinline__ float requant_b(float acc, float scale, float bias_scaled)
+{
+  return __builtin_amdgcn_fmed3f(floorf(__builtin_fmaf(acc, scale, bias_scaled)), 0.0f, 255.0f);
 }
 __device__ __forceinline__ bf16x8 lds_frag(const unsigned char* p)
 {
@@ -98,11 +109,144 @@ __device__ __forceinline__ int load_centered(const T* p, int shift)
   return v - 128;
 }
 
+// ---- fused epilogues (forceinline: everything stays in registers) ------------------------------------------
+// 16-lane row sum with DPP only (every lane ends with the row total)
+__device__ __forceinline__ int dpp_row_sum(int v)
+{
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);  // row_half_mirror
+  v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);  // row_mirror
+  return v;
+}
+// conv1: acc rows 0-15 = picture row y, rows 16-31 = row y+1 -> 2x2 max-pool, requant, store 4 channels (8 B)
+__device__ __forceinline__ void conv1_store(const f32x16& acc, float scale, unsigned char* lds, int yp, int xh, int r, int h)
+{
+  float v[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float m = max_with_xor1(fmaxf(acc[k], acc[k + 8]));  // vertical pair in-lane, horizontal pair by DPP
+    v[k] = requant(m, scale);
+  }
+  // channels: regs 0-3 -> 4h+k (plane 0), regs 4-7 -> 8+4h+k (plane 1); even lane stores plane 0, odd plane 1
+  const unsigned p0a = pack_bf16(v[0], v[1]), p0b = pack_bf16(v[2], v[3]);
+  const unsigned p1a = pack_bf16(v[4], v[5]), p1b = pack_bf16(v[6], v[7]);
+  const int pl = r & 1;
+  uint2 o;
+  o.x = pl ? p1a : p0a;
+  o.y = pl ? p1b : p0b;
+  const int pcol = 16 * xh + (r >> 1) + 1;
+  *reinterpret_cast<uint2*>(lds + R1_OFF + pl * A1_PLANE + ((yp + 1) * A1_PITCH + pcol) * 16 + h * 8) = o;
+}
+// conv2: two output rows -> 2x2 max-pool, requant, store 16 channels of this lane half (4 planes x 8 B)
+__device__ __forceinline__ void conv2_store(const f32x16& acc0, const f32x16& acc1, const float* bias32, float scale,
+                                            unsigned char* lds, int yp, int r, int h)
+{
+  const f32x16 b = bias_tile(bias32, h);  // pre-scaled bias, added after the pool (max(a,b)+c == max(a+c,b+c))
+  float v[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) v[k] = requant_b(max_with_xor1(fmaxf(acc0[k], acc1[k])), scale, b[k]);
+  if ((r & 1) == 0) {  // regs 4g..4g+3 -> channels 8g+4h.. of plane g
+    unsigned char* dst = lds + R2_OFF + ((yp + 1) * A2_PITCH + (r >> 1) + 1) * 16 + h * 8;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<uint2*>(dst + g * A2_PLANE) =
+          make_uint2(pack_bf16(v[4 * g], v[4 * g + 1]), pack_bf16(v[4 * g + 2], v[4 * g + 3]));
+  }
+}
+// conv3: requant to u8, 16 channels of this lane half for one position
+// dst = start of the position's 64-byte row + 4*h; channel 32*tile + 8*g + 4*h + k lives in logical 16-B chunk
+// 2*tile + (g >> 1), at byte 8*(g & 1) + 4*h + k; psw = chunk swizzle of this position
+__device__ __forceinline__ void conv3_store(const f32x16& acc, const float* bias32, int h, float scale, unsigned char* dst,
+                                            int tile, int psw)
+{
+  const f32x16 b = bias_tile(bias32, h);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    unsigned d = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d = __builtin_amdgcn_cvt_pk_u8_f32(requant_b(acc[4 * g + k], scale, b[4 * g + k]), k, d);
+    *reinterpret_cast<unsigned*>(dst + (((2 * tile + (g >> 1)) ^ psw) << 4) + 8 * (g & 1)) = d;
+  }
+}
+
+// conv2 MFMA chain of one unit = output rows 2yp, 2yp+1 (32 positions each), K = 9 taps x 16 channels
+__device__ __forceinline__ void conv2_unit(const unsigned char* a1, int yp, const bf16x8 (&wA2)[9], f32x16& acc0, f32x16& acc1)
+{
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { acc0[k] = 0.0f; acc1[k] = 0.0f; }
+#pragma unroll
+  for (int ir = 0; ir < 4; ++ir) {  // input rows 2yp-1 .. 2yp+2 (halo coordinates 2yp .. 2yp+3)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const bf16x8 b = lds_frag(a1 + ((2 * yp + ir) * A1_PITCH + kx) * 16);
+      if (ir < 3) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA2[ir * 3 + kx], b, acc0, 0, 0, 0);
+      if (ir > 0) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA2[(ir - 1) * 3 + kx], b, acc1, 0, 0, 0);
+    }
+  }
+}
+// conv3 MFMA chain of one unit = 32 output channels x 32 positions (rows 2yp, 2yp+1), K = 9 taps x 32 channels
+__device__ __forceinline__ f32x16 conv3_unit(const unsigned char* a2, int yp, const bf16x8 (&wA3)[18])
+{
+  f32x16 acc;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) acc[k] = 0.0f;
+  const unsigned char* base = a2 + (2 * yp) * A2_PITCH * 16;
+#pragma unroll
+  for (int s = 0; s < 18; ++s) {
+    const int tap = s >> 1, cb = s & 1;
+    const bf16x8 b = lds_frag(base + 2 * cb * A2_PLANE + ((tap / 3) * A2_PITCH + (tap % 3)) * 16);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA3[s], b, acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+// One thread's 16 samples of a CTU (picture row ld_row, columns 16*ld_seg..) fetched ahead of use.  fast = 0:
+// picture edge or unaligned plane, P0 falls back to guarded scalar loads.
+struct Prefetched { uint4 a, b; int fast; };
+__device__ __forceinline__ Prefetched prefetch_ctu(const FhevcFrames& F, int wk, int total, int per_frame, int ld_row, int ld_seg)
+{
+  Prefetched p;
+  p.a = make_uint4(0, 0, 0, 0); p.b = make_uint4(0, 0, 0, 0); p.fast = 0;
+  if (wk >= total) return p;
+  const int pf = wk / per_frame, prem = wk - pf * per_frame;
+  const int pcy = F.row_begin + prem / F.ctus_x, pcx = prem % F.ctus_x;
+  const int py = pcy * 64 + ld_row, px0 = pcx * 64 + ld_seg * 16;
+  if (py >= F.height || px0 + 16 > F.width) return p;
+  const long long base = (long long)pf * F.frame_stride + (long long)py * F.stride + px0;
+  if (F.sample_bytes == 2) {
+    const int16_t* src = reinterpret_cast<const int16_t*>(F.luma) + base;
+    if (reinterpret_cast<uintptr_t>(src) & 15) return p;
+    p.a = *reinterpret_cast<const uint4*>(src);
+    p.b = *reinterpret_cast<const uint4*>(src + 8);
+  } else {
+    const uint8_t* src = reinterpret_cast<const uint8_t*>(F.luma) + base;
+    if (reinterpret_cast<uintptr_t>(src) & 15) return p;
+    p.a = *reinterpret_cast<const uint4*>(src);
+  }
+  p.fast = 1;
+  return p;
+}
+
+// in-kernel stamp (diagnostic build only): s_memtime with its own lgkmcnt wait, fenced against reordering
+__device__ __forceinline__ unsigned long long stamp()
+{
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+
+// STAMPS = true is a separate diagnostic instantiation (fhevc_debug_cnn_phase_cycles): wave 0 of every workgroup
+// adds the cycles of each phase (incl. the barrier that ends it) into d_stamps[blockIdx.x * 8 + phase].
+template <bool STAMPS>
 __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, FhevcCnnWeights W,
                                                                   uint8_t* __restrict__ d_depth,
-                                                                  int32_t* __restrict__ d_logits)
+                                                                  int32_t* __restrict__ d_logits,
+                                                                  unsigned long long* __restrict__ d_stamps)
 {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -119,12 +263,27 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
 
   float* biasL = reinterpret_cast<float*>(lds + BIAS_OFF);
   int* logitL = reinterpret_cast<int*>(lds + LOGIT_OFF);
-  if (tid < 112) biasL[tid] = W.bias[tid];
+  if (tid < 112) biasL[tid] = W.bias[tid] * (tid < 16 ? 1.0f : (tid < 48 ? W.scale[1] : W.scale[2]));  // exact: integer * 2^-s
+  for (int i = tid; i < 18432 / 16; i += 256)  // head weights stay in LDS for the life of the workgroup
+    *reinterpret_cast<uint4*>(lds + HEADW_OFF + i * 16) = reinterpret_cast<const uint4*>(W.whead)[i];
 
   const int band_rows = F.row_end - F.row_begin;
   const int per_frame = band_rows * F.ctus_x;
   const int total = per_frame * F.num_frames;
   const int shift_in = F.bit_depth - 8;
+
+  unsigned long long tsum[7] = { 0, 0, 0, 0, 0, 0, 0 }, tprev = 0;
+#define FHEVC_STAMP(k)                                     \
+  if (STAMPS) {                                            \
+    const unsigned long long tn = stamp();                 \
+    tsum[k] += tn - tprev;                                 \
+    tprev = tn;                                            \
+  }
+  if (STAMPS) tprev = stamp();
+
+  // this thread's 16 samples of a CTU: picture row (tid >> 2), columns 16 * (tid & 3) ..
+  const int ld_row = tid >> 2, ld_seg = tid & 3;
+  Prefetched pre = prefetch_ctu(F, blockIdx.x, total, per_frame, ld_row, ld_seg);
 
   for (int work = blockIdx.x; work < total; work += gridDim.x) {
     const int f = work / per_frame;
@@ -132,50 +291,41 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
     const int cy = F.row_begin + rem / F.ctus_x;
     const int cx = rem % F.ctus_x;
 
-    // ================= P0: CTU -> LDS (centred 8-bit as bf16, halo 0); zero the A1 halo =================
+    // ====== P0: CTU -> LDS: centred 8-bit samples as bf16, two picture rows per dword, halo 0; zero the A1 halo ======
     {
-      unsigned short* in = reinterpret_cast<unsigned short*>(lds + R2_OFF);
-      const int row = tid >> 2, seg = tid & 3;
-      const int py = cy * 64 + row, px0 = cx * 64 + seg * 16;
-      const long long base = (long long)f * F.frame_stride + (long long)py * F.stride + px0;
-      unsigned short* dst = in + (row + 1) * IN_PITCH + seg * 16 + 1;
-      const bool row_ok = py < F.height;
-      if (F.sample_bytes == 2) {
-        const int16_t* src = reinterpret_cast<const int16_t*>(F.luma) + base;
-        if (row_ok && px0 + 16 <= F.width && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
-          const uint4 q0 = *reinterpret_cast<const uint4*>(src), q1 = *reinterpret_cast<const uint4*>(src + 8);
-          const unsigned wds[8] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w };
+      // halo coordinates: hy = row + 1, hx = col + 1; dword (hy >> 1) * IN_PITCH + hx, half (hy & 1)
+      unsigned short* inh = reinterpret_cast<unsigned short*>(lds + R2_OFF);
+      const int hy = ld_row + 1;
+      unsigned short* dst = inh + 2 * ((hy >> 1) * IN_PITCH + ld_seg * 16 + 1) + (hy & 1);
+      if (pre.fast) {
+        if (F.sample_bytes == 2) {
+          const unsigned wds[8] = { pre.a.x, pre.a.y, pre.a.z, pre.a.w, pre.b.x, pre.b.y, pre.b.z, pre.b.w };
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             short s0 = (short)(wds[j] & 0xFFFF), s1 = (short)(wds[j] >> 16);
-            dst[2 * j] = (unsigned short)(__float_as_uint((float)load_centered(&s0, shift_in)) >> 16);
-            dst[2 * j + 1] = (unsigned short)(__float_as_uint((float)load_centered(&s1, shift_in)) >> 16);
+            dst[4 * j] = (unsigned short)(__float_as_uint((float)load_centered(&s0, shift_in)) >> 16);
+            dst[4 * j + 2] = (unsigned short)(__float_as_uint((float)load_centered(&s1, shift_in)) >> 16);
           }
         } else {
-#pragma unroll 4
-          for (int j = 0; j < 16; ++j) {
-            int v = 0;
-            if (row_ok && px0 + j < F.width) v = load_centered(src + j, shift_in);
-            dst[j] = (unsigned short)(__float_as_uint((float)v) >> 16);
-          }
-        }
-      } else {
-        const uint8_t* src = reinterpret_cast<const uint8_t*>(F.luma) + base;
-        if (row_ok && px0 + 16 <= F.width && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
-          const uint4 q = *reinterpret_cast<const uint4*>(src);
-          const unsigned wds[4] = { q.x, q.y, q.z, q.w };
+          const unsigned wds[4] = { pre.a.x, pre.a.y, pre.a.z, pre.a.w };
 #pragma unroll
           for (int j = 0; j < 16; ++j) {
-            int v = (int)((wds[j >> 2] >> (8 * (j & 3))) & 0xFF) - 128;
-            dst[j] = (unsigned short)(__float_as_uint((float)v) >> 16);
+            const int v = (int)((wds[j >> 2] >> (8 * (j & 3))) & 0xFF) - 128;
+            dst[2 * j] = (unsigned short)(__float_as_uint((float)v) >> 16);
           }
-        } else {
+        }
+      } else {  // picture edge or unaligned plane: guarded scalar loads
+        const int py = cy * 64 + ld_row, px0 = cx * 64 + ld_seg * 16;
+        const long long base = (long long)f * F.frame_stride + (long long)py * F.stride + px0;
+        const bool row_ok = py < F.height;
 #pragma unroll 4
-          for (int j = 0; j < 16; ++j) {
-            int v = 0;
-            if (row_ok && px0 + j < F.width) v = (int)src[j] - 128;
-            dst[j] = (unsigned short)(__float_as_uint((float)v) >> 16);
+        for (int j = 0; j < 16; ++j) {
+          int v = 0;
+          if (row_ok && px0 + j < F.width) {
+            if (F.sample_bytes == 2) v = load_centered(reinterpret_cast<const int16_t*>(F.luma) + base + j, shift_in);
+            else v = (int)reinterpret_cast<const uint8_t*>(F.luma)[base + j] - 128;
           }
+          dst[2 * j] = (unsigned short)(__float_as_uint((float)v) >> 16);
         }
       }
       // input halo: 66*66 - 64*64 = 260 positions
@@ -184,7 +334,7 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
         if (e < 66) { y = 0; x = e; }
         else if (e < 132) { y = 65; x = e - 66; }
         else { const int k = e - 132; y = 1 + (k >> 1); x = (k & 1) ? 65 : 0; }
-        in[y * IN_PITCH + x] = 0;
+        inh[2 * ((y >> 1) * IN_PITCH + x) + (y & 1)] = 0;
       }
       // A1 halo: 132 positions x 2 planes
       for (int e = tid; e < 264; e += 256) {
@@ -197,65 +347,51 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
       }
     }
     __syncthreads();
+    FHEVC_STAMP(0)
 
-    // ================= P1: conv1 (1 -> 16), K = 9 taps padded to 16, fused maxpool + requant =================
+    // ====== P1: conv1 (1 -> 16): one MFMA per 32 positions x 2 rows, K = 4x3 window, fused maxpool + requant ======
     {
       if (tid < 42) {  // logits start from the head biases
         const int k = tid >> 1, cls = tid & 1;
         logitL[tid] = W.bhead[(k == 0 ? 0 : (k < 5 ? 2 : 4)) + cls];
       }
-      const unsigned short* in = reinterpret_cast<const unsigned short*>(lds + R2_OFF);
-      int toff[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) toff[j] = h ? (j == 0 ? 2 * IN_PITCH + 2 : 0) : ((j / 3) * IN_PITCH + (j % 3));
+      const unsigned* inp = reinterpret_cast<const unsigned*>(lds + R2_OFF);
+      // K slots: lanes h=0 hold columns x-1 and x, lanes h=1 column x+1 (+ 4 zero slots);
+      // inside a column: row pair (2yp-1, 2yp), then (2yp+1, 2yp+2)
+      const int c0 = h ? 2 : 0;
       const unsigned hmask = h ? 0u : 0xFFFFFFFFu;
       f32x16 bias1;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) bias1[i] = 0.0f;
       {
         const float4 b0 = *reinterpret_cast<const float4*>(biasL + 4 * h);
         const float4 b1 = *reinterpret_cast<const float4*>(biasL + 8 + 4 * h);
         bias1[0] = b0.x; bias1[1] = b0.y; bias1[2] = b0.z; bias1[3] = b0.w;
         bias1[4] = b1.x; bias1[5] = b1.y; bias1[6] = b1.z; bias1[7] = b1.w;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bias1[8 + i] = bias1[i];  // rows 16-31: the same filters, one picture row lower
       }
+      // software pipeline: MFMA of unit i is in flight while unit i-1 is pooled, requantised and stored
+      auto frag1 = [=](int u) {
+        const unsigned* p = inp + (u >> 1) * IN_PITCH + 32 * (u & 1) + r;
+        uint4 q;
+        q.x = p[c0];
+        q.y = p[IN_PITCH + c0];
+        q.z = p[1] & hmask;
+        q.w = p[IN_PITCH + 1] & hmask;
+        return __builtin_bit_cast(bf16x8, q);
+      };
+      // two accumulators in flight (no register copies): while one MFMA runs, the other unit is stored
+      f32x16 accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA1, frag1(wave), bias1, 0, 0, 0);
 #pragma unroll 1
-      for (int i = 0; i < 16; ++i) {
-        const int u = wave + 4 * i;
-        const int yp = u >> 1, xh = u & 1;
-        const int x = 32 * xh + r;
-        f32x16 acc[2];
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-          const int base = (2 * yp + rr) * IN_PITCH + x;
-          unsigned e[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) e[j] = in[base + toff[j]];
-          uint4 q;
-          q.x = e[0] | ((e[1] & hmask) << 16);
-          q.y = (e[2] | (e[3] << 16)) & hmask;
-          q.z = (e[4] | (e[5] << 16)) & hmask;
-          q.w = (e[6] | (e[7] << 16)) & hmask;
-          acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA1, __builtin_bit_cast(bf16x8, q), bias1, 0, 0, 0);
-        }
-        float v[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          float m = fmaxf(acc[0][k], acc[1][k]);
-          m = fmaxf(m, dpp_xor1(m));
-          v[k] = requant(m, W.scale[0]);
-        }
-        // channels: regs 0-3 -> 4h+k (plane 0), regs 4-7 -> 8+4h+k (plane 1); even lane stores plane 0, odd plane 1
-        const unsigned p0a = pack_bf16(v[0], v[1]), p0b = pack_bf16(v[2], v[3]);
-        const unsigned p1a = pack_bf16(v[4], v[5]), p1b = pack_bf16(v[6], v[7]);
-        const int pl = r & 1;
-        uint2 o;
-        o.x = pl ? p1a : p0a;
-        o.y = pl ? p1b : p0b;
-        const int pcol = 16 * xh + (r >> 1) + 1;
-        *reinterpret_cast<uint2*>(lds + R1_OFF + pl * A1_PLANE + ((yp + 1) * A1_PITCH + pcol) * 16 + h * 8) = o;
+      for (int i = 0; i < 16; i += 2) {
+        const int ua = wave + 4 * i, ub = ua + 4, uc = min(ua + 8, 60 + wave);  // uc: next A unit (clamped, last is redundant)
+        const f32x16 accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA1, frag1(ub), bias1, 0, 0, 0);
+        conv1_store(accA, W.scale[0], lds, ua >> 1, ua & 1, r, h);
+        accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA1, frag1(uc), bias1, 0, 0, 0);
+        conv1_store(accB, W.scale[0], lds, ub >> 1, ub & 1, r, h);
       }
     }
     __syncthreads();
+    FHEVC_STAMP(1)
 
     // ================= P2: conv2 (16 -> 32), K = 9 taps x 16 ch, fused maxpool + requant =================
     {
@@ -268,125 +404,98 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
         else { const int k = k0 - 36; y = 1 + (k >> 1); x = (k & 1) ? 17 : 0; }
         *reinterpret_cast<uint4*>(lds + R2_OFF + pl * A2_PLANE + (y * A2_PITCH + x) * 16) = make_uint4(0, 0, 0, 0);
       }
-      const unsigned char* a1 = lds + R1_OFF + h * A1_PLANE + r * 16;
-      const f32x16 bias2 = bias_tile(biasL + 16, h);
-#pragma unroll 1
-      for (int i = 0; i < 4; ++i) {
-        const int yp = wave + 4 * i;
-        f32x16 acc0 = bias2, acc1 = bias2;
-#pragma unroll
-        for (int ir = 0; ir < 4; ++ir) {  // input rows 2yp-1 .. 2yp+2 (halo coordinates 2yp .. 2yp+3)
-#pragma unroll
-          for (int kx = 0; kx < 3; ++kx) {
-            const bf16x8 b = lds_frag(a1 + ((2 * yp + ir) * A1_PITCH + kx) * 16);
-            if (ir < 3) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA2[ir * 3 + kx], b, acc0, 0, 0, 0);
-            if (ir > 0) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA2[(ir - 1) * 3 + kx], b, acc1, 0, 0, 0);
-          }
-        }
-        float v[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          float m = fmaxf(acc0[k], acc1[k]);
-          m = fmaxf(m, dpp_xor1(m));
-          v[k] = requant(m, W.scale[1]);
-        }
-        if ((r & 1) == 0) {  // regs 4g..4g+3 -> channels 8g+4h.. of plane g
-          unsigned char* dst = lds + R2_OFF + ((yp + 1) * A2_PITCH + (r >> 1) + 1) * 16 + h * 8;
-#pragma unroll
-          for (int g = 0; g < 4; ++g)
-            *reinterpret_cast<uint2*>(dst + g * A2_PLANE) =
-                make_uint2(pack_bf16(v[4 * g], v[4 * g + 1]), pack_bf16(v[4 * g + 2], v[4 * g + 3]));
-        }
-      }
+      const unsigned char* a1p = lds + R1_OFF + h * A1_PLANE + r * 16;
+      // straight-line software pipeline over the wave's 4 units: the MFMA chain of unit i+1 is issued before the
+      // VALU epilogue of unit i, so the scheduler can interleave them (separate pipes)
+      f32x16 a0, a1, b0, b1;
+      conv2_unit(a1p, wave, wA2, a0, a1);
+      conv2_unit(a1p, wave + 4, wA2, b0, b1);
+      conv2_store(a0, a1, biasL + 16, W.scale[1], lds, wave, r, h);
+      conv2_unit(a1p, wave + 8, wA2, a0, a1);
+      conv2_store(b0, b1, biasL + 16, W.scale[1], lds, wave + 4, r, h);
+      conv2_unit(a1p, wave + 12, wA2, b0, b1);
+      conv2_store(a0, a1, biasL + 16, W.scale[1], lds, wave + 8, r, h);
+      conv2_store(b0, b1, biasL + 16, W.scale[1], lds, wave + 12, r, h);
     }
     __syncthreads();
+    FHEVC_STAMP(2)
 
     // ================= P3: conv3 (32 -> 64), K = 9 taps x 32 ch, requant to u8 =================
     {
       const int yy = r >> 4, x = r & 15;
-      const f32x16 bias3 = bias_tile(biasL + 48 + 32 * tile3, h);
-#pragma unroll 1
-      for (int i = 0; i < 4; ++i) {
-        const int yp = (wave >> 1) + 2 * i;
-        const unsigned char* a2 = lds + R2_OFF + h * A2_PLANE + ((2 * yp + yy) * A2_PITCH + x) * 16;
-        f32x16 acc = bias3;
-#pragma unroll
-        for (int s = 0; s < 18; ++s) {
-          const int tap = s >> 1, cb = s & 1;
-          const bf16x8 b = lds_frag(a2 + 2 * cb * A2_PLANE + ((tap / 3) * A2_PITCH + (tap % 3)) * 16);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA3[s], b, acc, 0, 0, 0);
-        }
-        unsigned char* dst = lds + A3_OFF + ((2 * yp + yy) * 16 + x) * 64 + 32 * tile3 + 4 * h;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          unsigned d = 0;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) d = __builtin_amdgcn_cvt_pk_u8_f32(requant(acc[4 * g + k], W.scale[2]), k, d);
-          *reinterpret_cast<unsigned*>(dst + 8 * g) = d;
-        }
-      }
+      const float* bias3 = biasL + 48 + 32 * tile3;
+      const unsigned char* a2 = lds + R2_OFF + h * A2_PLANE + (yy * A2_PITCH + x) * 16;
+      // a3 row of a position p = 64 B = four 16-B chunks; chunk c is stored at c ^ ((p >> 2) & 3) so that the 16
+      // lanes of a ds_read_b128 group in the heads (consecutive positions, same logical chunk) hit 16 distinct slots
+      const int psw = (x >> 2) & 3;  // ((yy * 16 + x) >> 2) & 3, rows are 16 positions
+      unsigned char* a3dst = lds + A3_OFF + (yy * 16 + x) * 64 + 4 * h;
+      const int yp0 = wave >> 1;
+      f32x16 accA = conv3_unit(a2, yp0, wA3);
+      f32x16 accB = conv3_unit(a2, yp0 + 2, wA3);
+      conv3_store(accA, bias3, h, W.scale[2], a3dst + (yp0 + 0) * 2048, tile3, psw);
+      accA = conv3_unit(a2, yp0 + 4, wA3);
+      conv3_store(accB, bias3, h, W.scale[2], a3dst + (yp0 + 2) * 2048, tile3, psw);
+      accB = conv3_unit(a2, yp0 + 6, wA3);
+      conv3_store(accA, bias3, h, W.scale[2], a3dst + (yp0 + 4) * 2048, tile3, psw);
+      conv3_store(accB, bias3, h, W.scale[2], a3dst + (yp0 + 6) * 2048, tile3, psw);
     }
     __syncthreads();
+    FHEVC_STAMP(3)
 
-    // ================= P4: FC heads on v_dot4_u32_u8 (weights stored as w+128) =================
+    // ================= P4: FC heads on v_dot4_u32_u8 (weights stored as w+128, resident in LDS) =================
+    pre = prefetch_ctu(F, work + gridDim.x, total, per_frame, ld_row, ld_seg);  // travels while the heads run
     {
-      const int p = tid, y = p >> 4, x = p & 15;
-      const unsigned char* arow = lds + A3_OFF + p * 64;
-      const unsigned char* w16 = W.whead + HEAD16_OFF + ((y & 3) * 4 + (x & 3)) * 64;
-      const unsigned char* w32 = W.whead + HEAD32_OFF + ((y & 7) * 8 + (x & 7)) * 64;
-      unsigned sa = 0, s16a = 0, s16b = 0, s32a = 0, s32b = 0;
-#pragma unroll 1
-      for (int q = 0; q < 4; ++q) {  // 16 channels per step: keeps the register footprint of this phase small
-        const uint4 a = *reinterpret_cast<const uint4*>(arow + q * 16);
-        const uint4 b0 = *reinterpret_cast<const uint4*>(w16 + q * 16), b1 = *reinterpret_cast<const uint4*>(w16 + 1024 + q * 16);
-        const uint4 c0 = *reinterpret_cast<const uint4*>(w32 + q * 16), c1 = *reinterpret_cast<const uint4*>(w32 + 4096 + q * 16);
+      // wave = 32x32 quadrant q; 16-lane DPP row = one 16x16 block of it; lane bits [1:0] = x & 3, [3:2] = y & 3
+      const int q = wave, blk = lane >> 4;
+      const int y = (q >> 1) * 8 + (blk >> 1) * 4 + ((lane >> 2) & 3);
+      const int x = (q & 1) * 8 + (blk & 1) * 4 + (lane & 3);
+      const unsigned char* arow = lds + A3_OFF + (y * 16 + x) * 64;
+      const int psw = (x >> 2) & 3;  // chunk swizzle of this position (see P3)
+      const unsigned char* w16 = lds + HEADW_OFF + HEAD16_OFF + ((y & 3) * 4 + (x & 3)) * 64;
+      const unsigned char* w32 = lds + HEADW_OFF + HEAD32_OFF + ((y & 7) * 8 + (x & 7)) * 64;
+      const unsigned char* w64 = lds + HEADW_OFF + HEAD64_OFF + ((y >> 1) * 8 + (x >> 1)) * 64;  // 2x2 sum pool
+      unsigned sa = 0, s16a = 0, s16b = 0, s32a = 0, s32b = 0, s64a = 0, s64b = 0;
+#pragma unroll 2
+      for (int qq = 0; qq < 4; ++qq) {  // 16 channels per step keeps this phase's register footprint small
+        const uint4 a = *reinterpret_cast<const uint4*>(arow + ((qq ^ psw) << 4));
+        const uint4 b0 = *reinterpret_cast<const uint4*>(w16 + qq * 16), b1 = *reinterpret_cast<const uint4*>(w16 + 1024 + qq * 16);
+        const uint4 c0 = *reinterpret_cast<const uint4*>(w32 + qq * 16), c1 = *reinterpret_cast<const uint4*>(w32 + 4096 + qq * 16);
+        const uint4 d0 = *reinterpret_cast<const uint4*>(w64 + qq * 16), d1 = *reinterpret_cast<const uint4*>(w64 + 4096 + qq * 16);
         sa = udot4(a.x, 0x01010101u, sa); sa = udot4(a.y, 0x01010101u, sa); sa = udot4(a.z, 0x01010101u, sa); sa = udot4(a.w, 0x01010101u, sa);
         s16a = udot4(a.x, b0.x, s16a); s16a = udot4(a.y, b0.y, s16a); s16a = udot4(a.z, b0.z, s16a); s16a = udot4(a.w, b0.w, s16a);
         s16b = udot4(a.x, b1.x, s16b); s16b = udot4(a.y, b1.y, s16b); s16b = udot4(a.z, b1.z, s16b); s16b = udot4(a.w, b1.w, s16b);
         s32a = udot4(a.x, c0.x, s32a); s32a = udot4(a.y, c0.y, s32a); s32a = udot4(a.z, c0.z, s32a); s32a = udot4(a.w, c0.w, s32a);
         s32b = udot4(a.x, c1.x, s32b); s32b = udot4(a.y, c1.y, s32b); s32b = udot4(a.z, c1.z, s32b); s32b = udot4(a.w, c1.w, s32b);
+        s64a = udot4(a.x, d0.x, s64a); s64a = udot4(a.y, d0.y, s64a); s64a = udot4(a.z, d0.z, s64a); s64a = udot4(a.w, d0.w, s64a);
+        s64b = udot4(a.x, d1.x, s64b); s64b = udot4(a.y, d1.y, s64b); s64b = udot4(a.z, d1.z, s64b); s64b = udot4(a.w, d1.w, s64b);
       }
-      const int part16[2] = { (int)s16a - 128 * (int)sa, (int)s16b - 128 * (int)sa };
-      const int part32[2] = { (int)s32a - 128 * (int)sa, (int)s32b - 128 * (int)sa };
-      // 64-level head: features = maxpool2x2(a3); the thread at an even (y, x) owns pooled position (y/2, x/2)
-      int part64[2] = { 0, 0 };
-      if (((y | x) & 1) == 0) {
-        unsigned sp = 0, s0 = 0, s1 = 0;
-        const unsigned char* w64 = W.whead + HEAD64_OFF + ((y >> 1) * 8 + (x >> 1)) * 64;
-#pragma unroll 1
-        for (int q = 0; q < 4; ++q) {
-          const uint4 a = *reinterpret_cast<const uint4*>(arow + q * 16);
-          const uint4 b = *reinterpret_cast<const uint4*>(arow + 64 + q * 16);
-          const uint4 c = *reinterpret_cast<const uint4*>(arow + 16 * 64 + q * 16);
-          const uint4 d = *reinterpret_cast<const uint4*>(arow + 17 * 64 + q * 16);
-          uint4 m;
-          m.x = bytemax(bytemax(a.x, b.x), bytemax(c.x, d.x));
-          m.y = bytemax(bytemax(a.y, b.y), bytemax(c.y, d.y));
-          m.z = bytemax(bytemax(a.z, b.z), bytemax(c.z, d.z));
-          m.w = bytemax(bytemax(a.w, b.w), bytemax(c.w, d.w));
-          const uint4 u0 = *reinterpret_cast<const uint4*>(w64 + q * 16), u1 = *reinterpret_cast<const uint4*>(w64 + 4096 + q * 16);
-          sp = udot4(m.x, 0x01010101u, sp); sp = udot4(m.y, 0x01010101u, sp);
-          sp = udot4(m.z, 0x01010101u, sp); sp = udot4(m.w, 0x01010101u, sp);
-          s0 = udot4(m.x, u0.x, s0); s0 = udot4(m.y, u0.y, s0); s0 = udot4(m.z, u0.z, s0); s0 = udot4(m.w, u0.w, s0);
-          s1 = udot4(m.x, u1.x, s1); s1 = udot4(m.y, u1.y, s1); s1 = udot4(m.z, u1.z, s1); s1 = udot4(m.w, u1.w, s1);
-        }
-        part64[0] = (int)s0 - 128 * (int)sp;
-        part64[1] = (int)s1 - 128 * (int)sp;
+      // reductions: DPP inside the 16-lane row (= one 16x16 block), v_readlane across the four rows of the wave
+      const int corr = 128 * (int)sa;
+      const int r16a = dpp_row_sum((int)s16a - corr), r16b = dpp_row_sum((int)s16b - corr);
+      const int r32a = dpp_row_sum((int)s32a - corr), r32b = dpp_row_sum((int)s32b - corr);
+      const int r64a = dpp_row_sum((int)s64a - corr), r64b = dpp_row_sum((int)s64b - corr);
+      if ((lane & 15) == 0) {  // one owner per 16x16 block: no atomics
+        const int bi = ((q >> 1) * 2 + (blk >> 1)) * 4 + (q & 1) * 2 + (blk & 1);
+        logitL[(5 + bi) * 2 + 0] += r16a;
+        logitL[(5 + bi) * 2 + 1] += r16b;
       }
-      // wave = 4 rows of 16 positions: lane bits 0-3 = x, bits 4-5 = y & 3
-#pragma unroll
-      for (int cls = 0; cls < 2; ++cls) {
-        int s16 = part16[cls], s32 = part32[cls], s64 = part64[cls];
-        s16 += __shfl_xor(s16, 1); s16 += __shfl_xor(s16, 2); s16 += __shfl_xor(s16, 16); s16 += __shfl_xor(s16, 32);
-        s32 += __shfl_xor(s32, 1); s32 += __shfl_xor(s32, 2); s32 += __shfl_xor(s32, 4); s32 += __shfl_xor(s32, 16); s32 += __shfl_xor(s32, 32);
-#pragma unroll
-        for (int m = 1; m < 64; m <<= 1) s64 += __shfl_xor(s64, m);
-        if ((lane & 0x33) == 0) atomicAdd(&logitL[(5 + wave * 4 + (lane >> 2)) * 2 + cls], s16);  // one owner per 16x16 block
-        if ((lane & 0x37) == 0) atomicAdd(&logitL[(1 + (wave >> 1) * 2 + (lane >> 3)) * 2 + cls], s32);
-        if (lane == 0) atomicAdd(&logitL[cls], s64);
+      const int q32a = __builtin_amdgcn_readlane(r32a, 0) + __builtin_amdgcn_readlane(r32a, 16) +
+                       __builtin_amdgcn_readlane(r32a, 32) + __builtin_amdgcn_readlane(r32a, 48);
+      const int q32b = __builtin_amdgcn_readlane(r32b, 0) + __builtin_amdgcn_readlane(r32b, 16) +
+                       __builtin_amdgcn_readlane(r32b, 32) + __builtin_amdgcn_readlane(r32b, 48);
+      const int q64a = __builtin_amdgcn_readlane(r64a, 0) + __builtin_amdgcn_readlane(r64a, 16) +
+                       __builtin_amdgcn_readlane(r64a, 32) + __builtin_amdgcn_readlane(r64a, 48);
+      const int q64b = __builtin_amdgcn_readlane(r64b, 0) + __builtin_amdgcn_readlane(r64b, 16) +
+                       __builtin_amdgcn_readlane(r64b, 32) + __builtin_amdgcn_readlane(r64b, 48);
+      if (lane == 0) {
+        logitL[(1 + q) * 2 + 0] += q32a;  // one wave per quadrant: no atomics
+        logitL[(1 + q) * 2 + 1] += q32b;
+        atomicAdd(&logitL[0], q64a);      // four waves meet in the 64-level logits
+        atomicAdd(&logitL[1], q64b);
       }
     }
     __syncthreads();
+    FHEVC_STAMP(4)
 
     // ================= P5: top-down depth map (forced split at the picture edge) =================
     {
@@ -411,9 +520,14 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
       d_depth[o * 256 + tid] = (uint8_t)d;
       if (d_logits != nullptr && tid < 42) d_logits[o * 42 + tid] = logitL[tid];
     }
+    FHEVC_STAMP(5)
     // no barrier needed here: the next iteration's first LDS writes (P0) touch R1/R2, last read before the
     // P4 barrier, and the logits are re-initialised only after the P0 barrier.
   }
+  if (STAMPS && tid == 0) {
+    for (int k = 0; k < 6; ++k) d_stamps[blockIdx.x * 8 + k] = tsum[k];
+  }
+#undef FHEVC_STAMP
 }
 
 }  // namespace
@@ -425,6 +539,30 @@ hipError_t fhevc_launch_cnn(const FhevcFrames& fr, const FhevcCnnWeights& w, uin
   if (total <= 0) return hipSuccess;
   int grid = 2 * num_cus;
   if (total < grid) grid = (int)total;
-  hipLaunchKernelGGL(fhevc_cnn_depth_kernel, dim3(grid), dim3(256), 0, stream, fr, w, d_depth, d_logits);
+  static bool attr_set = false;  // > 64 KiB of LDS needs the opt-in; one device per process
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_kernel<false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(fhevc_cnn_depth_kernel<false>, dim3(grid), dim3(256), LDS_BYTES, stream, fr, w, d_depth, d_logits,
+                     (unsigned long long*)nullptr);
+  return hipGetLastError();
+}
+
+// diagnostic build of the same kernel with s_memtime stamps; d_stamps: grid * 8 cycle sums (phases P0..P5)
+hipError_t fhevc_launch_cnn_stamped(const FhevcFrames& fr, const FhevcCnnWeights& w, uint8_t* d_depth, int num_cus,
+                                    unsigned long long* d_stamps, int* grid_out, hipStream_t stream)
+{
+  const long long total = (long long)(fr.row_end - fr.row_begin) * fr.ctus_x * fr.num_frames;
+  int grid = 2 * num_cus;
+  if (total < grid) grid = (int)total;
+  *grid_out = grid;
+  if (total <= 0) return hipSuccess;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_kernel<true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(fhevc_cnn_depth_kernel<true>, dim3(grid), dim3(256), LDS_BYTES, stream, fr, w, d_depth, (int32_t*)nullptr, d_stamps);
   return hipGetLastError();
 }

@@ -7,7 +7,7 @@ Layout after the 8-byte header (magic "FHW1", uint32 version = 1), all little-en
   int8 w1[16][3][3]         int32 b1[16]
   int8 w2[32][16][3][3]     int32 b2[32]
   int8 w3[64][32][3][3]     int32 b3[64]
-  int8 wh64[2][8][8][64]    int32 bh64[2]
+  int8 wh64[2][8][8][64]    int32 bh64[2]      (64-level head, on the 2x2 sum-pooled conv3 map)
   int8 wh32[2][8][8][64]    int32 bh32[2]
   int8 wh16[2][4][4][64]    int32 bh16[2]
 """

@@ -513,16 +513,12 @@ void fho_cnn_ctu_debug(const fho_weights* w, const int8_t* ctu, uint8_t* a1o, ui
       }
   /* heads */
   for (int cls = 0; cls < 2; cls++) {
-    /* 64-level: FC over maxpool2x2(a3) = [8][8][64] */
+    /* 64-level: FC over sumpool2x2(a3) = [8][8][64]: every a3 position meets the weight of its 2x2 cell */
     int32_t acc = w->bh64[cls];
-    for (int y = 0; y < 8; y++)
-      for (int x = 0; x < 8; x++)
-        for (int c = 0; c < 64; c++) {
-          int m = 0;
-          for (int sy = 0; sy < 2; sy++)
-            for (int sx = 0; sx < 2; sx++) m = imax(m, a3[((2 * y + sy) * 16 + 2 * x + sx) * 64 + c]);
-          acc += (int32_t)w->wh64[cls * 4096 + (y * 8 + x) * 64 + c] * m;
-        }
+    for (int y = 0; y < 16; y++)
+      for (int x = 0; x < 16; x++)
+        for (int c = 0; c < 64; c++)
+          acc += (int32_t)w->wh64[cls * 4096 + ((y >> 1) * 8 + (x >> 1)) * 64 + c] * a3[(y * 16 + x) * 64 + c];
     logits[0][cls] = acc;
     /* 32-level: FC(8*8*64 -> 2) on each quadrant of a3 (the reference's classifier, Train...m:75-96) */
     for (int q = 0; q < 4; q++) {

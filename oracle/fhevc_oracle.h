@@ -104,7 +104,7 @@ typedef struct {
   int32_t b2[32];
   int8_t  w3[64 * 32 * 9];     /* [oc][ic][ky][kx]        */
   int32_t b3[64];
-  int8_t  wh64[2 * 4096];      /* [cls][y8][x8][c64] on maxpool2(a3) */
+  int8_t  wh64[2 * 4096];      /* [cls][y8][x8][c64] on sumpool2x2(a3) */
   int32_t bh64[2];
   int8_t  wh32[2 * 4096];      /* [cls][y8][x8][c64] on a quadrant of a3 */
   int32_t bh32[2];

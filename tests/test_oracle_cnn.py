@@ -22,7 +22,7 @@ def torch_cnn(w, ctu):
         acts.append(x[0].permute(1, 2, 0).numpy().astype(np.uint8))
     a3 = x[0].permute(1, 2, 0)  # [16,16,64]
     logits = np.zeros((21, 2), np.int64)
-    pooled = Fn.max_pool2d(x, 2)[0].permute(1, 2, 0)  # [8,8,64]
+    pooled = (4 * Fn.avg_pool2d(x, 2))[0].permute(1, 2, 0)  # 2x2 sum pool, [8,8,64]
     for cls in range(2):
         logits[0, cls] = int((pooled * t(w["wh64"][cls])).sum()) + int(w["bh64"][cls])
         for q in range(4):
