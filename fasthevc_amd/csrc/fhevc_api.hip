@@ -109,7 +109,7 @@ int build_weight_image(fhevc_ctx* c, const BlobView& b)
 {
   for (int l = 0; l < 3; ++l) {
     const int s = rd32(b.shift, l);
-    if (s < 0 || s > 24) return fail(c, FHEVC_E_WEIGHTS, "shift out of range");
+    if (s < 0 || s > 14) return fail(c, FHEVC_E_WEIGHTS, "shift out of range (0..14)");
     c->scale[l] = std::ldexp(1.0f, -s);
   }
   std::vector<uint16_t> frag((size_t)FHEVC_FRAG_TOTAL * 8, 0);

@@ -119,42 +119,46 @@ __device__ __forceinline__ int dpp_row_sum(int v)
   v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);  // row_mirror
   return v;
 }
-// conv1: acc rows 0-15 = picture row y, rows 16-31 = row y+1 -> 2x2 max-pool, requant, store 4 channels (8 B)
+// conv1: acc rows 0-15 = picture row y, rows 16-31 = row y+1 -> 2x2 max-pool, requant, store 4 channels (8 B).
+// Both lanes of a horizontal pair hold the same 8 pooled values; the even lane finishes channels 4h..4h+3 (plane 0),
+// the odd lane 8+4h.. (plane 1), so each requantises only the 4 values it stores.
 __device__ __forceinline__ void conv1_store(const f32x16& acc, float scale, unsigned char* lds, int yp, int xh, int r, int h)
 {
-  float v[8];
+  const bool odd = r & 1;
+  float v[4];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const float m = max_with_xor1(fmaxf(acc[k], acc[k + 8]));  // vertical pair in-lane, horizontal pair by DPP
-    v[k] = requant(m, scale);
+  for (int k = 0; k < 4; ++k) {
+    const float m0 = max_with_xor1(fmaxf(acc[k], acc[k + 8]));          // vertical pair in-lane, horizontal by DPP
+    const float m1 = max_with_xor1(fmaxf(acc[k + 4], acc[k + 12]));
+    v[k] = requant(odd ? m1 : m0, scale);
   }
-  // channels: regs 0-3 -> 4h+k (plane 0), regs 4-7 -> 8+4h+k (plane 1); even lane stores plane 0, odd plane 1
-  const unsigned p0a = pack_bf16(v[0], v[1]), p0b = pack_bf16(v[2], v[3]);
-  const unsigned p1a = pack_bf16(v[4], v[5]), p1b = pack_bf16(v[6], v[7]);
-  const int pl = r & 1;
-  uint2 o;
-  o.x = pl ? p1a : p0a;
-  o.y = pl ? p1b : p0b;
   const int pcol = 16 * xh + (r >> 1) + 1;
-  *reinterpret_cast<uint2*>(lds + R1_OFF + pl * A1_PLANE + ((yp + 1) * A1_PITCH + pcol) * 16 + h * 8) = o;
+  *reinterpret_cast<uint2*>(lds + R1_OFF + (odd ? A1_PLANE : 0) + ((yp + 1) * A1_PITCH + pcol) * 16 + h * 8) =
+      make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
 }
-// conv2: two output rows -> 2x2 max-pool, requant, store 16 channels of this lane half (4 planes x 8 B)
+// conv2: two output rows -> 2x2 max-pool, requant, store: the even lane of a horizontal pair finishes planes 0-1
+// (regs 0-7), the odd lane planes 2-3 (regs 8-15): 8 requants and two 8-byte stores per lane
 __device__ __forceinline__ void conv2_store(const f32x16& acc0, const f32x16& acc1, const float* bias32, float scale,
                                             unsigned char* lds, int yp, int r, int h)
 {
-  const f32x16 b = bias_tile(bias32, h);  // pre-scaled bias, added after the pool (max(a,b)+c == max(a+c,b+c))
-  float v[16];
+  const bool odd = r & 1;
+  const float* bp = bias32 + (odd ? 16 : 0) + 4 * h;   // pre-scaled bias of the channels this lane stores
+  const float4 bA = *reinterpret_cast<const float4*>(bp), bB = *reinterpret_cast<const float4*>(bp + 8);
+  const float bb[8] = { bA.x, bA.y, bA.z, bA.w, bB.x, bB.y, bB.z, bB.w };
+  float v[8];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) v[k] = requant_b(max_with_xor1(fmaxf(acc0[k], acc1[k])), scale, b[k]);
-  if ((r & 1) == 0) {  // regs 4g..4g+3 -> channels 8g+4h.. of plane g
-    unsigned char* dst = lds + R2_OFF + ((yp + 1) * A2_PITCH + (r >> 1) + 1) * 16 + h * 8;
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-      *reinterpret_cast<uint2*>(dst + g * A2_PLANE) =
-          make_uint2(pack_bf16(v[4 * g], v[4 * g + 1]), pack_bf16(v[4 * g + 2], v[4 * g + 3]));
+  for (int k = 0; k < 8; ++k) {
+    const float m0 = max_with_xor1(fmaxf(acc0[k], acc1[k]));           // bias after the pool: max(a,b)+c == max(a+c,b+c)
+    const float m1 = max_with_xor1(fmaxf(acc0[k + 8], acc1[k + 8]));
+    v[k] = requant_b(odd ? m1 : m0, scale, bb[k]);
   }
+  unsigned char* dst = lds + R2_OFF + (odd ? 2 * A2_PLANE : 0) + ((yp + 1) * A2_PITCH + (r >> 1) + 1) * 16 + h * 8;
+  *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
+  *reinterpret_cast<uint2*>(dst + A2_PLANE) = make_uint2(pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
 }
-// conv3: requant to u8, 16 channels of this lane half for one position
+// conv3: requant to u8, 16 channels of this lane half for one position.  v_cvt_pk_u8_f32 rounds to nearest even and
+// saturates to 0..255; the conv3 bias in LDS carries an extra -0.5 + 2^-(s+1), which turns that rounding into
+// floor() for every multiple of 2^-s (exact while shift <= 14): fma + cvt = floor + ReLU + clamp + pack
 // dst = start of the position's 64-byte row + 4*h; channel 32*tile + 8*g + 4*h + k lives in logical 16-B chunk
 // 2*tile + (g >> 1), at byte 8*(g & 1) + 4*h + k; psw = chunk swizzle of this position
 __device__ __forceinline__ void conv3_store(const f32x16& acc, const float* bias32, int h, float scale, unsigned char* dst,
@@ -165,24 +169,43 @@ __device__ __forceinline__ void conv3_store(const f32x16& acc, const float* bias
   for (int g = 0; g < 4; ++g) {
     unsigned d = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) d = __builtin_amdgcn_cvt_pk_u8_f32(requant_b(acc[4 * g + k], scale, b[4 * g + k]), k, d);
+    for (int k = 0; k < 4; ++k) d = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(acc[4 * g + k], scale, b[4 * g + k]), k, d);
     *reinterpret_cast<unsigned*>(dst + (((2 * tile + (g >> 1)) ^ psw) << 4) + 8 * (g & 1)) = d;
   }
 }
 
-// conv2 MFMA chain of one unit = output rows 2yp, 2yp+1 (32 positions each), K = 9 taps x 16 channels
+// ---- MFMA chains with a register ring of B fragments ---------------------------------------------------------
+// Each v_mfma needs one ds_read_b128 (its im2col fragment).  hipcc places the read right in front of its MFMA and
+// waits for it, exposing the LDS latency 18 times per chain; instead the reads run RING steps ahead of their MFMA
+// and sched_group_barrier pins the (MFMA, DS read, a few VALU of the previous unit's epilogue) interleave.
+constexpr int RING = 4;
+template <int VALU_PER_MFMA>
+__device__ __forceinline__ void sched_chain18()
+{
+#pragma unroll
+  for (int i = 0; i < 18; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                    // 1 MFMA
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                    // 1 DS read
+    if (VALU_PER_MFMA > 0) __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_MFMA, 0);  // VALU filler
+  }
+}
+// conv2 MFMA chain of one unit = output rows 2yp, 2yp+1 (32 positions each), K = 9 taps x 16 channels:
+// 12 fragments (4 input rows x 3 kx), 18 MFMAs (rows 1, 2 feed both accumulators)
 __device__ __forceinline__ void conv2_unit(const unsigned char* a1, int yp, const bf16x8 (&wA2)[9], f32x16& acc0, f32x16& acc1)
 {
 #pragma unroll
   for (int k = 0; k < 16; ++k) { acc0[k] = 0.0f; acc1[k] = 0.0f; }
+  const unsigned char* base = a1 + (2 * yp) * A1_PITCH * 16;  // halo rows 2yp .. 2yp+3
+  bf16x8 ring[RING];
 #pragma unroll
-  for (int ir = 0; ir < 4; ++ir) {  // input rows 2yp-1 .. 2yp+2 (halo coordinates 2yp .. 2yp+3)
+  for (int f = 0; f < RING; ++f) ring[f] = lds_frag(base + ((f / 3) * A1_PITCH + (f % 3)) * 16);
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
-      const bf16x8 b = lds_frag(a1 + ((2 * yp + ir) * A1_PITCH + kx) * 16);
-      if (ir < 3) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA2[ir * 3 + kx], b, acc0, 0, 0, 0);
-      if (ir > 0) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA2[(ir - 1) * 3 + kx], b, acc1, 0, 0, 0);
-    }
+  for (int f = 0; f < 12; ++f) {
+    const int ir = f / 3, kx = f % 3;
+    const bf16x8 b = ring[f % RING];
+    if (ir < 3) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA2[ir * 3 + kx], b, acc0, 0, 0, 0);
+    if (ir > 0) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA2[(ir - 1) * 3 + kx], b, acc1, 0, 0, 0);
+    if (f + RING < 12) ring[f % RING] = lds_frag(base + (((f + RING) / 3) * A1_PITCH + ((f + RING) % 3)) * 16);
   }
 }
 // conv3 MFMA chain of one unit = 32 output channels x 32 positions (rows 2yp, 2yp+1), K = 9 taps x 32 channels
@@ -192,11 +215,15 @@ __device__ __forceinline__ f32x16 conv3_unit(const unsigned char* a2, int yp, co
 #pragma unroll
   for (int k = 0; k < 16; ++k) acc[k] = 0.0f;
   const unsigned char* base = a2 + (2 * yp) * A2_PITCH * 16;
+  bf16x8 ring[RING];
+#pragma unroll
+  for (int s = 0; s < RING; ++s)
+    ring[s] = lds_frag(base + 2 * (s & 1) * A2_PLANE + (((s >> 1) / 3) * A2_PITCH + ((s >> 1) % 3)) * 16);
 #pragma unroll
   for (int s = 0; s < 18; ++s) {
-    const int tap = s >> 1, cb = s & 1;
-    const bf16x8 b = lds_frag(base + 2 * cb * A2_PLANE + ((tap / 3) * A2_PITCH + (tap % 3)) * 16);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA3[s], b, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA3[s], ring[s % RING], acc, 0, 0, 0);
+    const int n = s + RING;
+    if (n < 18) ring[s % RING] = lds_frag(base + 2 * (n & 1) * A2_PLANE + (((n >> 1) / 3) * A2_PITCH + ((n >> 1) % 3)) * 16);
   }
   return acc;
 }
@@ -263,9 +290,19 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
 
   float* biasL = reinterpret_cast<float*>(lds + BIAS_OFF);
   int* logitL = reinterpret_cast<int*>(lds + LOGIT_OFF);
-  if (tid < 112) biasL[tid] = W.bias[tid] * (tid < 16 ? 1.0f : (tid < 48 ? W.scale[1] : W.scale[2]));  // exact: integer * 2^-s
-  for (int i = tid; i < 18432 / 16; i += 256)  // head weights stay in LDS for the life of the workgroup
-    *reinterpret_cast<uint4*>(lds + HEADW_OFF + i * 16) = reinterpret_cast<const uint4*>(W.whead)[i];
+  if (tid < 112) {  // b1 raw (accumulator init); b2, b3 pre-scaled (exact: integer * 2^-s); b3 also carries the floor offset
+    float b = W.bias[tid];
+    if (tid >= 16) b *= (tid < 48 ? W.scale[1] : W.scale[2]);
+    if (tid >= 48) b += 0.5f * W.scale[2] - 0.5f;
+    biasL[tid] = b;
+  }
+  // head weights stay in LDS for the life of the workgroup; the four 16-B chunks of a 64-B row are XOR-swizzled by
+  // the row so that the 16 lanes of a ds_read_b128 group (a 4x4 block of positions) hit 16 distinct slots
+  for (int i = tid; i < 18432 / 16; i += 256) {
+    const int row = i >> 2, c = i & 3;
+    const int sw = (i < 2 * 4096 * 2 / 16) ? ((row >> 3) & 3) : ((row >> 2) & 3);  // wh64, wh32: rows of 8; wh16: rows of 4
+    *reinterpret_cast<uint4*>(lds + HEADW_OFF + row * 64 + ((c ^ sw) << 4)) = reinterpret_cast<const uint4*>(W.whead)[i];
+  }
 
   const int band_rows = F.row_end - F.row_begin;
   const int per_frame = band_rows * F.ctus_x;
@@ -409,12 +446,16 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
       // VALU epilogue of unit i, so the scheduler can interleave them (separate pipes)
       f32x16 a0, a1, b0, b1;
       conv2_unit(a1p, wave, wA2, a0, a1);
+      sched_chain18<0>();
       conv2_unit(a1p, wave + 4, wA2, b0, b1);
       conv2_store(a0, a1, biasL + 16, W.scale[1], lds, wave, r, h);
+      sched_chain18<5>();
       conv2_unit(a1p, wave + 8, wA2, a0, a1);
       conv2_store(b0, b1, biasL + 16, W.scale[1], lds, wave + 4, r, h);
+      sched_chain18<5>();
       conv2_unit(a1p, wave + 12, wA2, b0, b1);
       conv2_store(a0, a1, biasL + 16, W.scale[1], lds, wave + 8, r, h);
+      sched_chain18<5>();
       conv2_store(b0, b1, biasL + 16, W.scale[1], lds, wave + 12, r, h);
     }
     __syncthreads();
@@ -431,12 +472,16 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
       unsigned char* a3dst = lds + A3_OFF + (yy * 16 + x) * 64 + 4 * h;
       const int yp0 = wave >> 1;
       f32x16 accA = conv3_unit(a2, yp0, wA3);
+      sched_chain18<0>();
       f32x16 accB = conv3_unit(a2, yp0 + 2, wA3);
       conv3_store(accA, bias3, h, W.scale[2], a3dst + (yp0 + 0) * 2048, tile3, psw);
+      sched_chain18<4>();
       accA = conv3_unit(a2, yp0 + 4, wA3);
       conv3_store(accB, bias3, h, W.scale[2], a3dst + (yp0 + 2) * 2048, tile3, psw);
+      sched_chain18<4>();
       accB = conv3_unit(a2, yp0 + 6, wA3);
       conv3_store(accA, bias3, h, W.scale[2], a3dst + (yp0 + 4) * 2048, tile3, psw);
+      sched_chain18<4>();
       conv3_store(accB, bias3, h, W.scale[2], a3dst + (yp0 + 6) * 2048, tile3, psw);
     }
     __syncthreads();
@@ -454,13 +499,15 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
       const unsigned char* w16 = lds + HEADW_OFF + HEAD16_OFF + ((y & 3) * 4 + (x & 3)) * 64;
       const unsigned char* w32 = lds + HEADW_OFF + HEAD32_OFF + ((y & 7) * 8 + (x & 7)) * 64;
       const unsigned char* w64 = lds + HEADW_OFF + HEAD64_OFF + ((y >> 1) * 8 + (x >> 1)) * 64;  // 2x2 sum pool
+      const int sw16 = y & 3, sw32 = y & 3, sw64 = (y >> 1) & 3;  // (row >> 2) & 3, (row >> 3) & 3 of the weight rows (both classes)
       unsigned sa = 0, s16a = 0, s16b = 0, s32a = 0, s32b = 0, s64a = 0, s64b = 0;
 #pragma unroll 2
       for (int qq = 0; qq < 4; ++qq) {  // 16 channels per step keeps this phase's register footprint small
         const uint4 a = *reinterpret_cast<const uint4*>(arow + ((qq ^ psw) << 4));
-        const uint4 b0 = *reinterpret_cast<const uint4*>(w16 + qq * 16), b1 = *reinterpret_cast<const uint4*>(w16 + 1024 + qq * 16);
-        const uint4 c0 = *reinterpret_cast<const uint4*>(w32 + qq * 16), c1 = *reinterpret_cast<const uint4*>(w32 + 4096 + qq * 16);
-        const uint4 d0 = *reinterpret_cast<const uint4*>(w64 + qq * 16), d1 = *reinterpret_cast<const uint4*>(w64 + 4096 + qq * 16);
+        const int o16 = (qq ^ sw16) << 4, o32 = (qq ^ sw32) << 4, o64 = (qq ^ sw64) << 4;
+        const uint4 b0 = *reinterpret_cast<const uint4*>(w16 + o16), b1 = *reinterpret_cast<const uint4*>(w16 + 1024 + o16);
+        const uint4 c0 = *reinterpret_cast<const uint4*>(w32 + o32), c1 = *reinterpret_cast<const uint4*>(w32 + 4096 + o32);
+        const uint4 d0 = *reinterpret_cast<const uint4*>(w64 + o64), d1 = *reinterpret_cast<const uint4*>(w64 + 4096 + o64);
         sa = udot4(a.x, 0x01010101u, sa); sa = udot4(a.y, 0x01010101u, sa); sa = udot4(a.z, 0x01010101u, sa); sa = udot4(a.w, 0x01010101u, sa);
         s16a = udot4(a.x, b0.x, s16a); s16a = udot4(a.y, b0.y, s16a); s16a = udot4(a.z, b0.z, s16a); s16a = udot4(a.w, b0.w, s16a);
         s16b = udot4(a.x, b1.x, s16b); s16b = udot4(a.y, b1.y, s16b); s16b = udot4(a.z, b1.z, s16b); s16b = udot4(a.w, b1.w, s16b);
@@ -497,25 +544,18 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
     __syncthreads();
     FHEVC_STAMP(4)
 
-    // ================= P5: top-down depth map (forced split at the picture edge) =================
+    // ================= P5: top-down depth map (forced split at the picture edge), branch-free =================
     {
       const int vw = min(64, F.width - cx * 64), vh = min(64, F.height - cy * 64);
-      const int x = (tid & 15) * 4, y = (tid >> 4) * 4;
-      int d = 0;
-      if (x < vw && y < vh) {
-        const bool s64 = (vw < 64 || vh < 64) || (logitL[1] > logitL[0]);
-        if (s64) {
-          const int q = (y >> 5) * 2 + (x >> 5);
-          const bool cross32 = ((x >> 5) * 32 + 32 > vw) || ((y >> 5) * 32 + 32 > vh);
-          if (cross32 || logitL[(1 + q) * 2 + 1] > logitL[(1 + q) * 2]) {
-            const int bi = (y >> 4) * 4 + (x >> 4);
-            const bool cross16 = ((x >> 4) * 16 + 16 > vw) || ((y >> 4) * 16 + 16 > vh);
-            d = (cross16 || logitL[(5 + bi) * 2 + 1] > logitL[(5 + bi) * 2]) ? 3 : 2;
-          } else {
-            d = 1;
-          }
-        }
-      }
+      const int ux = tid & 15, uy = tid >> 4;
+      const int2 l64 = *reinterpret_cast<const int2*>(logitL);
+      const int2 l32 = *reinterpret_cast<const int2*>(logitL + 2 * (1 + (uy >> 3) * 2 + (ux >> 3)));
+      const int2 l16 = *reinterpret_cast<const int2*>(logitL + 2 * (5 + (uy >> 2) * 4 + (ux >> 2)));
+      const bool inside = (ux * 4 < vw) && (uy * 4 < vh);
+      const bool s64 = (vw < 64) || (vh < 64) || (l64.y > l64.x);
+      const bool s32 = ((ux >> 3) * 32 + 32 > vw) || ((uy >> 3) * 32 + 32 > vh) || (l32.y > l32.x);
+      const bool s16 = ((ux >> 2) * 16 + 16 > vw) || ((uy >> 2) * 16 + 16 > vh) || (l16.y > l16.x);
+      const int d = (inside && s64) ? (s32 ? (s16 ? 3 : 2) : 1) : 0;
       const long long o = (long long)(f * band_rows + (cy - F.row_begin)) * F.ctus_x + cx;
       d_depth[o * 256 + tid] = (uint8_t)d;
       if (d_logits != nullptr && tid < 42) d_logits[o * 42 + tid] = logitL[tid];

@@ -38,8 +38,8 @@ def validate(w):
     for k in ("b1", "b2", "b3"):
         if np.any(np.abs(w[k].astype(np.int64)) > BIAS_LIMIT):
             raise ValueError(f"{k}: |bias| must be <= 2^22")
-    if np.any(w["shift"] < 0) or np.any(w["shift"] > 24):
-        raise ValueError("shift out of range")
+    if np.any(w["shift"] < 0) or np.any(w["shift"] > 14):
+        raise ValueError("shift out of range (0..14)")
 
 
 def pack(w):
