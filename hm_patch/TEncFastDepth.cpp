@@ -1,0 +1,91 @@
+/* TEncFastDepth.cpp -- see TEncFastDepth.h.  Links against libfasthevc_hip.so (include/fasthevc.h). */
+#include "TEncFastDepth.h"
+
+#include <cstdio>
+#include <cstdlib>
+
+#include "TLibCommon/TComPic.h"
+#include "TLibCommon/TComDataCU.h"
+#include "TLibCommon/TComRom.h"
+
+#ifndef FHEVC_HOOK_NO_GPU
+#include "fasthevc.h"
+#endif
+
+TEncFastDepth::TEncFastDepth()
+  : m_enabled(false), m_valid(false), m_external(false), m_ctx(NULL), m_width(0), m_height(0), m_bitDepth(0)
+{
+  const char* en = std::getenv("FHEVC_ENABLE");
+  m_enabled = en != NULL && en[0] == '1';
+}
+
+TEncFastDepth::~TEncFastDepth()
+{
+#ifndef FHEVC_HOOK_NO_GPU
+  if (m_ctx != NULL) fhevc_destroy(m_ctx);
+#endif
+}
+
+void TEncFastDepth::setExternalMap(const unsigned char* map, int numCtus)
+{
+  m_external = map != NULL;
+  m_valid = m_external;
+  if (m_external) m_depth.assign(map, map + (size_t)numCtus * 256);
+}
+
+bool TEncFastDepth::predictPicture(TComPic* pcPic, int sliceQp, int sliceType)
+{
+  if (m_external) return true;       // validation feed wins
+  m_valid = false;
+  if (!m_enabled) return false;
+#ifdef FHEVC_HOOK_NO_GPU
+  (void)pcPic; (void)sliceQp; (void)sliceType;
+  return false;
+#else
+  TComPicYuv* org = pcPic->getPicYuvOrg();
+  const int w = org->getWidth(COMPONENT_Y), h = org->getHeight(COMPONENT_Y);
+  const int bd = pcPic->getPicSym()->getSPS().getBitDepth(CHANNEL_TYPE_LUMA);
+  if (m_ctx == NULL || w != m_width || h != m_height || bd != m_bitDepth)
+  {
+    if (m_ctx != NULL) { fhevc_destroy(m_ctx); m_ctx = NULL; }
+    const char* dev = std::getenv("FHEVC_DEVICE");
+    int device = dev ? std::atoi(dev) : 0;
+    fhevc_cfg cfg;
+    cfg.width = w; cfg.height = h; cfg.bit_depth = bd; cfg.ctu_size = 64; cfg.max_depth = 3;
+    cfg.num_devices = 1; cfg.device_ids = &device; cfg.weights_path = std::getenv("FHEVC_WEIGHTS");
+    cfg.backend = FHEVC_BACKEND_HIP; cfg.max_frames = 1;
+    if (cfg.weights_path == NULL || fhevc_create(&m_ctx, &cfg) != FHEVC_OK)
+    {
+      std::fprintf(stderr, "[fasthevc] disabled: cannot create the GPU context (weights/device)\n");
+      m_enabled = false; m_ctx = NULL;
+      return false;
+    }
+    m_width = w; m_height = h; m_bitDepth = bd;
+  }
+  m_depth.resize((size_t)pcPic->getNumberOfCtusInFrame() * 256);
+  const int rc = fhevc_predict_frame(m_ctx, org->getAddr(COMPONENT_Y), org->getStride(COMPONENT_Y), sliceQp, sliceType,
+                                     &m_depth[0], NULL);
+  if (rc != FHEVC_OK)
+  {
+    std::fprintf(stderr, "[fasthevc] picture falls back to full RDO: %s\n", fhevc_last_error(m_ctx));
+    return false;
+  }
+  m_valid = true;
+  return true;
+#endif
+}
+
+int TEncFastDepth::forcedDepth(const TComDataCU* pcCU) const
+{
+  if (!m_valid) return -1;
+  const size_t idx = (size_t)pcCU->getCtuRsAddr() * 256 + g_auiZscanToRaster[pcCU->getZorderIdxInCtu()];
+  return idx < m_depth.size() ? (int)m_depth[idx] : -1;
+}
+
+/* C entry for the oracle harness (oracle/ref_rdo_harness.cpp, FHEVC_HOOK builds) */
+static TEncFastDepth* g_hookInstance = NULL;
+void fhevc_hook_register(TEncFastDepth* p) { g_hookInstance = p; }
+extern "C" void fhevc_hook_set_external_map(const unsigned char* map, int num_ctus)
+{
+  if (g_hookInstance != NULL) g_hookInstance->setExternalMap(map, num_ctus);
+}

@@ -1,0 +1,43 @@
+/* TEncFastDepth.h -- host-side glue between HM's TEncCu/TEncSlice and the C ABI of include/fasthevc.h.
+ *
+ * New file for source/Lib/TLibEncoder (nothing in HM is replaced).  One instance lives in TEncCu.  Per picture,
+ * TEncSlice::compressSlice calls predictPicture() before its CTU loop (TEncSlice.cpp:792); per CU node,
+ * TEncCu::xCompressCU asks forcedDepth() right after bBoundary is known (TEncCu.cpp:574).  If the library is
+ * disabled, missing or returns an error, forcedDepth() is -1 and HM runs its stock full RDO: never aborts.
+ *
+ * Knobs arrive through the environment so that TAppEncCfg stays untouched:
+ *   FHEVC_ENABLE=1            turn the path on
+ *   FHEVC_WEIGHTS=<file>      FHW1 weight blob
+ *   FHEVC_DEVICE=<ordinal>    HIP device (default 0)
+ */
+#ifndef __TENCFASTDEPTH__
+#define __TENCFASTDEPTH__
+
+#include <vector>
+
+class TComPic;
+class TComDataCU;
+struct fhevc_ctx;
+
+class TEncFastDepth
+{
+public:
+  TEncFastDepth();
+  ~TEncFastDepth();
+
+  /// one GPU pass over the original luma plane of pcPic; false -> this picture runs stock RDO
+  bool predictPicture(TComPic* pcPic, int sliceQp, int sliceType);
+  /// predicted depth (0..3) of the CU whose top-left 4x4 unit is (ctuRsAddr, zorderIdx), or -1
+  int  forcedDepth(const TComDataCU* pcCU) const;
+  /// validation feed (oracle harness): use this map instead of the GPU for the next picture; NULL clears it
+  void setExternalMap(const unsigned char* map, int numCtus);
+  const std::vector<unsigned char>& depthMap() const { return m_depth; }
+
+private:
+  bool       m_enabled, m_valid, m_external;
+  fhevc_ctx* m_ctx;
+  int        m_width, m_height, m_bitDepth;
+  std::vector<unsigned char> m_depth;   // numCtus * 256, raster 16x16 per CTU
+};
+
+#endif

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Apply the fast-depth hook to a copy of HM-16.14's TEncCu.h / TEncCu.cpp / TEncSlice.cpp.
+
+usage: apply_hook.py <TLibEncoder dir of the HM tree> <output dir>
+Reads the three files, inserts the lines below at anchors (regular expressions over HM's own identifiers) and writes
+the patched copies to <output dir>; nothing else of HM is touched.  The script carries no HM source text.
+"""
+import os
+import re
+import sys
+
+
+def sub_once(text, pattern, repl, what):
+    new, n = re.subn(pattern, repl, text, count=1, flags=re.M)
+    if n != 1:
+        raise SystemExit(f"anchor not found: {what}")
+    return new
+
+
+def patch_cu_h(s):
+    s = sub_once(s, r'(#include "TEncSearch.h"\n)', r'\1#include "TEncFastDepth.h"\n', "TEncCu.h include")
+    s = sub_once(s, r'(^\s*TEncRateCtrl\*\s+m_pcRateCtrl;\n)', r'\1  TEncFastDepth           m_fastDepth;      ///< per-picture depth map from the GPU path\n', "TEncCu.h member")
+    s = sub_once(s, r'(^\s*Void\s+setFastDeltaQp\s*\(.*\n)', r'\1  TEncFastDepth& getFastDepth()                   { return m_fastDepth; }\n', "TEncCu.h accessor")
+    return s
+
+
+def patch_cu_cpp(s):
+    # 1. after bBoundary is computed: the two forcing flags
+    s = sub_once(s, r'(^\s*const Bool bBoundary = .*;\n)',
+                 r'\1\n    const Int  iForcedDepth = m_fastDepth.forcedDepth( rpcBestCU );   // -1: no prediction\n'
+                 r'    const Bool bForceSplit  = !bBoundary && iForcedDepth > (Int)uiDepth;  // skip the mode loop at this depth\n'
+                 r'    const Bool bForceStop   = !bBoundary && iForcedDepth == (Int)uiDepth; // do not recurse below it\n',
+                 "bBoundary")
+    # 2. the mode loop runs only when the node is not forced to split
+    s = sub_once(s, r'^(\s*)if \( !bBoundary \)\n', r'\1if ( !bBoundary && !bForceSplit )\n', "mode loop guard")
+    # 3. no recursion below a forced leaf
+    s = sub_once(s, r'(^\s*const Bool bSubBranch = )(.*);\n', r'\1( \2 ) && !bForceStop;\n', "bSubBranch")
+    return s
+
+
+def patch_slice_cpp(s):
+    # once per picture, before the CTU loop of compressSlice
+    s = sub_once(s, r'(^\s*m_pcCuEncoder->setFastDeltaQp\(bFastDeltaQP\);\n)',
+                 r'\1  m_pcCuEncoder->getFastDepth().predictPicture( pcPic, pcSlice->getSliceQp(), Int(pcSlice->getSliceType()) );\n',
+                 "compressSlice")
+    return s
+
+
+def main():
+    src, dst = sys.argv[1], sys.argv[2]
+    os.makedirs(dst, exist_ok=True)
+    for name, fn in (("TEncCu.h", patch_cu_h), ("TEncCu.cpp", patch_cu_cpp), ("TEncSlice.cpp", patch_slice_cpp)):
+        with open(os.path.join(src, name)) as f:
+            text = f.read()
+        with open(os.path.join(dst, name), "w") as f:
+            f.write(fn(text))
+    print("patched TEncCu.h TEncCu.cpp TEncSlice.cpp ->", dst)
+
+
+if __name__ == "__main__":
+    main()

@@ -91,16 +91,24 @@ def have_ref():
     return os.path.exists(REF_SO)
 
 
-def load_ref():
-    """Open oracle/_ref/libhmref.so with RTLD_LAZY (one never-called reference symbol stays unresolved:
-    see oracle/Makefile)."""
+HOOK_SO = os.path.join(HERE, "_ref", "libhmref_hook.so")
+
+
+def have_hook():
+    return os.path.exists(HOOK_SO)
+
+
+def load_ref(hook=False):
+    """Open oracle/_ref/libhmref.so (or the hook variant, libhmref_hook.so = the same reference objects with
+    hm_patch/ applied) with RTLD_LAZY: one never-called reference symbol stays unresolved, see oracle/Makefile."""
+    path = HOOK_SO if hook else REF_SO
     libdl = C.CDLL(None)
     libdl.dlopen.restype = C.c_void_p
     libdl.dlopen.argtypes = [C.c_char_p, C.c_int]
-    handle = libdl.dlopen(REF_SO.encode(), os.RTLD_LAZY | os.RTLD_LOCAL)
+    handle = libdl.dlopen(path.encode(), os.RTLD_LAZY | os.RTLD_LOCAL)
     if not handle:
-        raise OSError("cannot dlopen " + REF_SO)
-    lib = C.CDLL(REF_SO, handle=handle)
+        raise OSError("cannot dlopen " + path)
+    lib = C.CDLL(path, handle=handle)
     lib.href_version.restype = C.c_char_p
     for name in ("href_calc_had", "href_get_hads"):
         f = getattr(lib, name)
@@ -148,3 +156,32 @@ def roi_to_ref_line(roi, n):
     ref[2 * n:] = roi[0, :]
     ref[:2 * n] = roi[1:, 0][::-1]
     return ref
+
+
+def bind_rdo(lib):
+    """href_rdo_encode_frame of oracle/ref_rdo_harness.cpp (the reference's own compressSlice/xCompressCU)."""
+    lib.href_rdo_encode_frame.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, _u8p,
+                                          np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")]
+    lib.href_rdo_encode_frame.restype = C.c_int
+    lib.href_has_hook.restype = C.c_int
+    return lib
+
+
+def rdo_encode(lib, plane, origin, stride, width, height, bit_depth, qp, forced_depth=None):
+    """-> (depth [numCtus,256] uint8, stats dict).  plane: int16 Pel buffer."""
+    n = ((width + 63) // 64) * ((height + 63) // 64)
+    depth = np.zeros(n * 256, np.uint8)
+    stats = np.zeros(8, np.float64)
+    fd = None
+    if forced_depth is not None:
+        fd = np.ascontiguousarray(forced_depth, np.uint8).reshape(-1)
+        assert fd.size == n * 256
+    rc = lib.href_rdo_encode_frame(ptr(plane.reshape(-1), origin), stride, width, height, bit_depth, qp,
+                                   C.c_void_p(fd.ctypes.data) if fd is not None else None, depth, stats)
+    if rc != 0:
+        raise RuntimeError(f"href_rdo_encode_frame failed: {rc}")
+    mse = stats[4] / (width * height)
+    peak = (1 << bit_depth) - 1
+    return depth.reshape(n, 256), {"bits": stats[0], "dist": stats[1], "rdcost": stats[2], "seconds": stats[3],
+                                   "psnr_y": 10 * np.log10(peak * peak / mse) if mse > 0 else 99.0, "ctus": int(stats[5]),
+                                   "coded_bits": stats[6]}

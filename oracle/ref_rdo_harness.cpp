@@ -1,0 +1,351 @@
+// ref_rdo_harness.cpp -- drives the REAL reference decision path for one intra picture:
+//   TEncSlice::compressSlice -> TEncCu::compressCtu -> xCompressCU -> xCheckRDCostIntra -> TEncSearch::estIntraPred*QT
+// (TEncSlice.cpp:698-983, TEncCu.cpp:252-1058, TEncSearch.cpp:2178-2712) without TEncTop / TEncGOP / TAppEncoder,
+// which need OpenCV (Src_HARP) and are therefore not buildable in this image.
+//
+// TEST INFRASTRUCTURE ONLY (oracle/_ref/libhmref.so).  This file contains NO reference code: it constructs the
+// reference's own objects (TEncCfg, TComSPS/PPS, TComPic, TEncSlice, TEncCu, TEncSearch, TComTrQuant, TComRdCost,
+// the RD-SBAC coder arrays) and wires them the way TEncTop::create/init do (TEncTop.cpp:89-145, 183-231), with the
+// parameter values of cfg/encoder_intra_main.cfg / encoder_intra_main10.cfg.  Member wiring uses the usual
+// test-harness access trick (private -> public for the reference headers only); no layout changes.
+//
+// Used for: depth-map labels for the trainer, the "reference" CPU baseline of bench.py (HM's own xCompressCU timed
+// on the host), and the RD-cost check of the xCompressCU hook (hm_patch/) through FHEVC_HOOK builds.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <list>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#define private public
+#define protected public
+#ifdef FHEVC_HOOK
+#include "TEncFastDepth.h"
+#include "TEncCu.h"  // the patched copy: oracle/_ref/hook/src precedes the reference tree on the include path
+#endif
+#include "TLibCommon/CommonDef.h"
+#include "TLibCommon/TComRom.h"
+#include "TLibCommon/TComPic.h"
+#include "TLibCommon/TComSlice.h"
+#include "TLibCommon/TComTrQuant.h"
+#include "TLibCommon/TComRdCost.h"
+#include "TLibEncoder/TEncCfg.h"
+#include "TLibEncoder/TEncCu.h"
+#include "TLibEncoder/TEncSlice.h"
+#include "TLibEncoder/TEncSearch.h"
+#include "TLibEncoder/TEncEntropy.h"
+#include "TLibEncoder/TEncSbac.h"
+#include "TLibEncoder/TEncBinCoderCABAC.h"
+#include "TLibEncoder/TEncBinCoderCABACCounter.h"
+#include "TLibEncoder/TEncRateCtrl.h"
+#undef private
+#undef protected
+
+#ifdef FHEVC_HOOK
+// provided by the hook build (hm_patch/TEncFastDepth.cpp compiled into this library): explicit depth map feed
+extern "C" void fhevc_hook_set_external_map(const unsigned char* map, int num_ctus);
+void fhevc_hook_register(TEncFastDepth* p);
+#endif
+
+namespace {
+
+struct Encoder {
+  int width = 0, height = 0, bit_depth = 0;
+  TEncCfg cfg;
+  TComSPS sps;
+  TComPPS pps;
+  TEncCu cu;
+  TEncSlice slice;
+  TEncSearch search;
+  TComTrQuant trq;
+  TComRdCost rd;
+  TEncEntropy entropy;
+  TEncSbac sbac;
+  TEncBinCABAC bin;
+  TEncSbac rdGoOnSbac;
+#if FAST_BIT_EST
+  TEncBinCABACCounter rdGoOnBin;
+#else
+  TEncBinCABAC rdGoOnBin;
+#endif
+  TEncRateCtrl rc;
+  TEncSbac*** rdSbac = nullptr;
+  TComPic* pic = nullptr;
+};
+
+std::map<long long, Encoder*> g_encoders;
+
+int env_int(const char* name, int dflt);
+void configure(Encoder& e)
+{
+  TEncCfg& c = e.cfg;
+  // cfg/encoder_intra_main.cfg (+ TAppEncCfg.cpp defaults for everything the cfg does not name)
+  c.setSourceWidth(e.width); c.setSourceHeight(e.height);
+  c.setChromaFormatIdc(CHROMA_420);
+  c.setMaxCUWidth(64); c.setMaxCUHeight(64); c.setMaxTotalCUDepth(4); c.setLog2DiffMaxMinCodingBlockSize(3);
+  c.setQuadtreeTULog2MaxSize(5); c.setQuadtreeTULog2MinSize(2);
+  c.setQuadtreeTUMaxDepthInter(3); c.setQuadtreeTUMaxDepthIntra(3);
+  c.setIntraPeriod(1); c.setGOPSize(1); c.setDecodingRefreshType(1);
+  c.setBitDepth(CHANNEL_TYPE_LUMA, e.bit_depth); c.setBitDepth(CHANNEL_TYPE_CHROMA, e.bit_depth);
+  c.setUseRDOQ(env_int("FHREF_RDOQ", 1)); c.setUseRDOQTS(env_int("FHREF_RDOQ", 1)); c.setUseSelectiveRDOQ(false); c.setRDpenalty(0);
+  c.setUseTransformSkip(true); c.setUseTransformSkipFast(true); c.setLog2MaxTransformSkipBlockSize(2);
+  c.setFastUDIUseMPMEnabled(true); c.setUseEarlyCU(false); c.setUseCbfFastMode(false); c.setUseEarlySkipDetection(false);
+  c.setFastDeltaQp(false); c.setUseFastDecisionForMerge(true);
+  c.setMaxDeltaQP(0); c.setMaxCuDQPDepth(0); c.setDeltaQpRD(0); c.setUseAdaptiveQP(false);
+  c.setUsePCM(false); c.setPCMLog2MinSize(3); c.setPCMLog2MaxSize(5);
+  c.setUseAMP(true); c.setUseSAO(true);
+  c.setUseStrongIntraSmoothing(true);
+  c.setSignDataHidingEnabledFlag(env_int("FHREF_SDH", 1));
+  c.setTransquantBypassEnabledFlag(false); c.setCUTransquantBypassFlagForceValue(false);
+  c.setCostMode(COST_STANDARD_LOSSY);
+  c.setUseRateCtrl(false);
+  c.setEntropyCodingSyncEnabledFlag(false);
+  c.setSliceMode(NO_SLICES); c.setSliceSegmentMode(NO_SLICES);
+  c.setUseScalingListId(SCALING_LIST_OFF);
+  c.setCrossComponentPredictionEnabledFlag(false); c.setUseReconBasedCrossCPredictionEstimate(false);
+  c.setExtendedPrecisionProcessingFlag(false); c.setHighPrecisionOffsetsEnabledFlag(false);
+  c.setRdpcmEnabledFlag(RDPCM_SIGNAL_IMPLICIT, false); c.setRdpcmEnabledFlag(RDPCM_SIGNAL_EXPLICIT, false);
+  c.setTransformSkipRotationEnabledFlag(false); c.setTransformSkipContextEnabledFlag(false);
+  c.setPersistentRiceAdaptationEnabledFlag(false); c.setCabacBypassAlignmentEnabledFlag(false);
+  c.setIntraSmoothingDisabledFlag(false);
+#if ADAPTIVE_QP_SELECTION
+  c.setUseAdaptQpSelect(false);
+#endif
+  LumaLevelToDeltaQPMapping lm; lm.mode = LUMALVL_TO_DQP_DISABLED; lm.maxMethodWeight = 0.0;
+  c.setLumaLevelToDeltaQPControls(lm);
+}
+
+int env_int(const char* name, int dflt) { const char* v = std::getenv(name); return v ? std::atoi(v) : dflt; }
+
+// the subset of TEncTop::xInitSPS / xInitPPS (TEncTop.cpp:580-900) that the CTU decision path reads
+void init_parameter_sets(Encoder& e)
+{
+  TComSPS& sps = e.sps;
+  sps.setPicWidthInLumaSamples(e.width); sps.setPicHeightInLumaSamples(e.height);
+  sps.setMaxCUWidth(64); sps.setMaxCUHeight(64); sps.setMaxTotalCUDepth(4);
+  sps.setChromaFormatIdc(CHROMA_420);
+  sps.setLog2DiffMaxMinCodingBlockSize(3); sps.setLog2MinCodingBlockSize(3);
+  sps.setPCMLog2MinSize(3); sps.setUsePCM(false); sps.setPCMLog2MaxSize(5);
+  sps.setQuadtreeTULog2MaxSize(5); sps.setQuadtreeTULog2MinSize(2);
+  sps.setQuadtreeTUMaxDepthInter(3); sps.setQuadtreeTUMaxDepthIntra(3);
+  sps.setSPSTemporalMVPEnabledFlag(false);
+  sps.setMaxTrSize(32);
+  sps.setUseAMP(true);
+  for (UInt ch = 0; ch < MAX_NUM_CHANNEL_TYPE; ch++) {
+    sps.setBitDepth(ChannelType(ch), e.bit_depth);
+#if O0043_BEST_EFFORT_DECODING
+    sps.setStreamBitDepth(ChannelType(ch), e.bit_depth);
+#endif
+    sps.setQpBDOffset(ChannelType(ch), 6 * (e.bit_depth - 8));
+    sps.setPCMBitDepth(ChannelType(ch), e.bit_depth);
+  }
+  sps.setUseSAO(true);
+  sps.setMaxTLayers(1); sps.setTemporalIdNestingFlag(true);
+  sps.setScalingListFlag(false);
+  sps.setUseStrongIntraSmoothing(true);
+
+  TComPPS& pps = e.pps;
+  pps.setSPSId(0); pps.setPPSId(0);
+  pps.setUseDQP(false); pps.setMaxCuDQPDepth(0);
+  pps.setQpOffset(COMPONENT_Cb, 0); pps.setQpOffset(COMPONENT_Cr, 0);
+  pps.setEntropyCodingSyncEnabledFlag(false);
+  pps.setTilesEnabledFlag(false);
+  pps.setNumTileColumnsMinus1(0); pps.setNumTileRowsMinus1(0); pps.setTileUniformSpacingFlag(false);
+  pps.setUseWP(false); pps.setWPBiPred(false);
+  pps.setSignDataHidingEnabledFlag(env_int("FHREF_SDH", 1));
+  pps.setTransquantBypassEnabledFlag(false);
+  pps.setUseTransformSkip(true);
+  pps.getPpsRangeExtension().setLog2MaxTransformSkipBlockSize(2);
+  pps.setDependentSliceSegmentsEnabledFlag(false);
+  pps.setCabacInitPresentFlag(false);
+  pps.setLoopFilterAcrossTilesEnabledFlag(true);
+  pps.setScalingListPresentFlag(false);
+}
+
+Encoder* get_encoder(int w, int h, int bd)
+{
+  const long long key = ((long long)w << 40) | ((long long)h << 16) | bd;
+  auto it = g_encoders.find(key);
+  if (it != g_encoders.end()) return it->second;
+  static bool rom = false;
+  if (!rom) { initROM(); rom = true; }
+  Encoder* e = new Encoder();
+  e->width = w; e->height = h; e->bit_depth = bd;
+  configure(*e);
+  init_parameter_sets(*e);
+
+  // TEncTop::create (TEncTop.cpp:89-145)
+  e->slice.create(w, h, CHROMA_420, 64, 64, 4);
+  e->cu.create(4, 64, 64, CHROMA_420);
+  e->rdSbac = new TEncSbac**[5];
+  for (int d = 0; d < 5; d++) {
+    e->rdSbac[d] = new TEncSbac*[CI_NUM];
+    for (int ci = 0; ci < CI_NUM; ci++) {
+      e->rdSbac[d][ci] = new TEncSbac;
+#if FAST_BIT_EST
+      e->rdSbac[d][ci]->init(new TEncBinCABACCounter);
+#else
+      e->rdSbac[d][ci]->init(new TEncBinCABAC);
+#endif
+    }
+  }
+  // TEncTop::init (TEncTop.cpp:183-231) without the GOP encoder
+  e->rd.setCostMode(COST_STANDARD_LOSSY);
+  const Int maxLog2TrDynamicRange[MAX_NUM_CHANNEL_TYPE] = { e->sps.getMaxLog2TrDynamicRange(CHANNEL_TYPE_LUMA),
+                                                             e->sps.getMaxLog2TrDynamicRange(CHANNEL_TYPE_CHROMA) };
+  e->trq.init(32, env_int("FHREF_RDOQ", 1), env_int("FHREF_RDOQ", 1), false, true, true
+#if ADAPTIVE_QP_SELECTION
+              , false
+#endif
+  );
+  e->trq.setFlatScalingList(maxLog2TrDynamicRange, e->sps.getBitDepths());
+  e->trq.setUseScalingList(false);
+  e->sbac.init(&e->bin);
+  e->rdGoOnSbac.init(&e->rdGoOnBin);
+  // TEncSlice::init / TEncCu::init (TEncSlice.cpp:78-104, TEncCu.cpp:227-243) with our own owners instead of TEncTop
+  e->slice.m_pcCfg = &e->cfg; e->slice.m_pcListPic = nullptr; e->slice.m_pcGOPEncoder = nullptr;
+  e->slice.m_pcCuEncoder = &e->cu; e->slice.m_pcPredSearch = &e->search;
+  e->slice.m_pcEntropyCoder = &e->entropy; e->slice.m_pcSbacCoder = &e->sbac; e->slice.m_pcBinCABAC = &e->bin;
+  e->slice.m_pcTrQuant = &e->trq; e->slice.m_pcRdCost = &e->rd;
+  e->slice.m_pppcRDSbacCoder = e->rdSbac; e->slice.m_pcRDGoOnSbacCoder = &e->rdGoOnSbac;
+  e->slice.m_vdRdPicLambda.resize(1); e->slice.m_vdRdPicQp.resize(1); e->slice.m_viRdPicQp.resize(1);
+  e->slice.m_pcRateCtrl = &e->rc;
+  e->cu.m_pcEncCfg = &e->cfg; e->cu.m_pcPredSearch = &e->search; e->cu.m_pcTrQuant = &e->trq; e->cu.m_pcRdCost = &e->rd;
+  e->cu.m_pcEntropyCoder = &e->entropy; e->cu.m_pcBinCABAC = &e->bin;
+  e->cu.m_pppcRDSbacCoder = e->rdSbac; e->cu.m_pcRDGoOnSbacCoder = &e->rdGoOnSbac; e->cu.m_pcRateCtrl = &e->rc;
+  e->cu.m_lumaQPOffset = 0;
+  e->cu.initLumaDeltaQpLUT();
+  e->cu.setSliceEncoder(&e->slice);
+  e->search.init(&e->cfg, &e->trq, 64, 4, MESEARCH_DIAMOND, 64, 64, 4, &e->entropy, &e->rd, e->rdSbac, &e->rdGoOnSbac);
+
+  e->pic = new TComPic();
+  e->pic->create(e->sps, e->pps, true, true);
+  g_encoders[key] = e;
+  return e;
+}
+
+void load_picture(Encoder& e, const int16_t* luma, int stride)
+{
+  TComPicYuv* org = e.pic->getPicYuvOrg();
+  for (int comp = 0; comp < 3; comp++) {
+    const ComponentID id = ComponentID(comp);
+    Pel* dst = org->getAddr(id);
+    const int s = org->getStride(id), w = org->getWidth(id), h = org->getHeight(id);
+    for (int y = 0; y < h; y++)
+      for (int x = 0; x < w; x++)
+        dst[y * s + x] = (comp == 0) ? (Pel)luma[(size_t)y * stride + x] : (Pel)(1 << (e.bit_depth - 1));  // flat chroma
+  }
+  org->copyToPic(e.pic->getPicYuvTrueOrg());
+}
+
+// slice set-up: the parts of TEncSlice::initEncSlice (TEncSlice.cpp:159-430) that matter for one I picture
+void init_slice(Encoder& e, int qp)
+{
+  e.pic->getPicSym()->clearSliceBuffer();
+  e.pic->getPicSym()->allocateNewSlice();
+  TComSlice* s = e.pic->getSlice(0);
+  e.pic->setCurrSliceIdx(0);
+  s->setSPS(&e.sps); s->setPPS(&e.pps); s->setPic(e.pic);
+  s->initSlice();
+  s->setSliceBits(0); s->setPicOutputFlag(true);
+  s->setPOC(0); s->setDepth(0); s->setSliceType(I_SLICE); s->setNalUnitType(NAL_UNIT_CODED_SLICE_IDR_W_RADL);
+  s->setSliceQp(qp); s->setSliceQpBase(qp); s->setSliceQpDelta(0);
+  s->setSliceChromaQpDelta(COMPONENT_Cb, 0); s->setSliceChromaQpDelta(COMPONENT_Cr, 0);
+  s->setUseChromaQpAdj(false);
+  s->setNumRefIdx(REF_PIC_LIST_0, 0); s->setNumRefIdx(REF_PIC_LIST_1, 0);
+  s->setTLayer(0); e.pic->setTLayer(0);
+  s->setSliceMode(NO_SLICES); s->setSliceArgument(0); s->setSliceSegmentMode(NO_SLICES); s->setSliceSegmentArgument(0);
+  s->setMaxNumMergeCand(5);
+  s->setSliceCurStartCtuTsAddr(0); s->setSliceSegmentCurStartCtuTsAddr(0);
+  s->setSliceCurEndCtuTsAddr(e.pic->getNumberOfCtusInFrame()); s->setSliceSegmentCurEndCtuTsAddr(e.pic->getNumberOfCtusInFrame());
+  s->setDependentSliceSegmentFlag(false);
+  e.pic->setPicYuvPred(&e.slice.m_picYuvPred); e.pic->setPicYuvResi(&e.slice.m_picYuvResi);
+  e.slice.setSliceIdx(0);
+  // lambda: TEncSlice::calculateLambda for an I slice of an all-intra configuration (GOPSize 1, modifiers 1.0)
+  // = 0.57 * 2^((qp-12)/3) (TEncSlice.cpp:433-527); then the reference's own setUpLambda (:113-157)
+  const double lambda = 0.57 * std::pow(2.0, (qp - 12) / 3.0);
+  e.slice.setUpLambda(s, lambda, qp);
+}
+
+}  // namespace
+
+extern "C" {
+
+// One intra picture through the reference's compressSlice.  luma: Pel samples at the internal bit depth.
+// forced_depth (only in hook builds): numCtus*256 raster depth map fed to the xCompressCU hook, or NULL.
+// depth_out: numCtus*256, raster per CTU = getDepth(g_auiRasterToZscan[r]).  stats: [0] bits (RD-SBAC estimate summed
+// over CTUs), [1] distortion (SSE, chroma weighted as in TComRdCost), [2] RD cost, [3] seconds in compressSlice,
+// [4] luma SSE of the reconstruction vs the original, [5] number of CTUs.
+int href_rdo_encode_frame(const int16_t* luma, int stride, int width, int height, int bit_depth, int qp,
+                          const uint8_t* forced_depth, uint8_t* depth_out, double* stats)
+{
+  if ((width % 8) || (height % 8) || width < 64 || height < 64) return -1;
+  Encoder* e = get_encoder(width, height, bit_depth);
+  load_picture(*e, luma, stride);
+  init_slice(*e, qp);
+#ifdef FHEVC_HOOK
+  fhevc_hook_register(&e->cu.getFastDepth());
+  fhevc_hook_set_external_map(forced_depth, forced_depth ? (int)e->pic->getNumberOfCtusInFrame() : 0);
+#else
+  if (forced_depth) return -2;
+#endif
+  const auto t0 = std::chrono::steady_clock::now();
+  e->slice.compressSlice(e->pic, false, false);
+  const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  const int n = (int)e->pic->getNumberOfCtusInFrame();
+  for (int c = 0; c < n; c++) {
+    TComDataCU* ctu = e->pic->getCtu(c);
+    for (int r = 0; r < 256; r++) depth_out[c * 256 + r] = ctu->getDepth(g_auiRasterToZscan[r]);
+  }
+  if (stats) {
+    stats[0] = (double)e->slice.m_uiPicTotalBits;
+    stats[6] = (double)e->pic->getSlice(0)->getSliceBits();  // bits counted by encodeCtu (true CABAC state)
+    stats[1] = (double)e->slice.m_uiPicDist;
+    stats[2] = e->slice.m_dPicRdCost;
+    stats[3] = sec;
+    double sse = 0;
+    const Pel* o = e->pic->getPicYuvOrg()->getAddr(COMPONENT_Y);
+    const Pel* r = e->pic->getPicYuvRec()->getAddr(COMPONENT_Y);
+    const int so = e->pic->getPicYuvOrg()->getStride(COMPONENT_Y), sr = e->pic->getPicYuvRec()->getStride(COMPONENT_Y);
+    for (int y = 0; y < height; y++)
+      for (int x = 0; x < width; x++) { const double d = (double)o[y * so + x] - (double)r[y * sr + x]; sse += d * d; }
+    stats[4] = sse;
+    stats[5] = n;
+  }
+  return 0;
+}
+
+// debugging aid: histograms of the decisions of the last encoded picture of that geometry
+int href_rdo_debug_hist(int width, int height, int bit_depth, int* modes35, int* part2, int* trdepth4, int* tskip2, int* cbf2)
+{
+  Encoder* e = get_encoder(width, height, bit_depth);
+  const int n = (int)e->pic->getNumberOfCtusInFrame();
+  for (int c = 0; c < n; c++) {
+    TComDataCU* ctu = e->pic->getCtu(c);
+    for (int z = 0; z < 256; z++) {
+      modes35[ctu->getIntraDir(CHANNEL_TYPE_LUMA, z)]++;
+      part2[ctu->getPartitionSize(z) == SIZE_NxN ? 1 : 0]++;
+      trdepth4[std::min(3, (int)ctu->getTransformIdx(z))]++;
+      tskip2[ctu->getTransformSkip(z, COMPONENT_Y) ? 1 : 0]++;
+      cbf2[ctu->getCbf(z, COMPONENT_Y, ctu->getTransformIdx(z)) ? 1 : 0]++;
+    }
+  }
+  return n;
+}
+
+#ifdef FHEVC_HOOK
+int href_has_hook(void) { return 1; }
+#else
+int href_has_hook(void) { return 0; }
+#endif
+
+}  // extern "C"
