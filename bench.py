@@ -41,7 +41,7 @@ def cpu_baseline(width, height, bit_depth, w, seconds=12.0):
     for a in order:
         cx, cy = int(a % cw), int(a // cw)
         oracle.fho_load_ctu(op.ptr(buf.reshape(-1), org), stride, width, height, cx, cy, bit_depth, ctu)
-        oracle.fho_cnn_ctu(ws, ctu, logits)
+        oracle.fho_cnn_ctu(ws, ctu, 32, logits)
         oracle.fho_depth_from_logits(logits, min(64, width - cx * 64), min(64, height - cy * 64), depth)
         oracle.fho_ctu_src_hadamard(op.ptr(buf.reshape(-1), org + cy * 64 * stride + cx * 64), stride,
                                     min(64, width - cx * 64), min(64, height - cy * 64))

@@ -74,15 +74,16 @@ struct BlobView {
   const int8_t* wh64; const int32_t* bh64;
   const int8_t* wh32; const int32_t* bh32;
   const int8_t* wh16; const int32_t* bh16;
+  const int32_t* qp_bias;
 };
-constexpr size_t kBlobBytes = 8 + 12 + 144 + 64 + 4608 + 128 + 18432 + 256 + 8192 + 8 + 8192 + 8 + 2048 + 8;
+constexpr size_t kBlobBytes = 8 + 12 + 144 + 64 + 4608 + 128 + 18432 + 256 + 8192 + 8 + 8192 + 8 + 2048 + 8 + 3 * 52 * 4;
 
 bool parse_blob(const uint8_t* p, size_t n, BlobView& v, std::vector<uint8_t>& aligned)
 {
   if (n != kBlobBytes || std::memcmp(p, "FHW1", 4) != 0) return false;
   uint32_t ver;
   std::memcpy(&ver, p + 4, 4);
-  if (ver != 1) return false;
+  if (ver != 2) return false;
   // copy the int32 sections out to aligned storage: the blob packs int8 and int32 arrays back to back
   aligned.assign(p, p + n);
   size_t off = 8;
@@ -94,6 +95,7 @@ bool parse_blob(const uint8_t* p, size_t n, BlobView& v, std::vector<uint8_t>& a
   v.wh64 = reinterpret_cast<const int8_t*>(take(8192)); v.bh64 = reinterpret_cast<const int32_t*>(take(8));
   v.wh32 = reinterpret_cast<const int8_t*>(take(8192)); v.bh32 = reinterpret_cast<const int32_t*>(take(8));
   v.wh16 = reinterpret_cast<const int8_t*>(take(2048)); v.bh16 = reinterpret_cast<const int32_t*>(take(8));
+  v.qp_bias = reinterpret_cast<const int32_t*>(take(3 * 52 * 4));
   return off == n;
 }
 
@@ -144,7 +146,8 @@ int build_weight_image(fhevc_ctx* c, const BlobView& b)
   for (int i = 0; i < 8192; ++i) whead[i] = (uint8_t)((int)b.wh64[i] + 128);
   for (int i = 0; i < 8192; ++i) whead[8192 + i] = (uint8_t)((int)b.wh32[i] + 128);
   for (int i = 0; i < 2048; ++i) whead[16384 + i] = (uint8_t)((int)b.wh16[i] + 128);
-  int32_t bhead[6] = { rd32(b.bh64, 0), rd32(b.bh64, 1), rd32(b.bh32, 0), rd32(b.bh32, 1), rd32(b.bh16, 0), rd32(b.bh16, 1) };
+  int32_t bhead[6 + 3 * 52] = { rd32(b.bh64, 0), rd32(b.bh64, 1), rd32(b.bh32, 0), rd32(b.bh32, 1), rd32(b.bh16, 0), rd32(b.bh16, 1) };
+  for (int i = 0; i < 3 * 52; ++i) bhead[6 + i] = rd32(b.qp_bias, i);
 
   if (!c->d_frag) {
     HIP_TRY(c, hipMalloc(&c->d_frag, frag.size() * 2));
@@ -200,12 +203,13 @@ void time_resolve(fhevc_ctx* c)
 }
 
 FhevcFrames frames_of(const fhevc_ctx* c, const void* d_luma, int sample_bytes, int stride, long long frame_stride,
-                      int num_frames, int row_begin, int row_end)
+                      int num_frames, int row_begin, int row_end, int qp = 32)
 {
   FhevcFrames f;
   f.luma = d_luma; f.sample_bytes = sample_bytes; f.stride = stride; f.frame_stride = frame_stride;
   f.width = c->cfg.width; f.height = c->cfg.height; f.bit_depth = c->cfg.bit_depth;
   f.ctus_x = c->ctus_x; f.ctus_y = c->ctus_y; f.num_frames = num_frames; f.row_begin = row_begin; f.row_end = row_end;
+  f.qp = qp < 0 ? 0 : (qp > 51 ? 51 : qp);
   return f;
 }
 
@@ -321,7 +325,7 @@ int fhevc_kernel_timing(fhevc_ctx* c, int which, int reset, double* avg_ms, uint
 }
 
 int fhevc_predict_frames_device(fhevc_ctx* c, const void* d_luma, int sample_bytes, int stride_samples,
-                                long long frame_stride_samples, int num_frames, int ctu_row_begin, int ctu_row_end,
+                                long long frame_stride_samples, int num_frames, int ctu_row_begin, int ctu_row_end, int qp,
                                 uint8_t* d_depth_map, int32_t* d_hadamard, int32_t* d_logits, void* stream)
 {
   if (!c || !d_luma || !d_depth_map) return FHEVC_E_INVALID;
@@ -332,7 +336,7 @@ int fhevc_predict_frames_device(fhevc_ctx* c, const void* d_luma, int sample_byt
   if (num_frames > 1 && frame_stride_samples < (long long)stride_samples * (c->cfg.height - 1) + c->cfg.width) return fail(c, FHEVC_E_INVALID, "frames overlap");
   if (ctu_row_begin == ctu_row_end) return FHEVC_OK;
   hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
-  const FhevcFrames fr = frames_of(c, d_luma, sample_bytes, stride_samples, frame_stride_samples, num_frames, ctu_row_begin, ctu_row_end);
+  const FhevcFrames fr = frames_of(c, d_luma, sample_bytes, stride_samples, frame_stride_samples, num_frames, ctu_row_begin, ctu_row_end, qp);
   if (d_hadamard) {
     time_begin(c, s, 1);
     HIP_TRY(c, fhevc_launch_src_hadamard(fr, d_hadamard, s));
@@ -362,13 +366,13 @@ static int upload_frame(fhevc_ctx* c, const int16_t* luma, int stride_samples)
 int fhevc_predict_frame(fhevc_ctx* c, const int16_t* luma, int stride_samples, int qp, int slice_type,
                         uint8_t* depth_map, int32_t* ctu_src_hadamard)
 {
-  (void)qp; (void)slice_type;
+  (void)slice_type;
   if (!c || !luma || !depth_map || stride_samples < c->cfg.width) return FHEVC_E_INVALID;
   if (!c->have_weights) return fail(c, FHEVC_E_STATE, "weights not set");
   hipSetDevice(c->device);
   int rc = upload_frame(c, luma, stride_samples);
   if (rc != FHEVC_OK) return rc;
-  rc = fhevc_predict_frames_device(c, c->d_luma, 2, c->dev_stride, 0, 1, 0, c->ctus_y, c->d_depth,
+  rc = fhevc_predict_frames_device(c, c->d_luma, 2, c->dev_stride, 0, 1, 0, c->ctus_y, qp, c->d_depth,
                                    ctu_src_hadamard ? c->d_had : nullptr, nullptr, c->stream);
   if (rc != FHEVC_OK) return rc;
   HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));

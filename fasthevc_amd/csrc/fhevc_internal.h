@@ -10,7 +10,7 @@
 //   frag  : MFMA A-operand fragments, one uint4 (8 bf16) per lane: conv1 [64], conv2 [9][64], conv3 [2][18][64]
 //   bias  : float b1[16], b2[32], b3[64]
 //   whead : uint8 (w + 128): wh64[2][4096], wh32[2][4096], wh16[2][1024]
-//   bhead : int32 bh64[2], bh32[2], bh16[2], then sum-correction is done in-kernel
+//   bhead : int32 bh64[2], bh32[2], bh16[2], qp_bias[3][52]
 #define FHEVC_FRAG_CONV1 0
 #define FHEVC_FRAG_CONV2 64
 #define FHEVC_FRAG_CONV3 (64 + 9 * 64)
@@ -25,13 +25,14 @@ struct FhevcFrames {
   int ctus_x, ctus_y;
   int num_frames;
   int row_begin, row_end;    // CTU-row band processed by this launch
+  int qp;                    // slice QP (0..51): selects the per-QP prior of the classifier heads
 };
 
 struct FhevcCnnWeights {
   const uint4* frag;
   const float* bias;
   const uint8_t* whead;
-  const int32_t* bhead;
+  const int32_t* bhead;      // bh64[2], bh32[2], bh16[2], then qp_bias[3][52]
   float scale[3];            // 2^-shift per conv layer
 };
 

@@ -390,7 +390,8 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
     {
       if (tid < 42) {  // logits start from the head biases
         const int k = tid >> 1, cls = tid & 1;
-        logitL[tid] = W.bhead[(k == 0 ? 0 : (k < 5 ? 2 : 4)) + cls];
+        const int lvl = k == 0 ? 0 : (k < 5 ? 1 : 2);
+        logitL[tid] = W.bhead[2 * lvl + cls] + (cls ? W.bhead[6 + lvl * 52 + F.qp] : 0);  // head bias + QP prior on "split"
       }
       const unsigned* inp = reinterpret_cast<const unsigned*>(lds + R2_OFF);
       // K slots: lanes h=0 hold columns x-1 and x, lanes h=1 column x+1 (+ 4 zero slots);

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Training-set generator: replaces the reference's HARP dump + MATLAB getData pipeline
+(Src_HARP/CShow_PredResiReco.h:127-255, matlab/dataExtraction/detectAndClassify32Cu.m).
+
+For seeded synthetic pictures it runs the REFERENCE's own full-RDO decision path (oracle/_ref/libhmref.so:
+TEncSlice::compressSlice -> TEncCu::xCompressCU through oracle/ref_rdo_harness.cpp) at several QPs and stores, per
+full 64x64 CTU: the 8-bit luma tile and the 16x16 depth map.  Build-container only (needs oracle/_ref).
+
+usage: python -m fasthevc_amd.train.make_labels --out /tmp/fhevc_labels --frames 64 --workers 8
+"""
+import argparse
+import os
+import sys
+import time
+from multiprocessing import Pool
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from fasthevc_amd import frames  # noqa: E402
+
+QPS = (22, 27, 32, 37)
+W, H = 1024, 576  # 16 x 9 full CTUs
+
+
+def training_picture(seed):
+    """Seeded content different from the two pinned evaluation pictures (other seeds, random contrast/brightness)."""
+    rng = np.random.default_rng(10_000 + seed)
+    kind = seed % 4
+    if kind == 3:
+        y = frames.texture16_luma(W, H, seed=50_000 + seed, frame=int(rng.integers(0, 50))).astype(np.float64)
+    else:
+        y = frames.hetero_luma(W, H, seed=20_000 + seed).astype(np.float64)
+    gain = rng.uniform(0.6, 1.4)
+    offs = rng.uniform(-25, 25)
+    y = (y - 128.0) * gain + 128.0 + offs
+    if rng.random() < 0.3:  # soften some pictures: more large CUs
+        y = frames._box_blur(y, 3)
+    return np.clip(np.rint(y), 0, 255).astype(np.uint8)
+
+
+def work(seed):
+    from oracle import oracle_py as op
+    lib = op.bind_rdo(op.load_ref())
+    luma = training_picture(seed)
+    buf, org, stride = frames.to_pel_plane(luma, 8)
+    cw, ch = W // 64, H // 64
+    tiles = luma.reshape(ch, 64, cw, 64).transpose(0, 2, 1, 3).reshape(cw * ch, 64, 64)
+    out = {"tiles": tiles}
+    for qp in QPS:
+        depth, st = op.rdo_encode(lib, buf, org, stride, W, H, 8, qp)
+        out[f"depth_q{qp}"] = depth.reshape(cw * ch, 16, 16)
+        out[f"stats_q{qp}"] = np.array([st["bits"], st["dist"], st["psnr_y"], st["seconds"]])
+    return seed, out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default="/tmp/fhevc_labels")
+    ap.add_argument("--frames", type=int, default=64)
+    ap.add_argument("--first", type=int, default=0)
+    ap.add_argument("--workers", type=int, default=8)
+    args = ap.parse_args()
+    os.makedirs(args.out, exist_ok=True)
+    t0 = time.time()
+    with Pool(args.workers) as pool:
+        for i, (seed, out) in enumerate(pool.imap_unordered(work, range(args.first, args.first + args.frames))):
+            np.savez_compressed(os.path.join(args.out, f"pic_{seed:05d}.npz"), **out)
+            if i % 8 == 0:
+                print(f"{i + 1}/{args.frames} pictures, {time.time() - t0:.0f} s", flush=True)
+    print("done", time.time() - t0)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""Trainer for the integer-valued depth classifier -- replaces the reference's MATLAB
+scripts (matlab/dataExtraction/Train...Example.m:75-96, 195-205; labels detectAndClassify32Cu.m:11-62).
+
+The network is trained directly in the fixed-point domain the HIP kernel runs in: latent float
+weights are rounded to int8 in the forward pass (straight-through gradients), activations are
+clamp(floor((acc + b) >> s), 0, 255).  What the trainer evaluates is therefore bit-for-bit what
+fasthevc_amd/csrc/k_cnn.hip and oracle/fhevc_oracle.c compute from the exported FHW1 blob.
+
+Labels (per full CTU, per QP) come from the reference's own full-RDO depth maps (fasthevc_amd/train/make_labels.py):
+  s64 = depth(0,0) >= 1;  s32[q] = depth(quadrant origin) >= 2, counted only where s64;  s16[b] = depth(block origin)
+  == 3, counted only where its quadrant is split -- the 32-level rule is the reference's isDiv = (Depth != 1) under
+  Depth(CU0_0) != 0 (detectAndClassify32Cu.m:11-16, 57-62).
+
+usage: python -m fasthevc_amd.train.train --data /tmp/fhevc_labels --out fasthevc_amd/weights/depthnet_v1.fhw
+"""
+import argparse
+import glob
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as Fn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from fasthevc_amd import weights as W  # noqa: E402
+
+QPS = (22, 27, 32, 37)
+SHIFTS = (6, 7, 8)
+LOSS_SCALE = (2.0 ** -15, 2.0 ** -14, 2.0 ** -13)  # int logits -> loss units, per level (64, 32, 16)
+
+
+def ste_round(x):
+    return x + (torch.round(x) - x).detach()
+
+
+def ste_floor(x):
+    return x + (torch.floor(x) - x).detach()
+
+
+class DepthNetQ(nn.Module):
+    def __init__(self, seed=0):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        self.w1 = nn.Parameter(torch.randn(16, 1, 3, 3, generator=g) * 21.0)
+        self.b1 = nn.Parameter(torch.zeros(16))
+        self.w2 = nn.Parameter(torch.randn(32, 16, 3, 3, generator=g) * 9.0)
+        self.b2 = nn.Parameter(torch.zeros(32))
+        self.w3 = nn.Parameter(torch.randn(64, 32, 3, 3, generator=g) * 12.5)
+        self.b3 = nn.Parameter(torch.zeros(64))
+        self.h64 = nn.Parameter(torch.randn(2, 64, 8, 8, generator=g) * 6.0)   # [cls][c][y][x] (exported as [cls][y][x][c])
+        self.h32 = nn.Parameter(torch.randn(2, 64, 8, 8, generator=g) * 8.0)
+        self.h16 = nn.Parameter(torch.randn(2, 64, 4, 4, generator=g) * 8.0)
+        self.bh64 = nn.Parameter(torch.zeros(2))
+        self.bh32 = nn.Parameter(torch.zeros(2))
+        self.bh16 = nn.Parameter(torch.zeros(2))
+        self.qp_bias = nn.Parameter(torch.zeros(3, 52))
+
+    @staticmethod
+    def q8(w):
+        return ste_round(torch.clamp(w, -127, 127))
+
+    def trunk(self, x):
+        """x: [B,1,64,64] float holding integers -128..127 -> a3 [B,64,16,16] integers 0..255"""
+        z = Fn.conv2d(x, self.q8(self.w1), ste_round(self.b1), padding=1)
+        a = torch.clamp(ste_floor(Fn.max_pool2d(z, 2) / float(1 << SHIFTS[0])), 0, 255)
+        z = Fn.conv2d(a, self.q8(self.w2), ste_round(self.b2), padding=1)
+        a = torch.clamp(ste_floor(Fn.max_pool2d(z, 2) / float(1 << SHIFTS[1])), 0, 255)
+        z = Fn.conv2d(a, self.q8(self.w3), ste_round(self.b3), padding=1)
+        return torch.clamp(ste_floor(z / float(1 << SHIFTS[2])), 0, 255)
+
+    def heads(self, a3):
+        """integer logits without the QP prior: l64 [B,2], l32 [B,2,2,2], l16 [B,2,4,4]"""
+        pooled = 4.0 * Fn.avg_pool2d(a3, 2)
+        l64 = Fn.conv2d(pooled, self.q8(self.h64), ste_round(self.bh64)).flatten(1)
+        l32 = Fn.conv2d(a3, self.q8(self.h32), ste_round(self.bh32), stride=8)
+        l16 = Fn.conv2d(a3, self.q8(self.h16), ste_round(self.bh16), stride=4)
+        return l64, l32, l16
+
+    def export(self):
+        r = lambda t: torch.round(t.detach()).to(torch.int64).numpy()
+        q = lambda t: np.clip(r(t), -127, 127).astype(np.int8)
+        out = {
+            "shift": np.array(SHIFTS, np.int32),
+            "w1": q(self.w1).reshape(16, 3, 3), "b1": r(self.b1).astype(np.int32),
+            "w2": q(self.w2), "b2": r(self.b2).astype(np.int32),
+            "w3": q(self.w3), "b3": r(self.b3).astype(np.int32),
+            "wh64": q(self.h64).transpose(0, 2, 3, 1).copy(), "bh64": r(self.bh64).astype(np.int32),
+            "wh32": q(self.h32).transpose(0, 2, 3, 1).copy(), "bh32": r(self.bh32).astype(np.int32),
+            "wh16": q(self.h16).transpose(0, 2, 3, 1).copy(), "bh16": r(self.bh16).astype(np.int32),
+            "qp_bias": r(self.qp_bias).astype(np.int32),
+        }
+        for k in ("b1", "b2", "b3"):
+            out[k] = np.clip(out[k], -W.BIAS_LIMIT, W.BIAS_LIMIT).astype(np.int32)
+        return out
+
+
+def labels_from_depth(depth):
+    """depth [N,16,16] uint8 -> s64 [N], s32 [N,2,2], s16 [N,4,4] (int64 0/1) and validity masks m32, m16"""
+    d = torch.from_numpy(depth.astype(np.int64))
+    s64 = (d[:, 0, 0] >= 1).long()
+    s32 = (d[:, ::8, ::8] >= 2).long()
+    s16 = (d[:, ::4, ::4] == 3).long()
+    m32 = s64[:, None, None].expand_as(s32).bool()
+    m16 = s32.repeat_interleave(2, 1).repeat_interleave(2, 2).bool() & s64[:, None, None].bool()
+    return s64, s32, s16, m32, m16
+
+
+def load_data(path, val_every=8):
+    files = sorted(glob.glob(os.path.join(path, "pic_*.npz")))
+    tr, va = [], []
+    for i, f in enumerate(files):
+        z = np.load(f)
+        item = (z["tiles"], {qp: z[f"depth_q{qp}"] for qp in QPS})
+        (va if i % val_every == 0 else tr).append(item)
+
+    def cat(items):
+        tiles = np.concatenate([t for t, _ in items])
+        depth = {qp: np.concatenate([d[qp] for _, d in items]) for qp in QPS}
+        return tiles, depth
+    return cat(tr), cat(va), len(files)
+
+
+def batch_loss(model, x, depths, idx, stats=None):
+    a3 = model.trunk(x)
+    l64, l32, l16 = model.heads(a3)
+    total = 0.0
+    for qp in QPS:
+        s64, s32, s16, m32, m16 = labels_from_depth(depths[qp][idx])
+        qb = ste_round(model.qp_bias[:, qp])
+        z64 = (l64 + torch.stack([torch.zeros(()), qb[0]])[None, :]) * LOSS_SCALE[0]
+        z32 = (l32 + torch.stack([torch.zeros(()), qb[1]])[None, :, None, None]) * LOSS_SCALE[1]
+        z16 = (l16 + torch.stack([torch.zeros(()), qb[2]])[None, :, None, None]) * LOSS_SCALE[2]
+        total = total + Fn.cross_entropy(z64, s64)
+        if m32.any():
+            total = total + Fn.cross_entropy(z32.permute(0, 2, 3, 1)[m32], s32[m32])
+        if m16.any():
+            total = total + Fn.cross_entropy(z16.permute(0, 2, 3, 1)[m16], s16[m16])
+        if stats is not None:
+            with torch.no_grad():
+                p64 = (z64[:, 1] > z64[:, 0]).long()
+                p32 = (z32[:, 1] > z32[:, 0]).long()
+                p16 = (z16[:, 1] > z16[:, 0]).long()
+                st = stats.setdefault(qp, np.zeros(6))
+                st += np.array([(p64 == s64).sum().item(), s64.numel(), (p32 == s32)[m32].sum().item(), int(m32.sum()),
+                                (p16 == s16)[m16].sum().item(), int(m16.sum())], np.float64)
+    return total / len(QPS)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--data", default="/tmp/fhevc_labels")
+    ap.add_argument("--out", default=os.path.join(ROOT, "fasthevc_amd", "weights", "depthnet_v1.fhw"))
+    ap.add_argument("--epochs", type=int, default=12)
+    ap.add_argument("--batch", type=int, default=96)
+    ap.add_argument("--threads", type=int, default=8)
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+    torch.set_num_threads(args.threads)
+    torch.manual_seed(args.seed)
+    (tr_t, tr_d), (va_t, va_d), nfiles = load_data(args.data)
+    print(f"{nfiles} pictures: {len(tr_t)} training CTUs, {len(va_t)} validation CTUs, QPs {QPS}", flush=True)
+    model = DepthNetQ(args.seed)
+    conv_w = [model.w1, model.w2, model.w3]
+    conv_b = [model.b1, model.b2, model.b3]
+    head_w = [model.h64, model.h32, model.h16]
+    head_b = [model.bh64, model.bh32, model.bh16, model.qp_bias]
+    base = [0.4, 15.0, 0.4, 400.0]
+    opt = torch.optim.Adam([{"params": conv_w, "lr": base[0]}, {"params": conv_b, "lr": base[1]},
+                            {"params": head_w, "lr": base[2]}, {"params": head_b, "lr": base[3]}], betas=(0.9, 0.99))
+    steps_per_epoch = len(tr_t) // args.batch
+    total_steps = steps_per_epoch * args.epochs
+    xt = torch.from_numpy(tr_t.astype(np.float32) - 128.0)[:, None]
+    xv = torch.from_numpy(va_t.astype(np.float32) - 128.0)[:, None]
+    step, t0 = 0, time.time()
+    for ep in range(args.epochs):
+        perm = torch.randperm(len(tr_t))
+        model.train()
+        run = 0.0
+        for b in range(steps_per_epoch):
+            idx = perm[b * args.batch:(b + 1) * args.batch]
+            x = xt[idx]
+            if torch.rand(()) < 0.5:  # horizontal flip keeps the block grid: labels flip with it
+                x = torch.flip(x, dims=[3])
+                depths = {qp: tr_d[qp][:, :, ::-1] for qp in QPS}
+            else:
+                depths = tr_d
+            f = 0.5 * (1 + np.cos(np.pi * step / total_steps))
+            for gidx, grp in enumerate(opt.param_groups):
+                grp["lr"] = base[gidx] * (0.03 + 0.97 * f)
+            loss = batch_loss(model, x, depths, idx.numpy())
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            run += loss.item()
+            step += 1
+            if b % 100 == 99:
+                print(f"  ep {ep} step {b + 1}/{steps_per_epoch} loss {run / 100:.4f} ({time.time() - t0:.0f} s)", flush=True)
+                run = 0.0
+        model.eval()
+        stats, vl = {}, 0.0
+        with torch.no_grad():
+            for b in range(0, len(va_t), 256):
+                idx = np.arange(b, min(b + 256, len(va_t)))
+                vl += batch_loss(model, xv[idx], va_d, idx, stats).item() * len(idx)
+        msg = " ".join(f"q{qp}: 64 {s[0] / max(s[1], 1):.3f} 32 {s[2] / max(s[3], 1):.3f} 16 {s[4] / max(s[5], 1):.3f}" for qp, s in stats.items())
+        print(f"epoch {ep}: val loss {vl / len(va_t):.4f} acc {msg} ({time.time() - t0:.0f} s)", flush=True)
+        os.makedirs(os.path.dirname(args.out), exist_ok=True)
+        W.save(args.out, model.export())
+    print("saved", args.out)
+
+
+if __name__ == "__main__":
+    main()

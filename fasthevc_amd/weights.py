@@ -2,7 +2,7 @@
 FC heads.  The same bytes feed the HIP library (fhevc_cfg.weights_path) and, in tests,
 the CPU oracle.
 
-Layout after the 8-byte header (magic "FHW1", uint32 version = 1), all little-endian, no padding:
+Layout after the 8-byte header (magic "FHW1", uint32 version = 2), all little-endian, no padding:
   int32 shift[3]
   int8 w1[16][3][3]         int32 b1[16]
   int8 w2[32][16][3][3]     int32 b2[32]
@@ -10,6 +10,7 @@ Layout after the 8-byte header (magic "FHW1", uint32 version = 1), all little-en
   int8 wh64[2][8][8][64]    int32 bh64[2]      (64-level head, on the 2x2 sum-pooled conv3 map)
   int8 wh32[2][8][8][64]    int32 bh32[2]
   int8 wh16[2][4][4][64]    int32 bh16[2]
+  int32 qp_bias[3][52]      added to the "split" logit of the 64-, 32-, 16-level heads for slice QP 0..51
 """
 import numpy as np
 
@@ -22,6 +23,7 @@ FIELDS = [
     ("wh64", np.int8, (2, 8, 8, 64)), ("bh64", np.int32, (2,)),
     ("wh32", np.int8, (2, 8, 8, 64)), ("bh32", np.int32, (2,)),
     ("wh16", np.int8, (2, 4, 4, 64)), ("bh16", np.int32, (2,)),
+    ("qp_bias", np.int32, (3, 52)),
 ]
 BIAS_LIMIT = 1 << 22  # keeps |bias + sum(w*a)| < 2^24 so fp32 accumulation of bf16 operands is exact
 BLOB_BYTES = 8 + sum(int(np.prod(s)) * np.dtype(t).itemsize for _, t, s in FIELDS)
@@ -44,7 +46,7 @@ def validate(w):
 
 def pack(w):
     validate(w)
-    parts = [MAGIC, np.uint32(1).tobytes()]
+    parts = [MAGIC, np.uint32(2).tobytes()]
     for name, dt, _ in FIELDS:
         parts.append(np.ascontiguousarray(w[name], dtype=dt).tobytes())
     blob = b"".join(parts)
@@ -55,7 +57,7 @@ def pack(w):
 def unpack(blob):
     if len(blob) != BLOB_BYTES or blob[:4] != MAGIC:
         raise ValueError("not an FHW1 weight blob")
-    if int(np.frombuffer(blob[4:8], np.uint32)[0]) != 1:
+    if int(np.frombuffer(blob[4:8], np.uint32)[0]) != 2:
         raise ValueError("unsupported FHW1 version")
     off, out = 8, {}
     for name, dt, shape in FIELDS:
@@ -87,6 +89,8 @@ def random_weights(seed=0, extreme=False):
                 w[name] = rng.choice(np.array([-127, 127], np.int8), size=shape)
             elif name == "shift":
                 w[name] = np.array([4, 12, 13], np.int32)
+            elif name == "qp_bias":
+                w[name] = rng.integers(-100000, 100000, size=shape).astype(np.int32)
             else:
                 w[name] = rng.integers(-1000, 1000, size=shape).astype(np.int32)
         return w
@@ -101,4 +105,5 @@ def random_weights(seed=0, extreme=False):
         w[k] = rng.integers(-64, 65, size=shape).astype(np.int8)
     for k in ("bh64", "bh32", "bh16"):
         w[k] = rng.integers(-50000, 50000, size=2).astype(np.int32)
+    w["qp_bias"] = rng.integers(-200000, 200000, size=(3, 52)).astype(np.int32)
     return w

@@ -83,8 +83,9 @@ int  fhevc_set_weights(fhevc_ctx* ctx, const void* blob, size_t bytes);
  * TEncSlice::compressSlice (TEncSlice.cpp:792) with pcPic->getPicYuvOrg()->getAddr(COMPONENT_Y) / getStride
  * (TComPicYuv.h:121-147).  depth_map: numCtus*256 bytes.  ctu_src_hadamard: optional, numCtus values equal to
  * TEncCu::updateCtuDataISlice(ctu, w, h) (TEncCu.cpp:1324-1343) -- what TEncSlice::calCostSliceI sums
- * (TEncSlice.cpp:663-695).  qp / slice_type are the slice's (the intra classifier ignores them, like the
- * reference's MATLAB pipeline does: CShow_PredResiReco.h:93 stores QP, nothing reads it). */
+ * (TEncSlice.cpp:663-695).  qp is the slice QP: it selects a per-QP prior on the split decisions (the reference
+ * stores QP in its labels, CShow_PredResiReco.h:93, but its MATLAB pipeline never reads it); slice_type is
+ * reserved (I slices only this round). */
 int  fhevc_predict_frame(fhevc_ctx* ctx, const int16_t* luma, int stride_samples, int qp, int slice_type,
                          uint8_t* depth_map, int32_t* ctu_src_hadamard);
 
@@ -105,7 +106,7 @@ int  fhevc_intra_first_pass(fhevc_ctx* ctx, const int16_t* luma, int stride_samp
  * stream: hipStream_t (NULL = the context's stream).  Asynchronous with respect to the host. */
 int  fhevc_predict_frames_device(fhevc_ctx* ctx, const void* d_luma, int sample_bytes, int stride_samples,
                                  long long frame_stride_samples, int num_frames, int ctu_row_begin, int ctu_row_end,
-                                 uint8_t* d_depth_map, int32_t* d_hadamard, int32_t* d_logits, void* stream);
+                                 int qp, uint8_t* d_depth_map, int32_t* d_hadamard, int32_t* d_logits, void* stream);
 
 /* CTU-row band of rank `rank` out of `world`: rows [begin, end) */
 int  fhevc_band(int ctu_rows, int rank, int world, int* begin, int* end);

@@ -452,7 +452,7 @@ static inline uint8_t requant(int32_t acc, int shift)
   return (uint8_t)clip3(0, 255, v);
 }
 
-void fho_cnn_ctu_debug(const fho_weights* w, const int8_t* ctu, uint8_t* a1o, uint8_t* a2o, uint8_t* a3o,
+void fho_cnn_ctu_debug(const fho_weights* w, const int8_t* ctu, int qp, uint8_t* a1o, uint8_t* a2o, uint8_t* a3o,
                        int32_t logits[21][2])
 {
   static uint8_t a1[32 * 32 * 16], a2[16 * 16 * 32], a3[16 * 16 * 64];
@@ -541,14 +541,21 @@ void fho_cnn_ctu_debug(const fho_weights* w, const int8_t* ctu, uint8_t* a1o, ui
       logits[5 + b][cls] = acc;
     }
   }
+  /* QP prior on the split class (the reference stores QP in its JSON, CShow_PredResiReco.h:93, but never uses it) */
+  {
+    const int q = clip3(0, 51, qp);
+    logits[0][1] += w->qp_bias[q];
+    for (int k = 1; k < 5; k++) logits[k][1] += w->qp_bias[52 + q];
+    for (int k = 5; k < 21; k++) logits[k][1] += w->qp_bias[104 + q];
+  }
   if (a1o) memcpy(a1o, a1, sizeof a1);
   if (a2o) memcpy(a2o, a2, sizeof a2);
   if (a3o) memcpy(a3o, a3, sizeof a3);
 }
 
-void fho_cnn_ctu(const fho_weights* w, const int8_t* ctu, int32_t logits[21][2])
+void fho_cnn_ctu(const fho_weights* w, const int8_t* ctu, int qp, int32_t logits[21][2])
 {
-  fho_cnn_ctu_debug(w, ctu, 0, 0, 0, logits);
+  fho_cnn_ctu_debug(w, ctu, qp, 0, 0, 0, logits);
 }
 
 /* split decision: class 1 ("div", sortToDirLabels.m:11-19) wins only on a strict majority. */
@@ -603,7 +610,7 @@ void fho_load_ctu(const int16_t* luma, int stride, int width, int height, int ct
 }
 
 void fho_predict_frame(const fho_weights* w, const int16_t* luma, int stride, int width, int height,
-                       int bit_depth, uint8_t* depth_map, int32_t* logits_out)
+                       int bit_depth, int qp, uint8_t* depth_map, int32_t* logits_out)
 {
   const int cw = (width + 63) / 64, ch = (height + 63) / 64;
   int8_t ctu[64 * 64];
@@ -612,7 +619,7 @@ void fho_predict_frame(const fho_weights* w, const int16_t* luma, int stride, in
     for (int cx = 0; cx < cw; cx++) {
       const int a = cy * cw + cx;
       fho_load_ctu(luma, stride, width, height, cx, cy, bit_depth, ctu);
-      fho_cnn_ctu(w, ctu, logits);
+      fho_cnn_ctu(w, ctu, qp, logits);
       fho_depth_from_logits(logits, imin(64, width - cx * 64), imin(64, height - cy * 64), depth_map + a * 256);
       if (logits_out) memcpy(logits_out + a * 42, logits, sizeof logits);
     }

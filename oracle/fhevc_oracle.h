@@ -110,13 +110,14 @@ typedef struct {
   int32_t bh32[2];
   int8_t  wh16[2 * 1024];      /* [cls][y4][x4][c64] on a 4x4 window of a3 */
   int32_t bh16[2];
+  int32_t qp_bias[3 * 52];     /* [level 64,32,16][slice QP]: added to the split logit */
 } fho_weights;
 
 /* ctu: 64x64 centred 8-bit samples (value-128), row stride 64, zeros outside the picture.
  * logits[21][2]: 0 = 64-level, 1..4 = 32-level quadrants (raster), 5..20 = 16-level blocks (raster). */
-void fho_cnn_ctu(const fho_weights* w, const int8_t* ctu, int32_t logits[21][2]);
+void fho_cnn_ctu(const fho_weights* w, const int8_t* ctu, int qp, int32_t logits[21][2]);
 /* optional taps for debugging: a1 [32][32][16], a2 [16][16][32], a3 [16][16][64] (uint8) */
-void fho_cnn_ctu_debug(const fho_weights* w, const int8_t* ctu, uint8_t* a1, uint8_t* a2, uint8_t* a3,
+void fho_cnn_ctu_debug(const fho_weights* w, const int8_t* ctu, int qp, uint8_t* a1, uint8_t* a2, uint8_t* a3,
                        int32_t logits[21][2]);
 /* logits -> raster 16x16 depth map.  valid_w/valid_h = in-picture part of the CTU; nodes crossing
  * the picture edge are forced to split (TEncCu.cpp:574,894 bBoundary); units outside get 0. */
@@ -126,7 +127,7 @@ void fho_load_ctu(const int16_t* luma, int stride, int width, int height, int ct
                   int bit_depth, int8_t ctu[64 * 64]);
 /* whole frame: depth maps (numCtus*256, raster per CTU) and optionally logits (numCtus*42) */
 void fho_predict_frame(const fho_weights* w, const int16_t* luma, int stride, int width, int height,
-                       int bit_depth, uint8_t* depth_map, int32_t* logits_out);
+                       int bit_depth, int qp, uint8_t* depth_map, int32_t* logits_out);
 
 #ifdef __cplusplus
 }

@@ -36,6 +36,7 @@ class Weights(C.Structure):
         ("wh64", C.c_int8 * (2 * 4096)), ("bh64", C.c_int32 * 2),
         ("wh32", C.c_int8 * (2 * 4096)), ("bh32", C.c_int32 * 2),
         ("wh16", C.c_int8 * (2 * 1024)), ("bh16", C.c_int32 * 2),
+        ("qp_bias", C.c_int32 * (3 * 52)),
     ]
 
 
@@ -79,11 +80,11 @@ def load_oracle():
                                         C.c_double, C.POINTER(NodeCost), C.c_void_p]
     lib.fho_first_pass_ctu.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_double, C.POINTER(NodeCost)]
-    lib.fho_cnn_ctu.argtypes = [C.POINTER(Weights), _i8p, _i32p]
-    lib.fho_cnn_ctu_debug.argtypes = [C.POINTER(Weights), _i8p, _u8p, _u8p, _u8p, _i32p]
+    lib.fho_cnn_ctu.argtypes = [C.POINTER(Weights), _i8p, C.c_int, _i32p]
+    lib.fho_cnn_ctu_debug.argtypes = [C.POINTER(Weights), _i8p, C.c_int, _u8p, _u8p, _u8p, _i32p]
     lib.fho_depth_from_logits.argtypes = [_i32p, C.c_int, C.c_int, _u8p]
     lib.fho_load_ctu.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _i8p]
-    lib.fho_predict_frame.argtypes = [C.POINTER(Weights), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _u8p, C.c_void_p]
+    lib.fho_predict_frame.argtypes = [C.POINTER(Weights), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _u8p, C.c_void_p]
     return lib
 
 
@@ -134,7 +135,7 @@ def ptr(a, offset_elems=0):
 def weights_from_arrays(d):
     """dict of numpy arrays (fasthevc_amd.weights layout) -> Weights struct."""
     w = Weights()
-    for k in ("shift", "w1", "b1", "w2", "b2", "w3", "b3", "wh64", "bh64", "wh32", "bh32", "wh16", "bh16"):
+    for k in ("shift", "w1", "b1", "w2", "b2", "w3", "b3", "wh64", "bh64", "wh32", "bh32", "wh16", "bh16", "qp_bias"):
         arr = np.ascontiguousarray(d[k]).reshape(-1)
         field = getattr(w, k)
         assert len(field) == arr.size, (k, len(field), arr.size)

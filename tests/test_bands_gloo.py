@@ -34,7 +34,7 @@ def _worker(rank, world, port, q):
     for f in range(NF):
         buf, org, stride = frames.to_pel_plane(frames.texture16_luma(W, H, seed=50 + f), 8)
         depth = np.zeros(cw * ch * 256, np.uint8)
-        oracle.fho_predict_frame(ws, op.ptr(buf.reshape(-1), org), stride, W, H, 8, depth, None)
+        oracle.fho_predict_frame(ws, op.ptr(buf.reshape(-1), org), stride, W, H, 8, 32, depth, None)
         depth = depth.reshape(ch, cw, 256)
         full.append(depth.reshape(ch * cw, 256))
         gathered[rank, f, : e - b] = torch.from_numpy(depth[b:e])  # this rank only contributes its band

@@ -19,13 +19,13 @@ def torch_cuda():
     return torch
 
 
-def _oracle_frame(oracle, w, luma_u8, bd):
+def _oracle_frame(oracle, w, luma_u8, bd, qp=32):
     h, wd = luma_u8.shape
     buf, org, stride = frames.to_pel_plane(luma_u8, bd)
     cw, ch = frames.ctu_grid(wd, h)
     depth = np.zeros(cw * ch * 256, np.uint8)
     logits = np.zeros(cw * ch * 42, np.int32)
-    oracle.fho_predict_frame(op.weights_from_arrays(w), op.ptr(buf.reshape(-1), org), stride, wd, h, bd, depth,
+    oracle.fho_predict_frame(op.weights_from_arrays(w), op.ptr(buf.reshape(-1), org), stride, wd, h, bd, qp, depth,
                              C.c_void_p(logits.ctypes.data))
     had = np.zeros(cw * ch, np.int32)
     oracle.fho_frame_src_hadamard(op.ptr(buf.reshape(-1), org), stride, wd, h, had)
@@ -60,9 +60,10 @@ def test_predict_frame_416x240(oracle, golden, bd, seed, extreme):
     """config 1 geometry (7x4 CTUs, last column 32 px wide, last row 48 px tall), host-buffer entry point."""
     w = weights.random_weights(seed, extreme=extreme)
     luma = frames.texture16_luma(416, 240)
-    buf, org, stride, depth_ref, _, had_ref = _oracle_frame(oracle, w, luma, bd)
+    qp = 22 + 5 * (seed % 4)   # the per-QP prior of the heads is part of the parity
+    buf, org, stride, depth_ref, _, had_ref = _oracle_frame(oracle, w, luma, bd, qp)
     ctx = capi.Context(416, 240, bd, w)
-    depth, had = ctx.predict_frame(buf, org, stride)
+    depth, had = ctx.predict_frame(buf, org, stride, qp=qp)
     assert np.array_equal(had, had_ref)
     assert np.array_equal(had, golden[f"ctu_had_t16_416x240_{bd}"])  # == the reference's updateCtuDataISlice
     bad = np.nonzero((depth != depth_ref).any(axis=1))[0]
@@ -94,7 +95,7 @@ def test_device_batch_logits_and_bands(oracle, torch_cuda):
     w = weights.random_weights(2)
     W, H, NF = 416, 240, 3
     lumas = [frames.texture16_luma(W, H, seed=100 + f) for f in range(NF)]
-    refs = [_oracle_frame(oracle, w, y, 8) for y in lumas]
+    refs = [_oracle_frame(oracle, w, y, 8, 37) for y in lumas]
     ctx = capi.Context(W, H, 8, w)
     dev = torch.device("cuda:0")
     n = ctx.num_ctus
@@ -103,7 +104,7 @@ def test_device_batch_logits_and_bands(oracle, torch_cuda):
     depth = torch.zeros((NF, n, 256), dtype=torch.uint8, device=dev)
     had = torch.zeros((NF, n), dtype=torch.int32, device=dev)
     logits = torch.zeros((NF, n, 42), dtype=torch.int32, device=dev)
-    ctx.predict_frames_device(d8.data_ptr(), 1, W, W * H, NF, depth.data_ptr(), had.data_ptr(), logits.data_ptr())
+    ctx.predict_frames_device(d8.data_ptr(), 1, W, W * H, NF, depth.data_ptr(), had.data_ptr(), logits.data_ptr(), qp=37)
     torch.cuda.synchronize()
     for f in range(NF):
         assert np.array_equal(depth[f].cpu().numpy(), refs[f][3])
@@ -115,7 +116,7 @@ def test_device_batch_logits_and_bands(oracle, torch_cuda):
     d16 = torch.from_numpy(planes).to(dev)
     band = torch.full((NF, 2 * ctx.ctus_x, 256), 255, dtype=torch.uint8, device=dev)
     ctx.predict_frames_device(d16.data_ptr() + 2 * org, 2, stride, planes.shape[1] * planes.shape[2], NF,
-                              band.data_ptr(), None, None, rows=(1, 3), stream=torch.cuda.current_stream().cuda_stream)
+                              band.data_ptr(), None, None, rows=(1, 3), stream=torch.cuda.current_stream().cuda_stream, qp=37)
     torch.cuda.synchronize()
     for f in range(NF):
         assert np.array_equal(band[f].cpu().numpy(), refs[f][3][ctx.ctus_x:3 * ctx.ctus_x])

@@ -31,6 +31,10 @@ def torch_cnn(w, ctu):
         for b in range(16):
             by, bx = b >> 2, b & 3
             logits[5 + b, cls] = int((a3[by * 4:by * 4 + 4, bx * 4:bx * 4 + 4] * t(w["wh16"][cls])).sum()) + int(w["bh16"][cls])
+    qp = 27
+    logits[0, 1] += int(w["qp_bias"][0, qp])
+    logits[1:5, 1] += int(w["qp_bias"][1, qp])
+    logits[5:, 1] += int(w["qp_bias"][2, qp])
     return acts, logits
 
 
@@ -52,7 +56,7 @@ def test_oracle_cnn_matches_torch_float64(oracle):
             a2 = np.zeros(16 * 16 * 32, np.uint8)
             a3 = np.zeros(16 * 16 * 64, np.uint8)
             logits = np.zeros(42, np.int32)
-            oracle.fho_cnn_ctu_debug(ws, ctu.reshape(-1), a1, a2, a3, logits)
+            oracle.fho_cnn_ctu_debug(ws, ctu.reshape(-1), 27, a1, a2, a3, logits)
             acts, ref_logits = torch_cnn(w, ctu)
             assert np.array_equal(a1.reshape(32, 32, 16), acts[0])
             assert np.array_equal(a2.reshape(16, 16, 32), acts[1])
@@ -96,7 +100,7 @@ def test_predict_frame_edge_ctus(oracle):
     luma = frames.texture16_luma(416, 240)
     buf, org, stride = frames.to_pel_plane(luma, 8)
     depth = np.zeros(28 * 256, np.uint8)
-    oracle.fho_predict_frame(ws, op.ptr(buf.reshape(-1), org), stride, 416, 240, 8, depth, None)
+    oracle.fho_predict_frame(ws, op.ptr(buf.reshape(-1), org), stride, 416, 240, 8, 32, depth, None)
     depth = depth.reshape(4, 7, 16, 16)
     assert (depth[:, 6, :, 8:] == 0).all()     # last CTU column is 32 px wide
     assert (depth[3, :, 12:, :] == 0).all()    # last CTU row is 48 px tall
