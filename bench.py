@@ -25,12 +25,33 @@ PEAK_HBM_GBS = 8000.0
 
 
 def cpu_baseline(width, height, bit_depth, w, seconds=12.0):
-    """The oracle (CPU restatement, 1 thread) on a bounded sample of the same workload."""
+    """CPU baseline on a bounded sample of the same workload, 1 host thread.
+
+    kind "reference": HM's own full-RDO decision path (TEncSlice::compressSlice -> TEncCu::xCompressCU of the reference,
+    oracle/_ref/libhmref.so, built from /root/reference in the build container and shipped as a built artefact).
+    kind "port": the CPU oracle of the GPU path (depth CNN + source Hadamard) when that library is not present."""
     from oracle import oracle_py as op
     from fasthevc_amd import frames
+    luma = frames.hetero_luma(width, height)
+    if op.have_ref():
+        lib = op.bind_rdo(op.load_ref())
+        cw_, ch_ = 768, 512  # crops of the picture: 96 CTUs each, about 1.5 s of full RDO
+        done, spent, crops = 0, 0.0, 0
+        for (ox, oy) in ((0, 0), (768, 0), (1152, 0), (0, 512), (768, 512), (1152, 512), (384, 256), (960, 256)):
+            if oy + ch_ > height or ox + cw_ > width:
+                continue
+            buf, org, stride = frames.to_pel_plane(luma[oy:oy + ch_, ox:ox + cw_].copy(), bit_depth)
+            _, st = op.rdo_encode(lib, buf, org, stride, cw_, ch_, bit_depth, 32)
+            done += st["ctus"]
+            spent += st["seconds"]
+            crops += 1
+            if spent > seconds:
+                break
+        return {"value": done / spent, "unit": "CTU depth decisions/s", "cores": 1, "kind": "reference",
+                "sample": f"{crops} crops of 768x512 ({done} CTUs) of the same 1080p hetero frame at QP32 through the reference's own "
+                          f"TEncSlice::compressSlice/TEncCu::xCompressCU full RDO (intra_main settings), {spent:.1f} s of 1 thread"}
     oracle = op.load_oracle()
     ws = op.weights_from_arrays(w)
-    luma = frames.hetero_luma(width, height)
     buf, org, stride = frames.to_pel_plane(luma, bit_depth)
     cw, ch = frames.ctu_grid(width, height)
     ctu = np.zeros(64 * 64, np.int8)
@@ -82,7 +103,11 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     W, H, NF, bd = args.width, args.height, args.frames, args.bit_depth
-    w = weights.random_weights(0)   # random-init weights of the shipped architecture (synthetic bench)
+    trained = os.path.join(ROOT, "fasthevc_amd", "weights", "depthnet_v1.fhw")
+    if os.path.exists(trained):
+        w, wdesc = weights.load(trained), "trained weights fasthevc_amd/weights/depthnet_v1.fhw"
+    else:
+        w, wdesc = weights.random_weights(0), "random-init weights"  # same architecture, same arithmetic
     ctx = capi.Context(W, H, bd, w, device=local, max_frames=NF)
     cw, ch, n_ctus = ctx.ctus_x, ctx.ctus_y, ctx.num_ctus
 
@@ -157,7 +182,7 @@ def main():
             "dtype": "bf16 operands / f32 accumulate (fixed-point valued, exact)", "data": "synthetic",
             "config": {"workload": f"BQTerrace geometry {W}x{H} all-intra QP32, GOP of {NF} synthetic 'hetero' frames per GPU "
                                    f"({'int16 Pel planes, HM stride/margins' if sample_b == 2 else 'uint8 planes'}) resident in HBM, "
-                                   f"source Hadamard + CTU-batched CNN depth predictor, random-init weights",
+                                   f"source Hadamard + CTU-batched CNN depth predictor, {wdesc}",
                        "frames_per_gpu": NF, "ctus_per_frame": n_ctus, "bit_depth": bd,
                        "sharding": "frames dealt to ranks + one all-gather of the depth maps" if world > 1 else "single GPU"},
             "roofline": roof, "roofline_hbm_kernel": hbm,

@@ -120,12 +120,14 @@ int build_weight_image(fhevc_ctx* c, const BlobView& b)
     const int r = lane & 31, h = lane >> 5;
     for (int j = 0; j < 8; ++j) {
       const int k = 8 * h + j;
-      // conv1: rows 0-15 = filter c on picture row y, rows 16-31 = filter c on row y+1; K slot k < 12 addresses the
-      // 4x3 input window: column dx = k >> 2, window row wr = 2 * ((k >> 1) & 1) + (k & 1) (row-pair dwords)
-      if (k < 12) {
-        const int dxi = k >> 2, wr = 2 * ((k >> 1) & 1) + (k & 1);
-        const int c = r & 15, ky = (r < 16) ? wr : wr - 1;
-        if (ky >= 0 && ky <= 2) put(FHEVC_FRAG_CONV1, lane, j, b.w1[c * 9 + ky * 3 + dxi]);
+      // conv1: two MFMAs (jm = pre-pool column px).  Row m = r + 32*jm: channel = m[1:0] + 4*m[3] + 8*m[2],
+      // pre-pool row py = m[4].  K slot k = 8h + j addresses the 4x4 input window: column wc = 2h + ((j >> 1) & 1),
+      // row wr = 2*(j >> 2) + (j & 1) (two row-pair dwords per column).  Tap (ky, kx) = (wr - py, wc - px).
+      for (int jm = 0; jm < 2; ++jm) {
+        const int ch = (r & 3) + 4 * ((r >> 3) & 1) + 8 * ((r >> 2) & 1), py = (r >> 4) & 1, px = jm;
+        const int wc = 2 * h + ((j >> 1) & 1), wr = 2 * (j >> 2) + (j & 1);
+        const int ky = wr - py, kx = wc - px;
+        if (ky >= 0 && ky <= 2 && kx >= 0 && kx <= 2) put(FHEVC_FRAG_CONV1 + 64 * jm, lane, j, b.w1[ch * 9 + ky * 3 + kx]);
       }
       // conv2: K-step s = tap, k = input channel
       for (int s = 0; s < 9; ++s) put(FHEVC_FRAG_CONV2 + s * 64, lane, j, b.w2[((r * 16 + k) * 9) + s]);

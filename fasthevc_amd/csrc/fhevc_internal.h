@@ -7,14 +7,14 @@
 
 // ---- depth CNN (k_cnn.hip) -------------------------------------------------------------------------------
 // Packed weight image in HBM, built once by fhevc_set_weights (fhevc_api.hip: build_weight_image):
-//   frag  : MFMA A-operand fragments, one uint4 (8 bf16) per lane: conv1 [64], conv2 [9][64], conv3 [2][18][64]
+//   frag  : MFMA A-operand fragments, one uint4 (8 bf16) per lane: conv1 [2][64], conv2 [9][64], conv3 [2][18][64]
 //   bias  : float b1[16], b2[32], b3[64]
 //   whead : uint8 (w + 128): wh64[2][4096], wh32[2][4096], wh16[2][1024]
 //   bhead : int32 bh64[2], bh32[2], bh16[2], qp_bias[3][52]
 #define FHEVC_FRAG_CONV1 0
-#define FHEVC_FRAG_CONV2 64
-#define FHEVC_FRAG_CONV3 (64 + 9 * 64)
-#define FHEVC_FRAG_TOTAL (64 + 9 * 64 + 2 * 18 * 64)
+#define FHEVC_FRAG_CONV2 128
+#define FHEVC_FRAG_CONV3 (128 + 9 * 64)
+#define FHEVC_FRAG_TOTAL (128 + 9 * 64 + 2 * 18 * 64)
 
 struct FhevcFrames {
   const void* luma;          // device pointer to sample (0,0) of frame 0

@@ -16,8 +16,9 @@
 //     accumulation is exact in any order -> the integer depth map is bit-exact against the CPU oracle;
 //   * ReLU/requant/max-pool are fused into the MFMA epilogue (in-lane max for the vertical pair,
 //     DPP quad_perm for the horizontal pair), FC heads run on v_dot4_u32_u8 with weights resident in LDS;
-//   * conv1 packs two output rows into one MFMA: A rows 0-15 = the 16 filters applied to row y, rows 16-31 =
-//     the same filters shifted one row down, K = the 4x3 input window (12 of 16 slots), read as row-pair dwords;
+//   * conv1 folds the 2x2 max-pool window into the MFMA's M dimension: A rows = (16 filters) x (2x2 pre-pool
+//     positions) = 64 rows = two MFMAs, K = the 4x4 input window (all 16 slots used, read as row-pair dwords), so a
+//     lane holds all four pre-pool outputs of its pooled position: the pool is three in-lane max, no DPP;
 //   * the next CTU's samples are prefetched into registers while the heads of the current one run.
 #include "fhevc_internal.h"
 
@@ -119,22 +120,18 @@ __device__ __forceinline__ int dpp_row_sum(int v)
   v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);  // row_mirror
   return v;
 }
-// conv1: acc rows 0-15 = picture row y, rows 16-31 = row y+1 -> 2x2 max-pool, requant, store 4 channels (8 B).
-// Both lanes of a horizontal pair hold the same 8 pooled values; the even lane finishes channels 4h..4h+3 (plane 0),
-// the odd lane 8+4h.. (plane 1), so each requantises only the 4 values it stores.
-__device__ __forceinline__ void conv1_store(const f32x16& acc, float scale, unsigned char* lds, int yp, int xh, int r, int h)
+// conv1: the two MFMAs of a unit hold, per lane, the four pre-pool outputs of 8 channels for ONE pooled position
+// (rows m of A: channel = m[1:0] + 4*m[3] + 8*m[2], pre-pool row = m[4], pre-pool column = m[5]; lane half h = m[2]
+// holds channels 8h..8h+7 = plane h).  2x2 max-pool = 3 in-lane max per channel, then requant and ONE 16-byte store.
+__device__ __forceinline__ void conv1_store(const f32x16& acc0, const f32x16& acc1, float scale, unsigned char* dst)
 {
-  const bool odd = r & 1;
-  float v[4];
+  float v[8];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const float m0 = max_with_xor1(fmaxf(acc[k], acc[k + 8]));          // vertical pair in-lane, horizontal by DPP
-    const float m1 = max_with_xor1(fmaxf(acc[k + 4], acc[k + 12]));
-    v[k] = requant(odd ? m1 : m0, scale);
+  for (int k = 0; k < 8; ++k) {  // regs k (py 0) and k+8 (py 1) of both MFMAs (px 0, 1)
+    const float m = fmaxf(fmaxf(acc0[k], acc0[k + 8]), fmaxf(acc1[k], acc1[k + 8]));
+    v[k] = requant(m, scale);
   }
-  const int pcol = 16 * xh + (r >> 1) + 1;
-  *reinterpret_cast<uint2*>(lds + R1_OFF + (odd ? A1_PLANE : 0) + ((yp + 1) * A1_PITCH + pcol) * 16 + h * 8) =
-      make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
+  *reinterpret_cast<uint4*>(dst) = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
 }
 // conv2: two output rows -> 2x2 max-pool, requant, store: the even lane of a horizontal pair finishes planes 0-1
 // (regs 0-7), the odd lane planes 2-3 (regs 8-15): 8 requants and two 8-byte stores per lane
@@ -279,7 +276,8 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
   const int r = lane & 31, h = lane >> 5;
 
   // ---- resident weight fragments (A operands) ----
-  const bf16x8 wA1 = __builtin_bit_cast(bf16x8, W.frag[FHEVC_FRAG_CONV1 + lane]);
+  const bf16x8 wA1a = __builtin_bit_cast(bf16x8, W.frag[FHEVC_FRAG_CONV1 + lane]);
+  const bf16x8 wA1b = __builtin_bit_cast(bf16x8, W.frag[FHEVC_FRAG_CONV1 + 64 + lane]);
   bf16x8 wA2[9];
 #pragma unroll
   for (int s = 0; s < 9; ++s) wA2[s] = __builtin_bit_cast(bf16x8, W.frag[FHEVC_FRAG_CONV2 + s * 64 + lane]);
@@ -393,39 +391,33 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
         const int lvl = k == 0 ? 0 : (k < 5 ? 1 : 2);
         logitL[tid] = W.bhead[2 * lvl + cls] + (cls ? W.bhead[6 + lvl * 52 + F.qp] : 0);  // head bias + QP prior on "split"
       }
-      const unsigned* inp = reinterpret_cast<const unsigned*>(lds + R2_OFF);
-      // K slots: lanes h=0 hold columns x-1 and x, lanes h=1 column x+1 (+ 4 zero slots);
-      // inside a column: row pair (2yp-1, 2yp), then (2yp+1, 2yp+2)
-      const int c0 = h ? 2 : 0;
-      const unsigned hmask = h ? 0u : 0xFFFFFFFFu;
-      f32x16 bias1;
+      // unit = one pooled row of 32 positions (picture rows 2yp, 2yp+1, all 64 columns); lane (n, h): pooled column n,
+      // K slots = the 4x4 input window of the 2x2 pre-pool outputs: lanes h=0 hold window columns 0-1, h=1 columns 2-3,
+      // each column as two row-pair dwords -> the fragment is two ds_read_b64, all 16 K slots carry data
+      const unsigned char* inb = lds + R2_OFF + (2 * r + 2 * h) * 4;
+      f32x16 bias1;  // reg i -> channel (i&3) + 4*((i>>2)&1) + 8h, the same for both pre-pool rows and both MFMAs
       {
-        const float4 b0 = *reinterpret_cast<const float4*>(biasL + 4 * h);
-        const float4 b1 = *reinterpret_cast<const float4*>(biasL + 8 + 4 * h);
+        const float4 b0 = *reinterpret_cast<const float4*>(biasL + 8 * h);
+        const float4 b1 = *reinterpret_cast<const float4*>(biasL + 8 * h + 4);
         bias1[0] = b0.x; bias1[1] = b0.y; bias1[2] = b0.z; bias1[3] = b0.w;
         bias1[4] = b1.x; bias1[5] = b1.y; bias1[6] = b1.z; bias1[7] = b1.w;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) bias1[8 + i] = bias1[i];  // rows 16-31: the same filters, one picture row lower
+        for (int i = 0; i < 8; ++i) bias1[8 + i] = bias1[i];
       }
-      // software pipeline: MFMA of unit i is in flight while unit i-1 is pooled, requantised and stored
-      auto frag1 = [=](int u) {
-        const unsigned* p = inp + (u >> 1) * IN_PITCH + 32 * (u & 1) + r;
-        uint4 q;
-        q.x = p[c0];
-        q.y = p[IN_PITCH + c0];
-        q.z = p[1] & hmask;
-        q.w = p[IN_PITCH + 1] & hmask;
-        return __builtin_bit_cast(bf16x8, q);
+      auto frag1 = [=](int yp) {
+        const uint2 lo = *reinterpret_cast<const uint2*>(inb + yp * (IN_PITCH * 4));
+        const uint2 hi = *reinterpret_cast<const uint2*>(inb + (yp + 1) * (IN_PITCH * 4));
+        return __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
       };
-      // two accumulators in flight (no register copies): while one MFMA runs, the other unit is stored
-      f32x16 accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA1, frag1(wave), bias1, 0, 0, 0);
-#pragma unroll 1
-      for (int i = 0; i < 16; i += 2) {
-        const int ua = wave + 4 * i, ub = ua + 4, uc = min(ua + 8, 60 + wave);  // uc: next A unit (clamped, last is redundant)
-        const f32x16 accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA1, frag1(ub), bias1, 0, 0, 0);
-        conv1_store(accA, W.scale[0], lds, ua >> 1, ua & 1, r, h);
-        accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA1, frag1(uc), bias1, 0, 0, 0);
-        conv1_store(accB, W.scale[0], lds, ub >> 1, ub & 1, r, h);
+      unsigned char* a1dst = lds + R1_OFF + h * A1_PLANE + (A1_PITCH + r + 1) * 16;  // pooled row 0, column r (halo +1)
+      bf16x8 bq = frag1(wave);
+#pragma unroll 2
+      for (int i = 0; i < 8; ++i) {
+        const int yp = wave + 4 * i;
+        const f32x16 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA1a, bq, bias1, 0, 0, 0);
+        const f32x16 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA1b, bq, bias1, 0, 0, 0);
+        bq = frag1(min(yp + 4, 31));  // next unit's fragment travels during the epilogue (last one is redundant)
+        conv1_store(acc0, acc1, W.scale[0], a1dst + yp * (A1_PITCH * 16));
       }
     }
     __syncthreads();
