@@ -127,15 +127,19 @@ def main():
         gop = torch.stack([torch.roll(base, shifts=3 * (f + NF * rank), dims=1) for f in range(NF)]).to(torch.uint8).contiguous()
         luma_ptr = gop.data_ptr()
 
+    # every rank ends a step with the depth maps of the WHOLE GOP (all ranks' frames) in `gathered`; on the wire the
+    # maps travel as 4-byte split-flag words per CTU (64x less than 256 B) and are expanded on arrival
     gathered = torch.zeros((world, NF, n_ctus, 256), dtype=torch.uint8, device=dev)
+    flags = bands.alloc_flag_buffers(NF, n_ctus, world, dev)
     had = torch.zeros((NF, n_ctus), dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
         ctx.predict_frames_device(luma_ptr, args.sample_bytes, stride, frame_stride, NF, gathered[rank].data_ptr(),
-                                  had.data_ptr(), None, stream=stream)
+                                  had.data_ptr(), None, stream=stream, d_flags=flags[rank].data_ptr() if world > 1 else None)
         if world > 1:
-            dist.all_gather_into_tensor(gathered.view(-1), gathered[rank].view(-1))
+            bands.all_gather_flags(flags, rank)
+            ctx.expand_depth_flags_device(flags.data_ptr(), world * NF, gathered.data_ptr(), stream=stream)
 
     def fence():
         if world > 1:
@@ -184,7 +188,7 @@ def main():
                                    f"({'int16 Pel planes, HM stride/margins' if sample_b == 2 else 'uint8 planes'}) resident in HBM, "
                                    f"source Hadamard + CTU-batched CNN depth predictor, {wdesc}",
                        "frames_per_gpu": NF, "ctus_per_frame": n_ctus, "bit_depth": bd,
-                       "sharding": "frames dealt to ranks + one all-gather of the depth maps" if world > 1 else "single GPU"},
+                       "sharding": "frames dealt to ranks + one all-gather of the depth maps (as 4-byte split-flag words per CTU, expanded on every rank)" if world > 1 else "single GPU"},
             "roofline": roof, "roofline_hbm_kernel": hbm,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -46,3 +46,19 @@ def assemble(gathered, ctu_rows):
         parts.append(gathered[r, :, : e - b])
     full = torch.cat(parts, dim=1)
     return full.reshape(frames, ctu_rows * ctus_x, 256)
+
+
+def alloc_flag_buffers(num_frames, num_ctus, world, device):
+    """[world, frames, numCtus] int32 split-flag words (frames dealt to ranks): 4 B per CTU on the wire instead of the
+    256 B depth map; every rank expands the gathered words with fhevc_expand_depth_flags_device."""
+    return torch.zeros((world, num_frames, num_ctus), dtype=torch.int32, device=device)
+
+
+def all_gather_flags(gathered, rank, group=None):
+    world = gathered.shape[0]
+    if world == 1:
+        return gathered
+    flat = gathered.view(world, -1)
+    src = flat[rank].clone() if flat.device.type == "cpu" else flat[rank]
+    dist.all_gather_into_tensor(flat.view(-1), src, group=group)
+    return gathered

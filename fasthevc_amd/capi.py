@@ -22,6 +22,7 @@ SYMBOLS = [
     "fhevc_create", "fhevc_destroy", "fhevc_set_weights", "fhevc_predict_frame", "fhevc_satd",
     "fhevc_intra_first_pass", "fhevc_predict_frames_device", "fhevc_band", "fhevc_kernel_timing",
     "fhevc_enable_kernel_timing", "fhevc_get_stats", "fhevc_last_error", "fhevc_version",
+    "fhevc_expand_depth_flags_device",
 ]
 
 
@@ -71,7 +72,8 @@ def load_library():
     lib.fhevc_satd.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32)]
     lib.fhevc_intra_first_pass.argtypes = [vp, vp, C.c_int, C.c_int, vp]
     lib.fhevc_predict_frames_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_int,
-                                                C.c_int, vp, vp, vp, vp]
+                                                C.c_int, vp, vp, vp, vp, vp]
+    lib.fhevc_expand_depth_flags_device.argtypes = [vp, vp, C.c_int, vp, vp]
     lib.fhevc_band.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.fhevc_kernel_timing.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     lib.fhevc_enable_kernel_timing.argtypes = [vp, C.c_int]
@@ -152,11 +154,14 @@ class Context:
         return out.reshape(self.num_ctus, NODES_PER_CTU)
 
     def predict_frames_device(self, d_luma, sample_bytes, stride, frame_stride, num_frames, d_depth, d_hadamard=None,
-                              d_logits=None, rows=None, stream=None, qp=32):
+                              d_logits=None, rows=None, stream=None, qp=32, d_flags=None):
         """All pointers are raw device addresses (e.g. torch.Tensor.data_ptr()); asynchronous."""
         rb, re = rows if rows is not None else (0, self.ctus_y)
         self._check(self.lib.fhevc_predict_frames_device(self.h, d_luma, sample_bytes, stride, frame_stride, num_frames,
-                                                         rb, re, qp, d_depth, d_hadamard, d_logits, stream))
+                                                         rb, re, qp, d_depth, d_hadamard, d_logits, d_flags, stream))
+
+    def expand_depth_flags_device(self, d_flags, num_frames, d_depth, stream=None):
+        self._check(self.lib.fhevc_expand_depth_flags_device(self.h, d_flags, num_frames, d_depth, stream))
 
     def enable_kernel_timing(self, on=True):
         self._check(self.lib.fhevc_enable_kernel_timing(self.h, 1 if on else 0))

@@ -328,7 +328,7 @@ int fhevc_kernel_timing(fhevc_ctx* c, int which, int reset, double* avg_ms, uint
 
 int fhevc_predict_frames_device(fhevc_ctx* c, const void* d_luma, int sample_bytes, int stride_samples,
                                 long long frame_stride_samples, int num_frames, int ctu_row_begin, int ctu_row_end, int qp,
-                                uint8_t* d_depth_map, int32_t* d_hadamard, int32_t* d_logits, void* stream)
+                                uint8_t* d_depth_map, int32_t* d_hadamard, int32_t* d_logits, uint32_t* d_flags, void* stream)
 {
   if (!c || !d_luma || !d_depth_map) return FHEVC_E_INVALID;
   if (!c->have_weights) return fail(c, FHEVC_E_STATE, "weights not set");
@@ -346,11 +346,21 @@ int fhevc_predict_frames_device(fhevc_ctx* c, const void* d_luma, int sample_byt
     c->stats.kernels_launched++;
   }
   time_begin(c, s, 0);
-  HIP_TRY(c, fhevc_launch_cnn(fr, cnn_weights(c), d_depth_map, d_logits, c->num_cus, s));
+  HIP_TRY(c, fhevc_launch_cnn(fr, cnn_weights(c), d_depth_map, d_logits, d_flags, c->num_cus, s));
   time_end(c, s);
   c->stats.kernels_launched++;
   c->stats.frames += (uint64_t)num_frames;
   c->stats.ctus += (uint64_t)num_frames * (uint64_t)(ctu_row_end - ctu_row_begin) * (uint64_t)c->ctus_x;
+  return FHEVC_OK;
+}
+
+int fhevc_expand_depth_flags_device(fhevc_ctx* c, const uint32_t* d_flags, int num_frames, uint8_t* d_depth_map, void* stream)
+{
+  if (!c || !d_flags || !d_depth_map || num_frames < 1) return FHEVC_E_INVALID;
+  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
+  const FhevcFrames fr = frames_of(c, nullptr, 1, c->cfg.width, 0, num_frames, 0, c->ctus_y);
+  HIP_TRY(c, fhevc_launch_expand_flags(fr, d_flags, d_depth_map, s));
+  c->stats.kernels_launched++;
   return FHEVC_OK;
 }
 
@@ -375,7 +385,7 @@ int fhevc_predict_frame(fhevc_ctx* c, const int16_t* luma, int stride_samples, i
   int rc = upload_frame(c, luma, stride_samples);
   if (rc != FHEVC_OK) return rc;
   rc = fhevc_predict_frames_device(c, c->d_luma, 2, c->dev_stride, 0, 1, 0, c->ctus_y, qp, c->d_depth,
-                                   ctu_src_hadamard ? c->d_had : nullptr, nullptr, c->stream);
+                                   ctu_src_hadamard ? c->d_had : nullptr, nullptr, nullptr, c->stream);
   if (rc != FHEVC_OK) return rc;
   HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
   HIP_TRY(c, hipMemcpyAsync(depth_map, c->d_depth, (size_t)c->num_ctus * 256, hipMemcpyDeviceToHost, c->stream));

@@ -37,7 +37,8 @@ struct FhevcCnnWeights {
 };
 
 hipError_t fhevc_launch_cnn(const FhevcFrames& fr, const FhevcCnnWeights& w, uint8_t* d_depth, int32_t* d_logits,
-                            int num_cus, hipStream_t stream);
+                            uint32_t* d_flags, int num_cus, hipStream_t stream);
+hipError_t fhevc_launch_expand_flags(const FhevcFrames& fr, const uint32_t* d_flags, uint8_t* d_depth, hipStream_t stream);
 
 hipError_t fhevc_launch_cnn_stamped(const FhevcFrames& fr, const FhevcCnnWeights& w, uint8_t* d_depth, int num_cus,
                                     unsigned long long* d_stamps, int* grid_out, hipStream_t stream);

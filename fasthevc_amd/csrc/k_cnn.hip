@@ -36,7 +36,8 @@ constexpr int R1_BYTES = 2 * A1_PLANE;            // 36992
 constexpr int A3_OFF = R1_OFF;
 constexpr int P3_OFF = R1_OFF + 16384;            // maxpool2x2(a3): [8*8][64] u8
 constexpr int A2_PITCH = 18;                      // conv2 output 16x16 + halo
-constexpr int A2_PLANE = 18 * 18 * 16;            // 5184
+constexpr int A2_PLANE = 18 * 18 * 16 + 96;       // 5280: planes start 32 B apart modulo 128 B, so the paired 8-byte
+                                                  // stores of conv2 (even lane -> plane g, odd lane -> plane g+2) never share a bank
 constexpr int R2_OFF = R1_OFF + R1_BYTES;         // R2: input CTU bf16 [66][68]; later A2 (4 planes)
 constexpr int R2_BYTES = 4 * A2_PLANE;            // 20736
 constexpr int IN_PITCH = 68;                      // dwords per input row PAIR (66 used): lo = row 2j, hi = row 2j+1
@@ -252,6 +253,69 @@ __device__ __forceinline__ Prefetched prefetch_ctu(const FhevcFrames& F, int wk,
   return p;
 }
 
+// Stage one CTU into LDS (region R2): centred 8-bit samples as bf16, two picture rows per dword, zero halo.
+// halo coordinates: hy = row + 1, hx = col + 1; dword (hy >> 1) * IN_PITCH + hx, half (hy & 1)
+__device__ __forceinline__ void stage_ctu(unsigned char* lds, const Prefetched& pre, const FhevcFrames& F, int wk,
+                                          int per_frame, int tid, int ld_row, int ld_seg, int shift_in)
+{
+  unsigned short* inh = reinterpret_cast<unsigned short*>(lds + R2_OFF);
+  const int hy = ld_row + 1;
+  unsigned short* dst = inh + 2 * ((hy >> 1) * IN_PITCH + ld_seg * 16 + 1) + (hy & 1);
+  if (pre.fast) {
+    if (F.sample_bytes == 2) {
+      const unsigned wds[8] = { pre.a.x, pre.a.y, pre.a.z, pre.a.w, pre.b.x, pre.b.y, pre.b.z, pre.b.w };
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        short s0 = (short)(wds[j] & 0xFFFF), s1 = (short)(wds[j] >> 16);
+        dst[4 * j] = (unsigned short)(__float_as_uint((float)load_centered(&s0, shift_in)) >> 16);
+        dst[4 * j + 2] = (unsigned short)(__float_as_uint((float)load_centered(&s1, shift_in)) >> 16);
+      }
+    } else {
+      const unsigned wds[4] = { pre.a.x, pre.a.y, pre.a.z, pre.a.w };
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int v = (int)((wds[j >> 2] >> (8 * (j & 3))) & 0xFF) - 128;
+        dst[2 * j] = (unsigned short)(__float_as_uint((float)v) >> 16);
+      }
+    }
+  } else {  // picture edge or unaligned plane: guarded scalar loads
+    const int f = wk / per_frame, rem = wk - f * per_frame;
+    const int cy = F.row_begin + rem / F.ctus_x, cx = rem % F.ctus_x;
+    const int py = cy * 64 + ld_row, px0 = cx * 64 + ld_seg * 16;
+    const long long base = (long long)f * F.frame_stride + (long long)py * F.stride + px0;
+    const bool row_ok = py < F.height;
+#pragma unroll 4
+    for (int j = 0; j < 16; ++j) {
+      int v = 0;
+      if (row_ok && px0 + j < F.width) {
+        if (F.sample_bytes == 2) v = load_centered(reinterpret_cast<const int16_t*>(F.luma) + base + j, shift_in);
+        else v = (int)reinterpret_cast<const uint8_t*>(F.luma)[base + j] - 128;
+      }
+      dst[2 * j] = (unsigned short)(__float_as_uint((float)v) >> 16);
+    }
+  }
+  // input halo: 66*66 - 64*64 = 260 positions
+  for (int e = tid; e < 260; e += 256) {
+    int y, x;
+    if (e < 66) { y = 0; x = e; }
+    else if (e < 132) { y = 65; x = e - 66; }
+    else { const int k = e - 132; y = 1 + (k >> 1); x = (k & 1) ? 65 : 0; }
+    inh[2 * ((y >> 1) * IN_PITCH + x) + (y & 1)] = 0;
+  }
+}
+// zero the halo of the conv1 output planes (region R1, shared with the conv3 output): 132 positions x 2 planes
+__device__ __forceinline__ void zero_a1_halo(unsigned char* lds, int tid)
+{
+  for (int e = tid; e < 264; e += 256) {
+    const int pl = e / 132, k0 = e - pl * 132;
+    int y, x;
+    if (k0 < 34) { y = 0; x = k0; }
+    else if (k0 < 68) { y = 33; x = k0 - 34; }
+    else { const int k = k0 - 68; y = 1 + (k >> 1); x = (k & 1) ? 33 : 0; }
+    *reinterpret_cast<uint4*>(lds + R1_OFF + pl * A1_PLANE + (y * A1_PITCH + x) * 16) = make_uint4(0, 0, 0, 0);
+  }
+}
+
 // in-kernel stamp (diagnostic build only): s_memtime with its own lgkmcnt wait, fenced against reordering
 __device__ __forceinline__ unsigned long long stamp()
 {
@@ -268,6 +332,7 @@ template <bool STAMPS>
 __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, FhevcCnnWeights W,
                                                                   uint8_t* __restrict__ d_depth,
                                                                   int32_t* __restrict__ d_logits,
+                                                                  uint32_t* __restrict__ d_flags,
                                                                   unsigned long long* __restrict__ d_stamps)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -319,78 +384,25 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
   // this thread's 16 samples of a CTU: picture row (tid >> 2), columns 16 * (tid & 3) ..
   const int ld_row = tid >> 2, ld_seg = tid & 3;
   Prefetched pre = prefetch_ctu(F, blockIdx.x, total, per_frame, ld_row, ld_seg);
+  if ((int)blockIdx.x < total) {  // prologue: first CTU of this workgroup
+    stage_ctu(lds, pre, F, blockIdx.x, per_frame, tid, ld_row, ld_seg, shift_in);
+    zero_a1_halo(lds, tid);
+  }
+  __syncthreads();
+  FHEVC_STAMP(0)
 
+  // Per CTU: P1 conv1 | P2 conv2 | P3 conv3 (next CTU's samples are requested) | P4 heads + next CTU staged into LDS |
+  // P5 depth map + conv1 halo re-zeroed -- four barriers; P5 runs into the next P1 without one (disjoint LDS).
   for (int work = blockIdx.x; work < total; work += gridDim.x) {
     const int f = work / per_frame;
     const int rem = work - f * per_frame;
     const int cy = F.row_begin + rem / F.ctus_x;
     const int cx = rem % F.ctus_x;
 
-    // ====== P0: CTU -> LDS: centred 8-bit samples as bf16, two picture rows per dword, halo 0; zero the A1 halo ======
-    {
-      // halo coordinates: hy = row + 1, hx = col + 1; dword (hy >> 1) * IN_PITCH + hx, half (hy & 1)
-      unsigned short* inh = reinterpret_cast<unsigned short*>(lds + R2_OFF);
-      const int hy = ld_row + 1;
-      unsigned short* dst = inh + 2 * ((hy >> 1) * IN_PITCH + ld_seg * 16 + 1) + (hy & 1);
-      if (pre.fast) {
-        if (F.sample_bytes == 2) {
-          const unsigned wds[8] = { pre.a.x, pre.a.y, pre.a.z, pre.a.w, pre.b.x, pre.b.y, pre.b.z, pre.b.w };
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            short s0 = (short)(wds[j] & 0xFFFF), s1 = (short)(wds[j] >> 16);
-            dst[4 * j] = (unsigned short)(__float_as_uint((float)load_centered(&s0, shift_in)) >> 16);
-            dst[4 * j + 2] = (unsigned short)(__float_as_uint((float)load_centered(&s1, shift_in)) >> 16);
-          }
-        } else {
-          const unsigned wds[4] = { pre.a.x, pre.a.y, pre.a.z, pre.a.w };
-#pragma unroll
-          for (int j = 0; j < 16; ++j) {
-            const int v = (int)((wds[j >> 2] >> (8 * (j & 3))) & 0xFF) - 128;
-            dst[2 * j] = (unsigned short)(__float_as_uint((float)v) >> 16);
-          }
-        }
-      } else {  // picture edge or unaligned plane: guarded scalar loads
-        const int py = cy * 64 + ld_row, px0 = cx * 64 + ld_seg * 16;
-        const long long base = (long long)f * F.frame_stride + (long long)py * F.stride + px0;
-        const bool row_ok = py < F.height;
-#pragma unroll 4
-        for (int j = 0; j < 16; ++j) {
-          int v = 0;
-          if (row_ok && px0 + j < F.width) {
-            if (F.sample_bytes == 2) v = load_centered(reinterpret_cast<const int16_t*>(F.luma) + base + j, shift_in);
-            else v = (int)reinterpret_cast<const uint8_t*>(F.luma)[base + j] - 128;
-          }
-          dst[2 * j] = (unsigned short)(__float_as_uint((float)v) >> 16);
-        }
-      }
-      // input halo: 66*66 - 64*64 = 260 positions
-      for (int e = tid; e < 260; e += 256) {
-        int y, x;
-        if (e < 66) { y = 0; x = e; }
-        else if (e < 132) { y = 65; x = e - 66; }
-        else { const int k = e - 132; y = 1 + (k >> 1); x = (k & 1) ? 65 : 0; }
-        inh[2 * ((y >> 1) * IN_PITCH + x) + (y & 1)] = 0;
-      }
-      // A1 halo: 132 positions x 2 planes
-      for (int e = tid; e < 264; e += 256) {
-        const int pl = e / 132, k0 = e - pl * 132;
-        int y, x;
-        if (k0 < 34) { y = 0; x = k0; }
-        else if (k0 < 68) { y = 33; x = k0 - 34; }
-        else { const int k = k0 - 68; y = 1 + (k >> 1); x = (k & 1) ? 33 : 0; }
-        *reinterpret_cast<uint4*>(lds + R1_OFF + pl * A1_PLANE + (y * A1_PITCH + x) * 16) = make_uint4(0, 0, 0, 0);
-      }
-    }
-    __syncthreads();
-    FHEVC_STAMP(0)
+    // (the samples of this CTU were staged into LDS during the previous iteration's P4, or by the prologue)
 
     // ====== P1: conv1 (1 -> 16): one MFMA per 32 positions x 2 rows, K = 4x3 window, fused maxpool + requant ======
     {
-      if (tid < 42) {  // logits start from the head biases
-        const int k = tid >> 1, cls = tid & 1;
-        const int lvl = k == 0 ? 0 : (k < 5 ? 1 : 2);
-        logitL[tid] = W.bhead[2 * lvl + cls] + (cls ? W.bhead[6 + lvl * 52 + F.qp] : 0);  // head bias + QP prior on "split"
-      }
       // unit = one pooled row of 32 positions (picture rows 2yp, 2yp+1, all 64 columns); lane (n, h): pooled column n,
       // K slots = the 4x4 input window of the 2x2 pre-pool outputs: lanes h=0 hold window columns 0-1, h=1 columns 2-3,
       // each column as two row-pair dwords -> the fragment is two ds_read_b64, all 16 K slots carry data
@@ -425,6 +437,11 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
 
     // ================= P2: conv2 (16 -> 32), K = 9 taps x 16 ch, fused maxpool + requant =================
     {
+      if (tid < 42) {  // logits start from the head biases (the previous CTU's logits were consumed before the P1 barrier)
+        const int k = tid >> 1, cls = tid & 1;
+        const int lvl = k == 0 ? 0 : (k < 5 ? 1 : 2);
+        logitL[tid] = W.bhead[2 * lvl + cls] + (cls ? W.bhead[6 + lvl * 52 + F.qp] : 0);  // head bias + QP prior on "split"
+      }
       // the input tile is dead: zero the A2 halo (68 positions x 4 planes) while conv2 fills the interior
       for (int e = tid; e < 272; e += 256) {
         const int pl = e / 68, k0 = e - pl * 68;
@@ -456,7 +473,9 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
 
     // ================= P3: conv3 (32 -> 64), K = 9 taps x 32 ch, requant to u8 =================
     {
-      const int yy = r >> 4, x = r & 15;
+      // column rotation of the second row: with an 18-position (288 B) row pitch the 16 lanes of every ds_read_b128
+      // group then cover 16 distinct 16-byte slots modulo 256 B
+      const int yy = r >> 4, x = yy ? ((r - 2) & 15) : (r & 15);
       const float* bias3 = biasL + 48 + 32 * tile3;
       const unsigned char* a2 = lds + R2_OFF + h * A2_PLANE + (yy * A2_PITCH + x) * 16;
       // a3 row of a position p = 64 B = four 16-B chunks; chunk c is stored at c ^ ((p >> 2) & 3) so that the 16
@@ -481,7 +500,7 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
     FHEVC_STAMP(3)
 
     // ================= P4: FC heads on v_dot4_u32_u8 (weights stored as w+128, resident in LDS) =================
-    pre = prefetch_ctu(F, work + gridDim.x, total, per_frame, ld_row, ld_seg);  // travels while the heads run
+    pre = prefetch_ctu(F, work + gridDim.x, total, per_frame, ld_row, ld_seg);  // next CTU's samples travel under the heads
     {
       // wave = 32x32 quadrant q; 16-lane DPP row = one 16x16 block of it; lane bits [1:0] = x & 3, [3:2] = y & 3
       const int q = wave, blk = lane >> 4;
@@ -534,6 +553,8 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
         atomicAdd(&logitL[1], q64b);
       }
     }
+    // the A2/input region (R2) is free since the P3 barrier: stage the next CTU now, its P1 needs no extra barrier
+    if (work + (int)gridDim.x < total) stage_ctu(lds, pre, F, work + gridDim.x, per_frame, tid, ld_row, ld_seg, shift_in);
     __syncthreads();
     FHEVC_STAMP(4)
 
@@ -552,10 +573,30 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
       const long long o = (long long)(f * band_rows + (cy - F.row_begin)) * F.ctus_x + cx;
       d_depth[o * 256 + tid] = (uint8_t)d;
       if (d_logits != nullptr && tid < 42) d_logits[o * 42 + tid] = logitL[tid];
+      if (d_flags != nullptr && wave == 0) {  // the 21 decisions as one word: lane k < 21 evaluates node k
+        const int k = lane;
+        const int bi = k - 5, qq = k < 5 ? k - 1 : (bi >> 3) * 2 + ((bi >> 1) & 1);  // own / parent quadrant
+        const int qx = (qq & 1) * 32, qy = (qq >> 1) * 32, bxx = (bi & 3) * 16, byy = (bi >> 2) * 16;
+        const int2 a64 = *reinterpret_cast<const int2*>(logitL);
+        const bool n64 = (vw < 64) || (vh < 64) || (a64.y > a64.x);
+        bool bit = n64;
+        if (k >= 1 && k < 21) {
+          const int2 a32 = *reinterpret_cast<const int2*>(logitL + 2 * (1 + qq));
+          const bool n32 = n64 && (qx < vw) && (qy < vh) && ((qx + 32 > vw) || (qy + 32 > vh) || (a32.y > a32.x));
+          bit = n32;
+          if (k >= 5) {
+            const int2 a16 = *reinterpret_cast<const int2*>(logitL + 2 * k);
+            bit = n32 && (bxx < vw) && (byy < vh) && ((bxx + 16 > vw) || (byy + 16 > vh) || (a16.y > a16.x));
+          }
+        }
+        const unsigned long long m = __ballot(bit && k < 21);
+        if (lane == 0) d_flags[o] = (uint32_t)(m & 0x1FFFFFu);
+      }
+      zero_a1_halo(lds, tid);  // R1 held the conv3 output until the P4 barrier; conv1 of the next CTU needs a zero halo
     }
     FHEVC_STAMP(5)
-    // no barrier needed here: the next iteration's first LDS writes (P0) touch R1/R2, last read before the
-    // P4 barrier, and the logits are re-initialised only after the P0 barrier.
+    // no barrier here: the next P1 reads R2 (staged before the P4 barrier) and writes the A1 interior (R1, last read
+    // before the P4 barrier, halo rewritten above by disjoint addresses); the logits are re-initialised in P2.
   }
   if (STAMPS && tid == 0) {
     for (int k = 0; k < 6; ++k) d_stamps[blockIdx.x * 8 + k] = tsum[k];
@@ -563,10 +604,38 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
 #undef FHEVC_STAMP
 }
 
+// split-flag words -> depth maps (whole pictures, CTU raster order): one thread per 4x4 unit, 256 B per CTU written
+__global__ __launch_bounds__(256) void fhevc_expand_flags_kernel(FhevcFrames F, const uint32_t* __restrict__ flags,
+                                                                  uint8_t* __restrict__ depth)
+{
+  const int per_frame = F.ctus_x * F.ctus_y, total = per_frame * F.num_frames;
+  const int tid = threadIdx.x, ux = tid & 15, uy = tid >> 4;
+  for (int c = blockIdx.x; c < total; c += gridDim.x) {
+    const int rem = c % per_frame, cy = rem / F.ctus_x, cx = rem % F.ctus_x;
+    const int vw = min(64, F.width - cx * 64), vh = min(64, F.height - cy * 64);
+    const uint32_t w = flags[c];
+    int d = 0;
+    if (ux * 4 < vw && uy * 4 < vh && (w & 1u)) {
+      const int q = (uy >> 3) * 2 + (ux >> 3), bi = (uy >> 2) * 4 + (ux >> 2);
+      d = ((w >> (1 + q)) & 1u) ? (((w >> (5 + bi)) & 1u) ? 3 : 2) : 1;
+    }
+    depth[(long long)c * 256 + tid] = (uint8_t)d;
+  }
+}
+
 }  // namespace
 
+hipError_t fhevc_launch_expand_flags(const FhevcFrames& fr, const uint32_t* d_flags, uint8_t* d_depth, hipStream_t stream)
+{
+  const long long total = (long long)fr.ctus_x * fr.ctus_y * fr.num_frames;
+  if (total <= 0) return hipSuccess;
+  const int grid = (int)(total < 8192 ? total : 8192);
+  hipLaunchKernelGGL(fhevc_expand_flags_kernel, dim3(grid), dim3(256), 0, stream, fr, d_flags, d_depth);
+  return hipGetLastError();
+}
+
 hipError_t fhevc_launch_cnn(const FhevcFrames& fr, const FhevcCnnWeights& w, uint8_t* d_depth, int32_t* d_logits,
-                            int num_cus, hipStream_t stream)
+                            uint32_t* d_flags, int num_cus, hipStream_t stream)
 {
   const long long total = (long long)(fr.row_end - fr.row_begin) * fr.ctus_x * fr.num_frames;
   if (total <= 0) return hipSuccess;
@@ -580,7 +649,7 @@ hipError_t fhevc_launch_cnn(const FhevcFrames& fr, const FhevcCnnWeights& w, uin
     attr_set = true;
   }
   hipLaunchKernelGGL(fhevc_cnn_depth_kernel<false>, dim3(grid), dim3(256), LDS_BYTES, stream, fr, w, d_depth, d_logits,
-                     (unsigned long long*)nullptr);
+                     d_flags, (unsigned long long*)nullptr);
   return hipGetLastError();
 }
 
@@ -596,6 +665,7 @@ hipError_t fhevc_launch_cnn_stamped(const FhevcFrames& fr, const FhevcCnnWeights
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_kernel<true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(fhevc_cnn_depth_kernel<true>, dim3(grid), dim3(256), LDS_BYTES, stream, fr, w, d_depth, (int32_t*)nullptr, d_stamps);
+  hipLaunchKernelGGL(fhevc_cnn_depth_kernel<true>, dim3(grid), dim3(256), LDS_BYTES, stream, fr, w, d_depth, (int32_t*)nullptr,
+                     (uint32_t*)nullptr, d_stamps);
   return hipGetLastError();
 }

@@ -102,11 +102,18 @@ int  fhevc_intra_first_pass(fhevc_ctx* ctx, const int16_t* luma, int stride_samp
 /* Device-resident batch: num_frames pictures already in HBM, CTU rows [ctu_row_begin, ctu_row_end) of each.
  * d_luma: sample_bytes = 2 -> int16 Pel plane(s) as HM lays them out, 1 -> uint8 (8-bit content);
  * frame f starts at d_luma + f * frame_stride_samples.  Outputs are device pointers, compact over the band:
- * entry ((f * band_rows + (row - ctu_row_begin)) * ctus_per_row + col).  d_hadamard / d_logits may be NULL.
+ * entry ((f * band_rows + (row - ctu_row_begin)) * ctus_per_row + col).  d_hadamard / d_logits / d_flags may be NULL.
  * stream: hipStream_t (NULL = the context's stream).  Asynchronous with respect to the host. */
 int  fhevc_predict_frames_device(fhevc_ctx* ctx, const void* d_luma, int sample_bytes, int stride_samples,
                                  long long frame_stride_samples, int num_frames, int ctu_row_begin, int ctu_row_end,
-                                 int qp, uint8_t* d_depth_map, int32_t* d_hadamard, int32_t* d_logits, void* stream);
+                                 int qp, uint8_t* d_depth_map, int32_t* d_hadamard, int32_t* d_logits, uint32_t* d_flags,
+                                 void* stream);
+
+/* The 21 split decisions of a CTU as one word (bit 0 = 64x64, bits 1..4 = 32x32 quadrants, bits 5..20 = 16x16
+ * blocks; set only under split parents, forced splits at the picture edge included): the optional d_flags output
+ * above, 4 bytes per CTU instead of 256 -- what the ranks of a node all-gather.  This call expands gathered words
+ * back into depth maps on the device: num_frames * numCtus words, whole pictures in CTU raster order. */
+int  fhevc_expand_depth_flags_device(fhevc_ctx* ctx, const uint32_t* d_flags, int num_frames, uint8_t* d_depth_map, void* stream);
 
 /* CTU-row band of rank `rank` out of `world`: rows [begin, end) */
 int  fhevc_band(int ctu_rows, int rank, int world, int* begin, int* end);

@@ -592,6 +592,42 @@ void fho_depth_from_logits(const int32_t logits[21][2], int vw, int vh, uint8_t 
   }
 }
 
+uint32_t fho_flags_from_logits(const int32_t logits[21][2], int vw, int vh)
+{
+  uint32_t f = 0;
+  const int s64 = (vw < 64 || vh < 64) ? 1 : is_split(logits[0]);
+  if (!s64) return 0;
+  f |= 1u;
+  for (int q = 0; q < 4; q++) {
+    const int qx = (q & 1) * 32, qy = (q >> 1) * 32;
+    if (qx >= vw || qy >= vh) continue;
+    const int cross = (qx + 32 > vw) || (qy + 32 > vh);
+    if (!(cross || is_split(logits[1 + q]))) continue;
+    f |= 1u << (1 + q);
+    for (int b = 0; b < 4; b++) {
+      const int bx = qx + (b & 1) * 16, by = qy + (b >> 1) * 16;
+      if (bx >= vw || by >= vh) continue;
+      const int c16 = (bx + 16 > vw) || (by + 16 > vh);
+      const int bi = (by / 16) * 4 + bx / 16;
+      if (c16 || is_split(logits[5 + bi])) f |= 1u << (5 + bi);
+    }
+  }
+  return f;
+}
+
+void fho_depth_from_flags(uint32_t flags, int vw, int vh, uint8_t depth[256])
+{
+  for (int uy = 0; uy < 16; uy++)
+    for (int ux = 0; ux < 16; ux++) {
+      int d = 0;
+      if (ux * 4 < vw && uy * 4 < vh && (flags & 1u)) {
+        const int q = (uy >> 3) * 2 + (ux >> 3), bi = (uy >> 2) * 4 + (ux >> 2);
+        d = ((flags >> (1 + q)) & 1u) ? (((flags >> (5 + bi)) & 1u) ? 3 : 2) : 1;
+      }
+      depth[uy * 16 + ux] = (uint8_t)d;
+    }
+}
+
 void fho_load_ctu(const int16_t* luma, int stride, int width, int height, int ctu_x, int ctu_y,
                   int bit_depth, int8_t ctu[64 * 64])
 {

@@ -122,6 +122,12 @@ void fho_cnn_ctu_debug(const fho_weights* w, const int8_t* ctu, int qp, uint8_t*
 /* logits -> raster 16x16 depth map.  valid_w/valid_h = in-picture part of the CTU; nodes crossing
  * the picture edge are forced to split (TEncCu.cpp:574,894 bBoundary); units outside get 0. */
 void fho_depth_from_logits(const int32_t logits[21][2], int valid_w, int valid_h, uint8_t depth_raster[256]);
+/* The same decisions as one 21-bit word per CTU: bit 0 = 64x64 split, bits 1..4 = 32x32 quadrants (raster),
+ * bits 5..20 = 16x16 blocks (raster); a bit is set only under split parents and inside the picture (forced
+ * splits at the picture edge included).  This is the reference's pre-order split-flag serialisation
+ * (TComSysuCuMDTools.cpp:16-38) in fixed positions; 4 bytes instead of 256 for the multi-GPU all-gather. */
+uint32_t fho_flags_from_logits(const int32_t logits[21][2], int valid_w, int valid_h);
+void fho_depth_from_flags(uint32_t flags, int valid_w, int valid_h, uint8_t depth_raster[256]);
 /* gather + centre one CTU from the frame (8- or 10-bit Pel) */
 void fho_load_ctu(const int16_t* luma, int stride, int width, int height, int ctu_x, int ctu_y,
                   int bit_depth, int8_t ctu[64 * 64]);

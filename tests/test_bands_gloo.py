@@ -41,6 +41,23 @@ def _worker(rank, world, port, q):
     bands.all_gather_depth(gathered, rank)
     out = bands.assemble(gathered, ch).numpy()
     ok = all(np.array_equal(out[f], full[f]) for f in range(NF))
+    # the bench's variant: frames dealt to ranks, 4-byte split-flag words on the wire, expanded on arrival
+    flags = bands.alloc_flag_buffers(1, cw * ch, world, "cpu")
+    buf, org, stride = frames.to_pel_plane(frames.texture16_luma(W, H, seed=50 + rank), 8)  # rank r owns frame r
+    logits = np.zeros(cw * ch * 42, np.int32)
+    depth = np.zeros(cw * ch * 256, np.uint8)
+    import ctypes as C
+    oracle.fho_predict_frame(ws, op.ptr(buf.reshape(-1), org), stride, W, H, 8, 32, depth, C.c_void_p(logits.ctypes.data))
+    for c in range(cw * ch):
+        vw, vh = min(64, W - (c % cw) * 64), min(64, H - (c // cw) * 64)
+        flags[rank, 0, c] = int(oracle.fho_flags_from_logits(np.ascontiguousarray(logits[c * 42:(c + 1) * 42]), vw, vh))
+    bands.all_gather_flags(flags, rank)
+    for r in range(world):
+        for c in range(cw * ch):
+            vw, vh = min(64, W - (c % cw) * 64), min(64, H - (c // cw) * 64)
+            d = np.zeros(256, np.uint8)
+            oracle.fho_depth_from_flags(int(flags[r, 0, c]), vw, vh, d)
+            ok = ok and np.array_equal(d, full[r][c])
     q.put((rank, ok))
     dist.barrier()
     dist.destroy_process_group()

@@ -104,8 +104,18 @@ def test_device_batch_logits_and_bands(oracle, torch_cuda):
     depth = torch.zeros((NF, n, 256), dtype=torch.uint8, device=dev)
     had = torch.zeros((NF, n), dtype=torch.int32, device=dev)
     logits = torch.zeros((NF, n, 42), dtype=torch.int32, device=dev)
-    ctx.predict_frames_device(d8.data_ptr(), 1, W, W * H, NF, depth.data_ptr(), had.data_ptr(), logits.data_ptr(), qp=37)
+    flags = torch.zeros((NF, n), dtype=torch.int32, device=dev)
+    ctx.predict_frames_device(d8.data_ptr(), 1, W, W * H, NF, depth.data_ptr(), had.data_ptr(), logits.data_ptr(), qp=37,
+                              d_flags=flags.data_ptr())
+    expanded = torch.full((NF, n, 256), 9, dtype=torch.uint8, device=dev)
+    ctx.expand_depth_flags_device(flags.data_ptr(), NF, expanded.data_ptr())
     torch.cuda.synchronize()
+    assert torch.equal(expanded, depth)  # the 4-byte word per CTU carries the whole map (multi-GPU all-gather payload)
+    for f in range(NF):
+        lg = refs[f][4].reshape(n, 21, 2)
+        for c in range(n):
+            vw, vh = min(64, W - (c % ctx.ctus_x) * 64), min(64, H - (c // ctx.ctus_x) * 64)
+            assert int(flags[f, c].item()) == oracle.fho_flags_from_logits(np.ascontiguousarray(lg[c].reshape(-1)), vw, vh)
     for f in range(NF):
         assert np.array_equal(depth[f].cpu().numpy(), refs[f][3])
         assert np.array_equal(logits[f].cpu().numpy(), refs[f][4])

@@ -106,3 +106,18 @@ def test_predict_frame_edge_ctus(oracle):
     assert (depth[3, :, 12:, :] == 0).all()    # last CTU row is 48 px tall
     assert (depth[3, :6, 8:12, :] >= 2).all()  # 32x32 blocks crossing the bottom edge are split
     assert (depth[:3, 6, :, :8] >= 1).all()    # CTUs crossing the right edge are split at 64
+
+
+def test_split_flag_word_equals_depth_map(oracle):
+    """The 21-bit word (what the ranks all-gather) carries exactly the depth map, picture edges included."""
+    rng = np.random.default_rng(9)
+    for _ in range(400):
+        lg = rng.integers(-5, 6, size=(21, 2)).astype(np.int32)
+        vw, vh = int(rng.choice([64, 64, 64, 56, 48, 32, 16, 8])), int(rng.choice([64, 64, 64, 56, 48, 40, 24, 8]))
+        d_ref = np.zeros(256, np.uint8)
+        oracle.fho_depth_from_logits(lg.reshape(-1), vw, vh, d_ref)
+        word = oracle.fho_flags_from_logits(lg.reshape(-1), vw, vh)
+        assert word < (1 << 21)
+        d = np.zeros(256, np.uint8)
+        oracle.fho_depth_from_flags(word, vw, vh, d)
+        assert np.array_equal(d, d_ref), (vw, vh, hex(word))

@@ -22,7 +22,7 @@ out = np.zeros(8, np.float64)
 for rep in range(3):
     rc = lib.fhevc_debug_cnn_phase_cycles(ctx.h, gop.data_ptr(), 1, W, W * H, NF, depth.data_ptr(), out.ctypes.data)
     assert rc == 0, rc
-names = ["P0 load", "P1 conv1", "P2 conv2", "P3 conv3", "P4 heads", "P5 depth"]
+names = ["prologue", "P1 conv1", "P2 conv2", "P3 conv3", "P4 heads+stage", "P5 depth"]
 per_ctu = out[:6] / out[6]
 tot = per_ctu.sum()
 print(f"grid {int(out[7])}, {out[6]:.1f} CTUs per workgroup, {tot:.0f} cycles per CTU per workgroup (wave 0, incl. barrier waits)")
