@@ -165,6 +165,18 @@ def main():
     had_ms, had_n = ctx.kernel_timing(1)
     ctx.enable_kernel_timing(False)
 
+    def measured_traffic(kernel):
+        """HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes,
+        FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) -- only for the workload they were taken on."""
+        path = os.path.join(ROOT, "profiles", "r01_pmc_bench_frames64_int16.json")
+        if not (os.path.exists(path) and NF == 64 and args.sample_bytes == 2 and (W, H) == (1920, 1080)):
+            return None
+        d = json.load(open(path))
+        for k, v in d.items():
+            if k.startswith(kernel) and "hbm_read_bytes_corrected" in v and "hbm_write_bytes" in v:
+                return v["hbm_read_bytes_corrected"] + v["hbm_write_bytes"]
+        return None
+
     if rank == 0:
         ctus_per_step = world * NF * n_ctus
         value = ctus_per_step * args.steps / dt
@@ -172,11 +184,11 @@ def main():
         sample_b = args.sample_bytes
         bytes_per_launch_had = NF * (W * H * sample_b + n_ctus * 4)
         roof = {"bound": "mfma", "kernel": "fhevc_cnn_depth_kernel", "achieved": flop_per_launch / (cnn_ms * 1e-3) / 1e12 if cnn_ms else None,
-                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "traffic": None,
+                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "traffic": measured_traffic("fhevc_cnn_depth_kernel"),
                 "avg_launch_ms": cnn_ms, "launches": cnn_n, "flop_per_ctu": FLOP_PER_CTU}
         roof["frac"] = roof["achieved"] / roof["peak"] if roof["achieved"] else None
         hbm = {"bound": "hbm", "kernel": "fhevc_src_hadamard_kernel", "achieved": bytes_per_launch_had / (had_ms * 1e-3) / 1e9 if had_ms else None,
-               "peak": PEAK_HBM_GBS, "unit": "GB/s", "traffic": None, "avg_launch_ms": had_ms, "launches": had_n,
+               "peak": PEAK_HBM_GBS, "unit": "GB/s", "traffic": measured_traffic("fhevc_src_hadamard_kernel"), "avg_launch_ms": had_ms, "launches": had_n,
                "bytes_per_launch": bytes_per_launch_had}
         hbm["frac"] = hbm["achieved"] / hbm["peak"] if hbm["achieved"] else None
         line = {

@@ -383,9 +383,12 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
 
   // this thread's 16 samples of a CTU: picture row (tid >> 2), columns 16 * (tid & 3) ..
   const int ld_row = tid >> 2, ld_seg = tid & 3;
-  Prefetched pre = prefetch_ctu(F, blockIdx.x, total, per_frame, ld_row, ld_seg);
-  if ((int)blockIdx.x < total) {  // prologue: first CTU of this workgroup
-    stage_ctu(lds, pre, F, blockIdx.x, per_frame, tid, ld_row, ld_seg, shift_in);
+  // XCD-aware order (speed only): blockIdx % 8 share an L2, give each XCD a contiguous run of CTUs per sweep so that the
+  // 128-byte lines shared by horizontally adjacent CTUs (HM's unaligned margins) are fetched into one L2, not two
+  const int vblock = (gridDim.x & 7) ? (int)blockIdx.x : (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));
+  Prefetched pre = prefetch_ctu(F, vblock, total, per_frame, ld_row, ld_seg);
+  if (vblock < total) {  // prologue: first CTU of this workgroup
+    stage_ctu(lds, pre, F, vblock, per_frame, tid, ld_row, ld_seg, shift_in);
     zero_a1_halo(lds, tid);
   }
   __syncthreads();
@@ -393,7 +396,7 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
 
   // Per CTU: P1 conv1 | P2 conv2 | P3 conv3 (next CTU's samples are requested) | P4 heads + next CTU staged into LDS |
   // P5 depth map + conv1 halo re-zeroed -- four barriers; P5 runs into the next P1 without one (disjoint LDS).
-  for (int work = blockIdx.x; work < total; work += gridDim.x) {
+  for (int work = vblock; work < total; work += gridDim.x) {
     const int f = work / per_frame;
     const int rem = work - f * per_frame;
     const int cy = F.row_begin + rem / F.ctus_x;

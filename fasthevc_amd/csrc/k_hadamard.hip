@@ -37,7 +37,11 @@ __global__ __launch_bounds__(256) void fhevc_src_hadamard_kernel(FhevcFrames F, 
   const int band_rows = F.row_end - F.row_begin;
   const int per_frame = band_rows * F.ctus_x;
   const int total = per_frame * F.num_frames;
-  for (int work = blockIdx.x * 4 + wave; work < total; work += gridDim.x * 4) {
+  // XCD-aware order: blocks are dealt round-robin to the 8 XCDs (blockIdx % 8 share an L2), so give every XCD a
+  // contiguous run of CTUs: horizontally adjacent CTUs share 128-byte lines when the plane is not 128-byte aligned
+  // (HM's 80-sample margin), and then the shared line is fetched into one L2 instead of two.  Speed only.
+  const int vblock = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);  // grid is a multiple of 8
+  for (int work = vblock * 4 + wave; work < total; work += gridDim.x * 4) {
     const int f = work / per_frame;
     const int rem = work - f * per_frame;
     const int cy = F.row_begin + rem / F.ctus_x, cx = rem % F.ctus_x;
@@ -147,7 +151,7 @@ hipError_t fhevc_launch_src_hadamard(const FhevcFrames& fr, int32_t* d_out, hipS
   const long long total = (long long)(fr.row_end - fr.row_begin) * fr.ctus_x * fr.num_frames;
   if (total <= 0) return hipSuccess;
   long long groups = (total + 3) / 4;
-  const int grid = (int)(groups < 4096 ? groups : 4096);
+  const int grid = (int)(((groups < 4096 ? groups : 4096) + 7) & ~7LL);  // multiple of 8: see the XCD remap in the kernel
   if (fr.sample_bytes == 2)
     hipLaunchKernelGGL(fhevc_src_hadamard_kernel<int16_t>, dim3(grid), dim3(256), 0, stream, fr, d_out);
   else

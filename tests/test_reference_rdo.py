@@ -56,3 +56,20 @@ def test_hook_with_own_depth_map_reproduces_full_rdo():
     # a wrong map costs RD: all-8x8 is clearly worse than the reference's choice
     _, s_bad = op.rdo_encode(hook, buf, org, stride, 768, 512, 8, 32, forced_depth=np.full_like(fx["depth"], 3))
     assert s_bad["rdcost"] > 1.05 * s_stock["rdcost"]
+
+
+def test_trained_weights_follow_the_reference_decisions(oracle):
+    """The shipped blob (fasthevc_amd/weights/depthnet_v1.fhw, trained on the reference's full-RDO labels) against the
+    committed reference depth map of a picture it never saw (pinned hetero content): most units get HM's depth."""
+    from fasthevc_amd import weights
+    path = os.path.join(ROOT, "fasthevc_amd", "weights", "depthnet_v1.fhw")
+    w = weights.load(path)
+    buf, org, stride = _crop()
+    pred = np.zeros(96 * 256, np.uint8)
+    oracle.fho_predict_frame(op.weights_from_arrays(w), op.ptr(buf.reshape(-1), org), stride, 768, 512, 8, 32, pred, None)
+    ref = np.load(FIX)["depth"].reshape(-1)
+    agree = float((pred == ref).mean())
+    mean_err = float(np.abs(pred.astype(int) - ref.astype(int)).mean())  # compareSplitMode / units (TComSysuCuMDTools.cpp:48-77)
+    assert agree > 0.80 and mean_err < 0.30, (agree, mean_err)
+    const = max(float((ref == c).mean()) for c in range(4))
+    assert agree > const + 0.15  # clearly better than any constant map
