@@ -37,7 +37,8 @@ def cpu_baseline(width, height, bit_depth, w, seconds=12.0):
         lib = op.bind_rdo(op.load_ref())
         cw_, ch_ = 768, 512  # crops of the picture: 96 CTUs each, about 1.5 s of full RDO
         done, spent, crops = 0, 0.0, 0
-        for (ox, oy) in ((0, 0), (768, 0), (1152, 0), (0, 512), (768, 512), (1152, 512), (384, 256), (960, 256)):
+        for (ox, oy) in ((0, 0), (768, 0), (1152, 0), (0, 512), (768, 512), (1152, 512), (384, 256), (960, 256),
+                         (192, 128), (576, 384), (1088, 64), (128, 448), (640, 192), (1024, 320)):
             if oy + ch_ > height or ox + cw_ > width:
                 continue
             buf, org, stride = frames.to_pel_plane(luma[oy:oy + ch_, ox:ox + cw_].copy(), bit_depth)
@@ -130,16 +131,17 @@ def main():
     # every rank ends a step with the depth maps of the WHOLE GOP (all ranks' frames) in `gathered`; on the wire the
     # maps travel as 4-byte split-flag words per CTU (64x less than 256 B) and are expanded on arrival
     gathered = torch.zeros((world, NF, n_ctus, 256), dtype=torch.uint8, device=dev)
-    flags = bands.alloc_flag_buffers(NF, n_ctus, world, dev)
+    flags_all = bands.alloc_flag_buffers(NF, n_ctus, world, dev)          # receive buffer of the all-gather
+    flags_mine = torch.zeros((NF, n_ctus), dtype=torch.int32, device=dev)  # this rank's words (send buffer)
     had = torch.zeros((NF, n_ctus), dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
         ctx.predict_frames_device(luma_ptr, args.sample_bytes, stride, frame_stride, NF, gathered[rank].data_ptr(),
-                                  had.data_ptr(), None, stream=stream, d_flags=flags[rank].data_ptr() if world > 1 else None)
+                                  had.data_ptr(), None, stream=stream, d_flags=flags_mine.data_ptr() if world > 1 else None)
         if world > 1:
-            bands.all_gather_flags(flags, rank)
-            ctx.expand_depth_flags_device(flags.data_ptr(), world * NF, gathered.data_ptr(), stream=stream)
+            dist.all_gather_into_tensor(flags_all.view(-1), flags_mine.view(-1))  # the path's only collective
+            ctx.expand_depth_flags_device(flags_all.data_ptr(), world * NF, gathered.data_ptr(), stream=stream)
 
     def fence():
         if world > 1:

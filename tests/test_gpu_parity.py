@@ -73,16 +73,18 @@ def test_predict_frame_416x240(oracle, golden, bd, seed, extreme):
     ctx.close()
 
 
-def test_predict_frame_1080p_hetero(oracle, golden):
-    """config 2 geometry, the heterogeneous content: 510 CTUs, last row 56 px tall."""
-    w = weights.random_weights(1)
+@pytest.mark.parametrize("which", ["random", "trained"])
+def test_predict_frame_1080p_hetero(oracle, golden, which):
+    """config 2 geometry, the heterogeneous content: 510 CTUs, last row 56 px tall; random-init and shipped weights."""
+    w = weights.random_weights(1) if which == "random" else weights.load(
+        os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fasthevc_amd", "weights", "depthnet_v1.fhw"))
     luma = frames.hetero_luma(1920, 1080)
     buf, org, stride, depth_ref, _, had_ref = _oracle_frame(oracle, w, luma, 8)
     ctx = capi.Context(1920, 1080, 8, w)
     depth, had = ctx.predict_frame(buf, org, stride)
     assert np.array_equal(had, had_ref)
     assert np.array_equal(depth, depth_ref)
-    assert len(np.unique(depth)) == 4  # all four depths occur, so the comparison is not vacuous
+    assert len(np.unique(depth)) >= 3  # several depths occur, so the comparison is not vacuous
     buf2, org2, stride2 = frames.to_pel_plane(frames.texture16_luma(1920, 1080), 8)
     _, had2 = ctx.predict_frame(buf2, org2, stride2)
     assert np.array_equal(had2, golden["ctu_had_t16_1920x1080_8"])
