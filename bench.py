@@ -35,6 +35,7 @@ def cpu_baseline(width, height, bit_depth, w, seconds=12.0):
     luma = frames.hetero_luma(width, height)
     if op.have_ref():
         lib = op.bind_rdo(op.load_ref())
+        cu, cv = frames.chroma_planes("hetero", width, height)
         cw_, ch_ = 768, 512  # crops of the picture: 96 CTUs each, about 1.5 s of full RDO
         done, spent, crops = 0, 0.0, 0
         for (ox, oy) in ((0, 0), (768, 0), (1152, 0), (0, 512), (768, 512), (1152, 512), (384, 256), (960, 256),
@@ -42,7 +43,8 @@ def cpu_baseline(width, height, bit_depth, w, seconds=12.0):
             if oy + ch_ > height or ox + cw_ > width:
                 continue
             buf, org, stride = frames.to_pel_plane(luma[oy:oy + ch_, ox:ox + cw_].copy(), bit_depth)
-            _, st = op.rdo_encode(lib, buf, org, stride, cw_, ch_, bit_depth, 32)
+            chroma = tuple((c[oy // 2:(oy + ch_) // 2, ox // 2:(ox + cw_) // 2].astype(np.int16) << (bit_depth - 8)) for c in (cu, cv))
+            _, st = op.rdo_encode(lib, buf, org, stride, cw_, ch_, bit_depth, 32, chroma=chroma)
             done += st["ctus"]
             spent += st["seconds"]
             crops += 1

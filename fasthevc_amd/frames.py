@@ -92,3 +92,14 @@ def to_pel_plane(luma_u8, internal_bit_depth=8, margin=HM_MARGIN):
     buf = np.zeros((h + 2 * margin, stride), np.int16)
     buf[margin:margin + h, margin:margin + w] = luma_u8.astype(np.int16) << (internal_bit_depth - 8)
     return buf, margin * stride + margin, stride
+
+
+def chroma_planes(kind, width, height):
+    """(U, V) uint8 planes [H/2, W/2] of the pinned generators: U = 128, V a horizontal sinusoid."""
+    _, xx = np.mgrid[0:height, 0:width]
+    u = np.full((height // 2, width // 2), 128, np.uint8)
+    if kind == "hetero":
+        v = np.clip(128 + 15 * np.sin(xx[::2, ::2].astype(np.float64) / 90.0), 0, 255).astype(np.uint8)
+    else:
+        v = np.clip(128 + 20 * np.sin(xx[::2, ::2] / 50.0), 0, 255).astype(np.uint8)
+    return u, v

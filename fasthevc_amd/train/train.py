@@ -7,7 +7,7 @@ weights are rounded to int8 in the forward pass (straight-through gradients), ac
 clamp(floor((acc + b) >> s), 0, 255).  What the trainer evaluates is therefore bit-for-bit what
 fasthevc_amd/csrc/k_cnn.hip and oracle/fhevc_oracle.c compute from the exported FHW1 blob.
 
-Labels (per full CTU, per QP) come from the reference's own full-RDO depth maps (fasthevc_amd/train/make_labels.py):
+Labels (per full CTU, per QP) come from the reference's own full-RDO depth maps (tests/quality/make_labels.py):
   s64 = depth(0,0) >= 1;  s32[q] = depth(quadrant origin) >= 2, counted only where s64;  s16[b] = depth(block origin)
   == 3, counted only where its quadrant is split -- the 32-level rule is the reference's isDiv = (Depth != 1) under
   Depth(CU0_0) != 0 (detectAndClassify32Cu.m:11-16, 57-62).

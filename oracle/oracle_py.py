@@ -167,12 +167,16 @@ def bind_rdo(lib):
     lib.href_rdo_encode_frame.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, _u8p,
                                           np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")]
     lib.href_rdo_encode_frame.restype = C.c_int
+    lib.href_rdo_encode_frame_yuv.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                              C.c_void_p, _u8p, np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")]
+    lib.href_rdo_encode_frame_yuv.restype = C.c_int
     lib.href_has_hook.restype = C.c_int
     return lib
 
 
-def rdo_encode(lib, plane, origin, stride, width, height, bit_depth, qp, forced_depth=None):
-    """-> (depth [numCtus,256] uint8, stats dict).  plane: int16 Pel buffer."""
+def rdo_encode(lib, plane, origin, stride, width, height, bit_depth, qp, forced_depth=None, chroma=None):
+    """-> (depth [numCtus,256] uint8, stats dict).  plane: int16 Pel buffer; chroma: optional (cb, cr) int16 arrays
+    [H/2, W/2] at the internal bit depth (default: flat mid-grey)."""
     n = ((width + 63) // 64) * ((height + 63) // 64)
     depth = np.zeros(n * 256, np.uint8)
     stats = np.zeros(8, np.float64)
@@ -180,8 +184,14 @@ def rdo_encode(lib, plane, origin, stride, width, height, bit_depth, qp, forced_
     if forced_depth is not None:
         fd = np.ascontiguousarray(forced_depth, np.uint8).reshape(-1)
         assert fd.size == n * 256
-    rc = lib.href_rdo_encode_frame(ptr(plane.reshape(-1), origin), stride, width, height, bit_depth, qp,
-                                   C.c_void_p(fd.ctypes.data) if fd is not None else None, depth, stats)
+    if chroma is not None:
+        cb, cr = (np.ascontiguousarray(c, np.int16) for c in chroma)
+        assert cb.shape == (height // 2, width // 2) and cr.shape == cb.shape
+        rc = lib.href_rdo_encode_frame_yuv(ptr(plane.reshape(-1), origin), stride, ptr(cb), ptr(cr), width, height, bit_depth, qp,
+                                           C.c_void_p(fd.ctypes.data) if fd is not None else None, depth, stats)
+    else:
+        rc = lib.href_rdo_encode_frame(ptr(plane.reshape(-1), origin), stride, width, height, bit_depth, qp,
+                                       C.c_void_p(fd.ctypes.data) if fd is not None else None, depth, stats)
     if rc != 0:
         raise RuntimeError(f"href_rdo_encode_frame failed: {rc}")
     mse = stats[4] / (width * height)

@@ -34,6 +34,7 @@
 #endif
 #include "TLibCommon/CommonDef.h"
 #include "TLibCommon/TComRom.h"
+#include "TLibCommon/ContextModel.h"
 #include "TLibCommon/TComPic.h"
 #include "TLibCommon/TComSlice.h"
 #include "TLibCommon/TComTrQuant.h"
@@ -177,7 +178,13 @@ Encoder* get_encoder(int w, int h, int bd)
   auto it = g_encoders.find(key);
   if (it != g_encoders.end()) return it->second;
   static bool rom = false;
-  if (!rom) { initROM(); rom = true; }
+  if (!rom) {
+    initROM();
+#if FAST_BIT_EST
+    ContextModel::buildNextStateTable();  // done by TEncTop's constructor in the real encoder (TEncTop.cpp:73-76)
+#endif
+    rom = true;
+  }
   Encoder* e = new Encoder();
   e->width = w; e->height = h; e->bit_depth = bd;
   configure(*e);
@@ -233,7 +240,7 @@ Encoder* get_encoder(int w, int h, int bd)
   return e;
 }
 
-void load_picture(Encoder& e, const int16_t* luma, int stride)
+void load_picture(Encoder& e, const int16_t* luma, int stride, const int16_t* cb, const int16_t* cr)
 {
   TComPicYuv* org = e.pic->getPicYuvOrg();
   for (int comp = 0; comp < 3; comp++) {
@@ -242,7 +249,9 @@ void load_picture(Encoder& e, const int16_t* luma, int stride)
     const int s = org->getStride(id), w = org->getWidth(id), h = org->getHeight(id);
     for (int y = 0; y < h; y++)
       for (int x = 0; x < w; x++)
-        dst[y * s + x] = (comp == 0) ? (Pel)luma[(size_t)y * stride + x] : (Pel)(1 << (e.bit_depth - 1));  // flat chroma
+        dst[y * s + x] = (comp == 0) ? (Pel)luma[(size_t)y * stride + x]
+                         : ((comp == 1 ? cb : cr) ? (Pel)(comp == 1 ? cb : cr)[(size_t)y * w + x]   // packed W/2 x H/2 plane
+                                                  : (Pel)(1 << (e.bit_depth - 1)));                 // flat chroma
   }
   org->copyToPic(e.pic->getPicYuvTrueOrg());
 }
@@ -285,12 +294,22 @@ extern "C" {
 // depth_out: numCtus*256, raster per CTU = getDepth(g_auiRasterToZscan[r]).  stats: [0] bits (RD-SBAC estimate summed
 // over CTUs), [1] distortion (SSE, chroma weighted as in TComRdCost), [2] RD cost, [3] seconds in compressSlice,
 // [4] luma SSE of the reconstruction vs the original, [5] number of CTUs.
+int href_rdo_encode_frame_yuv(const int16_t* luma, int stride, const int16_t* cb, const int16_t* cr, int width, int height,
+                              int bit_depth, int qp, const uint8_t* forced_depth, uint8_t* depth_out, double* stats);
+
 int href_rdo_encode_frame(const int16_t* luma, int stride, int width, int height, int bit_depth, int qp,
                           const uint8_t* forced_depth, uint8_t* depth_out, double* stats)
 {
+  return href_rdo_encode_frame_yuv(luma, stride, nullptr, nullptr, width, height, bit_depth, qp, forced_depth, depth_out, stats);
+}
+
+// same with 4:2:0 chroma planes (packed W/2 x H/2, internal bit depth); NULL = flat mid-grey chroma
+int href_rdo_encode_frame_yuv(const int16_t* luma, int stride, const int16_t* cb, const int16_t* cr, int width, int height,
+                              int bit_depth, int qp, const uint8_t* forced_depth, uint8_t* depth_out, double* stats)
+{
   if ((width % 8) || (height % 8) || width < 64 || height < 64) return -1;
   Encoder* e = get_encoder(width, height, bit_depth);
-  load_picture(*e, luma, stride);
+  load_picture(*e, luma, stride, cb, cr);
   init_slice(*e, qp);
 #ifdef FHEVC_HOOK
   fhevc_hook_register(&e->cu.getFastDepth());

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Quality guard: BD-rate of depth-map-driven encoding against the reference's full RDO.
+"""TEST/QUALITY INFRASTRUCTURE (uses oracle/ and oracle/_ref).  Quality guard: BD-rate of depth-map-driven encoding against the reference's full RDO.
 
 For the two pinned 1080p pictures (or crops of them) and QP {22,27,32,37}:
   anchor   = the reference's full-RDO decision path (oracle/_ref/libhmref.so, oracle/ref_rdo_harness.cpp)
@@ -9,7 +9,7 @@ Rate = bits counted by TEncCu::encodeCtu over the picture (true CABAC state), di
 reconstruction before the in-loop filters.  The full encoder (NAL/SEI, deblocking, SAO) cannot be built here (OpenCV), so
 this is the decision-stage BD-rate, not a bitstream BD-rate -- stated next to every number.
 
-usage: python -m fasthevc_amd.train.eval_rd --weights fasthevc_amd/weights/depthnet_v1.fhw [--crop 1024x576]
+usage: python tests/quality/eval_rd.py --weights fasthevc_amd/weights/depthnet_v1.fhw [--crop 1024x576]
 """
 import argparse
 import json
@@ -18,7 +18,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # tests/quality -> repo root
 sys.path.insert(0, ROOT)
 from fasthevc_amd import frames, weights  # noqa: E402
 
@@ -55,6 +55,8 @@ def main():
     for name in args.content.split(","):
         full = frames.hetero_luma(1920, 1080) if name == "hetero" else frames.texture16_luma(1920, 1080)
         luma = full[:ch_, :cw_].copy()
+        cu, cv = frames.chroma_planes(name, 1920, 1080)
+        chroma = (cu[:ch_ // 2, :cw_ // 2].astype(np.int16), cv[:ch_ // 2, :cw_ // 2].astype(np.int16))
         buf, org, stride = frames.to_pel_plane(luma, 8)
         H, Wd = luma.shape
         n = ((Wd + 63) // 64) * ((H + 63) // 64)
@@ -64,12 +66,12 @@ def main():
                 rows[f"const{c}"] = []
         agree = []
         for qp in QPS:
-            d_anchor, s_anchor = op.rdo_encode(ref, buf, org, stride, Wd, H, 8, qp)
+            d_anchor, s_anchor = op.rdo_encode(ref, buf, org, stride, Wd, H, 8, qp, chroma=chroma)
             rows["anchor"].append((s_anchor["coded_bits"], s_anchor["psnr_y"], s_anchor["seconds"]))
             pred = np.zeros(n * 256, np.uint8)
             oracle.fho_predict_frame(ws, op.ptr(buf.reshape(-1), org), stride, Wd, H, 8, qp, pred, None)
             pred = pred.reshape(n, 256)
-            _, s_cnn = op.rdo_encode(hook, buf, org, stride, Wd, H, 8, qp, forced_depth=pred)
+            _, s_cnn = op.rdo_encode(hook, buf, org, stride, Wd, H, 8, qp, forced_depth=pred, chroma=chroma)
             rows["cnn"].append((s_cnn["coded_bits"], s_cnn["psnr_y"], s_cnn["seconds"]))
             inpic = np.ones((n, 16, 16), bool)  # compare in-picture units only
             cwn = (Wd + 63) // 64
@@ -82,7 +84,7 @@ def main():
                           np.bincount(pred[m], minlength=4).tolist(), np.bincount(d_anchor[m], minlength=4).tolist()))
             if args.floors:
                 for c in range(4):
-                    _, s_c = op.rdo_encode(hook, buf, org, stride, Wd, H, 8, qp, forced_depth=np.full((n, 256), c, np.uint8))
+                    _, s_c = op.rdo_encode(hook, buf, org, stride, Wd, H, 8, qp, forced_depth=np.full((n, 256), c, np.uint8), chroma=chroma)
                     rows[f"const{c}"].append((s_c["coded_bits"], s_c["psnr_y"], s_c["seconds"]))
             print(f"{name} qp{qp}: anchor {s_anchor['coded_bits']:.0f} b {s_anchor['psnr_y']:.3f} dB {s_anchor['seconds']:.2f} s | "
                   f"cnn {s_cnn['coded_bits']:.0f} b {s_cnn['psnr_y']:.3f} dB {s_cnn['seconds']:.2f} s | unit agreement {agree[-1][0]:.3f}", flush=True)

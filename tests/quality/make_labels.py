@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""Training-set generator: replaces the reference's HARP dump + MATLAB getData pipeline
+"""TEST/QUALITY INFRASTRUCTURE (uses oracle/_ref): training-set generator: replaces the reference's HARP dump + MATLAB getData pipeline
 (Src_HARP/CShow_PredResiReco.h:127-255, matlab/dataExtraction/detectAndClassify32Cu.m).
 
 For seeded synthetic pictures it runs the REFERENCE's own full-RDO decision path (oracle/_ref/libhmref.so:
 TEncSlice::compressSlice -> TEncCu::xCompressCU through oracle/ref_rdo_harness.cpp) at several QPs and stores, per
 full 64x64 CTU: the 8-bit luma tile and the 16x16 depth map.  Build-container only (needs oracle/_ref).
 
-usage: python -m fasthevc_amd.train.make_labels --out /tmp/fhevc_labels --frames 64 --workers 8
+usage: python tests/quality/make_labels.py --out /tmp/fhevc_labels --frames 64 --workers 8
 """
 import argparse
 import os
@@ -16,7 +16,7 @@ from multiprocessing import Pool
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # tests/quality -> repo root
 sys.path.insert(0, ROOT)
 from fasthevc_amd import frames  # noqa: E402
 
@@ -37,19 +37,20 @@ def training_picture(seed):
     y = (y - 128.0) * gain + 128.0 + offs
     if rng.random() < 0.3:  # soften some pictures: more large CUs
         y = frames._box_blur(y, 3)
-    return np.clip(np.rint(y), 0, 255).astype(np.uint8)
+    return np.clip(np.rint(y), 0, 255).astype(np.uint8), ("texture16" if kind == 3 else "hetero")
 
 
 def work(seed):
     from oracle import oracle_py as op
     lib = op.bind_rdo(op.load_ref())
-    luma = training_picture(seed)
+    luma, kind = training_picture(seed)
+    chroma = tuple(c.astype(np.int16) for c in frames.chroma_planes(kind, W, H))
     buf, org, stride = frames.to_pel_plane(luma, 8)
     cw, ch = W // 64, H // 64
     tiles = luma.reshape(ch, 64, cw, 64).transpose(0, 2, 1, 3).reshape(cw * ch, 64, 64)
     out = {"tiles": tiles}
     for qp in QPS:
-        depth, st = op.rdo_encode(lib, buf, org, stride, W, H, 8, qp)
+        depth, st = op.rdo_encode(lib, buf, org, stride, W, H, 8, qp, chroma=chroma)
         out[f"depth_q{qp}"] = depth.reshape(cw * ch, 16, 16)
         out[f"stats_q{qp}"] = np.array([st["bits"], st["dist"], st["psnr_y"], st["seconds"]])
     return seed, out

@@ -18,6 +18,11 @@ def _crop():
     return frames.to_pel_plane(frames.hetero_luma(1920, 1080)[:512, :768].copy(), 8)
 
 
+def _crop_chroma():
+    u, v = frames.chroma_planes("hetero", 1920, 1080)
+    return u[:256, :384].astype(np.int16), v[:256, :384].astype(np.int16)
+
+
 def test_fixture_is_a_valid_depth_map(oracle):
     fx = np.load(FIX)
     depth = fx["depth"]
@@ -35,10 +40,26 @@ def test_fixture_is_a_valid_depth_map(oracle):
 def test_reference_rdo_is_reproducible_and_matches_fixture():
     buf, org, stride = _crop()
     ref = op.bind_rdo(op.load_ref())
-    depth, st = op.rdo_encode(ref, buf, org, stride, 768, 512, 8, 32)
+    depth, st = op.rdo_encode(ref, buf, org, stride, 768, 512, 8, 32, chroma=_crop_chroma())
     fx = np.load(FIX)
     assert np.array_equal(depth, fx["depth"])
     assert st["bits"] == float(fx["bits"]) and st["dist"] == float(fx["dist"])
+
+
+@need_ref
+def test_harness_reproduces_the_full_encoders_depth_histogram():
+    """SURVEY.md section 6.2 records what the reference's FULL encoder (built with OpenCV stubs during the survey) decided
+    for the pinned 1080p hetero picture at QP32: 777 248 bits, 35.86 dB (after the in-loop filters), 6.75 s, and the depth
+    histogram over 4x4 units d0 74 240, d1 31 424, d2 15 616, d3 9 280.  Our harness around the same objects must land
+    on the same decisions (bits differ by the uncounted headers, PSNR by the filters)."""
+    W, H = 1920, 1080
+    buf, org, stride = frames.to_pel_plane(frames.hetero_luma(W, H), 8)
+    u, v = frames.chroma_planes("hetero", W, H)
+    ref = op.bind_rdo(op.load_ref())
+    depth, st = op.rdo_encode(ref, buf, org, stride, W, H, 8, 32, chroma=(u.astype(np.int16), v.astype(np.int16)))
+    assert np.bincount(depth.reshape(-1), minlength=4).tolist() == [74240, 31424, 15616, 9280]
+    assert abs(st["coded_bits"] / 777248.0 - 1.0) < 0.01
+    assert abs(st["psnr_y"] - 35.86) < 0.2
 
 
 @need_ref
@@ -47,14 +68,15 @@ def test_hook_with_own_depth_map_reproduces_full_rdo():
     buf, org, stride = _crop()
     hook = op.bind_rdo(op.load_ref(hook=True))
     fx = np.load(FIX)
-    d_stock, s_stock = op.rdo_encode(hook, buf, org, stride, 768, 512, 8, 32)          # no map: stock behaviour
+    ch = _crop_chroma()
+    d_stock, s_stock = op.rdo_encode(hook, buf, org, stride, 768, 512, 8, 32, chroma=ch)          # no map: stock behaviour
     assert np.array_equal(d_stock, fx["depth"]) and s_stock["bits"] == float(fx["bits"])
-    d_forced, s_forced = op.rdo_encode(hook, buf, org, stride, 768, 512, 8, 32, forced_depth=fx["depth"])
+    d_forced, s_forced = op.rdo_encode(hook, buf, org, stride, 768, 512, 8, 32, forced_depth=fx["depth"], chroma=ch)
     assert np.array_equal(d_forced, fx["depth"])
     assert s_forced["bits"] == s_stock["bits"] and s_forced["dist"] == s_stock["dist"]
     assert s_forced["seconds"] < 0.5 * s_stock["seconds"]  # and it skips most of the search
     # a wrong map costs RD: all-8x8 is clearly worse than the reference's choice
-    _, s_bad = op.rdo_encode(hook, buf, org, stride, 768, 512, 8, 32, forced_depth=np.full_like(fx["depth"], 3))
+    _, s_bad = op.rdo_encode(hook, buf, org, stride, 768, 512, 8, 32, forced_depth=np.full_like(fx["depth"], 3), chroma=ch)
     assert s_bad["rdcost"] > 1.05 * s_stock["rdcost"]
 
 
