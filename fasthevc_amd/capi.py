@@ -22,7 +22,7 @@ SYMBOLS = [
     "fhevc_create", "fhevc_destroy", "fhevc_set_weights", "fhevc_predict_frame", "fhevc_satd",
     "fhevc_intra_first_pass", "fhevc_predict_frames_device", "fhevc_band", "fhevc_kernel_timing",
     "fhevc_enable_kernel_timing", "fhevc_get_stats", "fhevc_last_error", "fhevc_version",
-    "fhevc_expand_depth_flags_device",
+    "fhevc_expand_depth_flags_device", "fhevc_aq_parts", "fhevc_preanalyze", "fhevc_preanalyze_frames_device",
 ]
 
 
@@ -75,6 +75,10 @@ def load_library():
                                                 C.c_int, vp, vp, vp, vp, vp]
     lib.fhevc_expand_depth_flags_device.argtypes = [vp, vp, C.c_int, vp, vp]
     lib.fhevc_band.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.fhevc_aq_parts.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_longlong)]
+    lib.fhevc_preanalyze.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
+    lib.fhevc_preanalyze_frames_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_int,
+                                                   C.c_int, vp, vp]
     lib.fhevc_kernel_timing.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     lib.fhevc_enable_kernel_timing.argtypes = [vp, C.c_int]
     lib.fhevc_get_stats.argtypes = [vp, vp, C.c_size_t]
@@ -152,6 +156,30 @@ class Context:
         out = np.zeros(self.num_ctus * NODES_PER_CTU, NODE_DTYPE)
         self._check(self.lib.fhevc_intra_first_pass(self.h, flat.ctypes.data + 2 * origin, stride, qp, out.ctypes.data))
         return out.reshape(self.num_ctus, NODES_PER_CTU)
+
+    def aq_layout(self, max_aq_depth):
+        """Offsets of the AQ layers in the concatenated activity array (max_aq_depth + 1 entries)."""
+        off = (C.c_longlong * (max_aq_depth + 1))()
+        n = self.lib.fhevc_aq_parts(self.width, self.height, max_aq_depth, off)
+        self._check(min(n, 0))
+        return list(off)
+
+    def preanalyze(self, plane, origin=0, stride=None, max_aq_depth=3):
+        """TEncPreanalyzer::xPreanalyze: (activity of all layers concatenated, per-layer averages)."""
+        flat = np.ascontiguousarray(plane).reshape(-1)
+        stride = stride if stride is not None else plane.shape[-1]
+        off = self.aq_layout(max_aq_depth)
+        act = np.zeros(off[-1], np.float64)
+        avg = np.zeros(max_aq_depth, np.float64)
+        self._check(self.lib.fhevc_preanalyze(self.h, flat.ctypes.data + 2 * origin, stride, max_aq_depth,
+                                              act.ctypes.data, avg.ctypes.data))
+        return act, avg
+
+    def preanalyze_frames_device(self, d_luma, sample_bytes, stride, frame_stride, num_frames, d_activity,
+                                 max_aq_depth=3, rows=None, stream=None):
+        rb, re = rows if rows is not None else (0, self.ctus_y)
+        self._check(self.lib.fhevc_preanalyze_frames_device(self.h, d_luma, sample_bytes, stride, frame_stride,
+                                                            num_frames, rb, re, max_aq_depth, d_activity, stream))
 
     def predict_frames_device(self, d_luma, sample_bytes, stride, frame_stride, num_frames, d_depth, d_hadamard=None,
                               d_logits=None, rows=None, stream=None, qp=32, d_flags=None):

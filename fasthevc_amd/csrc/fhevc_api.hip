@@ -34,8 +34,9 @@ struct fhevc_ctx {
   bool timing = false;
   std::vector<TimedLaunch> pending;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
-  double sum_ms[3] = { 0, 0, 0 };
-  uint64_t launches[3] = { 0, 0, 0 };
+  double sum_ms[4] = { 0, 0, 0, 0 };
+  uint64_t launches[4] = { 0, 0, 0, 0 };
+  double* d_act = nullptr;
   fhevc_stats stats{};
   std::string err;
 };
@@ -290,7 +291,7 @@ void fhevc_destroy(fhevc_ctx* c)
   for (auto& p : c->pool) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
   for (auto& e : c->ev) if (e) hipEventDestroy(e);
   hipFree(c->d_frag); hipFree(c->d_bias); hipFree(c->d_whead); hipFree(c->d_bhead);
-  hipFree(c->d_luma); hipFree(c->d_depth); hipFree(c->d_had); hipFree(c->d_nodes); hipFree(c->d_satd); hipFree(c->d_satd_out);
+  hipFree(c->d_luma); hipFree(c->d_depth); hipFree(c->d_had); hipFree(c->d_nodes); hipFree(c->d_satd); hipFree(c->d_satd_out); hipFree(c->d_act);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
 }
@@ -318,7 +319,7 @@ int fhevc_enable_kernel_timing(fhevc_ctx* c, int on)
 
 int fhevc_kernel_timing(fhevc_ctx* c, int which, int reset, double* avg_ms, uint64_t* launches)
 {
-  if (!c || which < 0 || which > 2) return FHEVC_E_INVALID;
+  if (!c || which < 0 || which > 3) return FHEVC_E_INVALID;
   time_resolve(c);
   if (avg_ms) *avg_ms = c->launches[which] ? c->sum_ms[which] / (double)c->launches[which] : 0.0;
   if (launches) *launches = c->launches[which];
@@ -432,6 +433,64 @@ int fhevc_intra_first_pass(fhevc_ctx* c, const int16_t* luma, int stride_samples
   HIP_TRY(c, hipMemcpyAsync(out, c->d_nodes, (size_t)c->num_ctus * FHEVC_NODES_PER_CTU * sizeof(FhevcNodeCost), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->stats.kernels_launched++;
+  return FHEVC_OK;
+}
+
+int fhevc_aq_parts(int width, int height, int max_aq_depth, long long* layer_offsets)
+{
+  if (width <= 0 || height <= 0 || max_aq_depth < 1 || max_aq_depth > 4) return FHEVC_E_INVALID;
+  long long off = 0;
+  for (int d = 0; d < max_aq_depth; ++d) {
+    if (layer_offsets) layer_offsets[d] = off;
+    const int p = 64 >> d;
+    off += (long long)((width + p - 1) / p) * ((height + p - 1) / p);
+  }
+  if (layer_offsets) layer_offsets[max_aq_depth] = off;
+  return (int)off;
+}
+
+int fhevc_preanalyze_frames_device(fhevc_ctx* c, const void* d_luma, int sample_bytes, int stride_samples,
+                                   long long frame_stride_samples, int num_frames, int ctu_row_begin, int ctu_row_end,
+                                   int max_aq_depth, double* d_activity, void* stream)
+{
+  if (!c || !d_luma || !d_activity) return FHEVC_E_INVALID;
+  if ((sample_bytes != 1 && sample_bytes != 2) || stride_samples < c->cfg.width || num_frames < 1 ||
+      ctu_row_begin < 0 || ctu_row_end > c->ctus_y || ctu_row_begin > ctu_row_end || max_aq_depth < 1 || max_aq_depth > 4)
+    return fail(c, FHEVC_E_INVALID, "bad pre-analysis arguments");
+  if ((c->cfg.width & 7) || (c->cfg.height & 7)) return fail(c, FHEVC_E_INVALID, "pre-analysis needs picture sizes that are multiples of 8");
+  if (sample_bytes == 1 && c->cfg.bit_depth != 8) return fail(c, FHEVC_E_INVALID, "uint8 samples need bit depth 8");
+  hipSetDevice(c->device);
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  const FhevcFrames fr = frames_of(c, d_luma, sample_bytes, stride_samples, frame_stride_samples, num_frames, ctu_row_begin, ctu_row_end);
+  const long long per_frame = fhevc_aq_parts(c->cfg.width, c->cfg.height, max_aq_depth, nullptr);
+  time_begin(c, st, 3);
+  HIP_TRY(c, fhevc_launch_preanalyze(fr, max_aq_depth, per_frame, d_activity, c->num_cus, st));
+  time_end(c, st);
+  c->stats.kernels_launched++;
+  return FHEVC_OK;
+}
+
+int fhevc_preanalyze(fhevc_ctx* c, const int16_t* luma, int stride_samples, int max_aq_depth, double* activity, double* avg_activity)
+{
+  if (!c || !luma || !activity || !avg_activity || stride_samples < c->cfg.width) return FHEVC_E_INVALID;
+  long long off[5];
+  const int total = fhevc_aq_parts(c->cfg.width, c->cfg.height, max_aq_depth, off);
+  if (total < 0) return fail(c, FHEVC_E_INVALID, "bad max_aq_depth");
+  hipSetDevice(c->device);
+  if (!c->d_act) HIP_TRY(c, hipMalloc(&c->d_act, (size_t)fhevc_aq_parts(c->cfg.width, c->cfg.height, 4, nullptr) * sizeof(double)));
+  int rc = upload_frame(c, luma, stride_samples);
+  if (rc != FHEVC_OK) return rc;
+  rc = fhevc_preanalyze_frames_device(c, c->d_luma, 2, c->dev_stride, 0, 1, 0, c->ctus_y, max_aq_depth, c->d_act, c->stream);
+  if (rc != FHEVC_OK) return rc;
+  HIP_TRY(c, hipMemcpyAsync(activity, c->d_act, (size_t)total * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  // TEncPreanalyzer.cpp:147-150: dSumAct accumulates part by part in raster order; keep that order
+  for (int d = 0; d < max_aq_depth; ++d) {
+    double sum = 0.0;
+    for (long long i = off[d]; i < off[d + 1]; ++i) sum += activity[i];
+    avg_activity[d] = sum / (double)(off[d + 1] - off[d]);
+  }
+  c->stats.bytes_d2h += (uint64_t)total * sizeof(double);
   return FHEVC_OK;
 }
 

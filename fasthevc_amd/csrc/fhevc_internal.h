@@ -51,3 +51,8 @@ hipError_t fhevc_launch_satd(const int16_t* d_org, int org_stride, const int16_t
 // ---- 35-mode first pass (k_firstpass.hip) ------------------------------------------------------------------
 struct FhevcNodeCost { uint32_t satd; uint32_t mode; double cost; };
 hipError_t fhevc_launch_first_pass(const FhevcFrames& fr, double sqrt_lambda, FhevcNodeCost* d_out, hipStream_t stream);
+
+// ---- adaptive-QP pre-analysis (k_preanalyze.hip) -----------------------------------------------------------
+// d_activity: per frame parts_per_frame doubles, layers concatenated (layer d: ceil(H/P) x ceil(W/P), P = 64 >> d)
+hipError_t fhevc_launch_preanalyze(const FhevcFrames& fr, int layers, long long parts_per_frame, double* d_activity,
+                                   int num_cus, hipStream_t stream);

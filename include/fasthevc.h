@@ -115,11 +115,26 @@ int  fhevc_predict_frames_device(fhevc_ctx* ctx, const void* d_luma, int sample_
  * back into depth maps on the device: num_frames * numCtus words, whole pictures in CTU raster order. */
 int  fhevc_expand_depth_flags_device(fhevc_ctx* ctx, const uint32_t* d_flags, int num_frames, uint8_t* d_depth_map, void* stream);
 
+/* Adaptive-QP pre-analysis == TEncPreanalyzer::xPreanalyze (TEncPreanalyzer.cpp:64-152), called by TEncGOP before
+ * compressSlice when --AdaptiveQP is on (TEncGOP.cpp: m_pcPreanalyzer->xPreanalyze(pcPic)).  max_aq_depth =
+ * TEncPic's uiMaxAdaptiveQPDepth (1..4): layer d has parts of 64 >> d samples, ceil(height/P) x ceil(width/P) of
+ * them, raster order.  activity: all layers concatenated (fhevc_aq_parts gives the offsets) = what
+ * TEncQPAdaptationUnit::getActivity returns; avg_activity: max_aq_depth values = TEncPicQPAdaptationLayer::
+ * getAvgActivity.  Doubles are bit-identical to HM's.  Picture width/height must be multiples of 8. */
+int  fhevc_aq_parts(int width, int height, int max_aq_depth, long long* layer_offsets /* max_aq_depth + 1, may be NULL */);
+int  fhevc_preanalyze(fhevc_ctx* ctx, const int16_t* luma, int stride_samples, int max_aq_depth,
+                      double* activity, double* avg_activity);
+/* device-resident batch; d_activity holds num_frames * fhevc_aq_parts() doubles in whole-picture layout, of which
+ * this call writes the parts inside CTU rows [ctu_row_begin, ctu_row_end) */
+int  fhevc_preanalyze_frames_device(fhevc_ctx* ctx, const void* d_luma, int sample_bytes, int stride_samples,
+                                    long long frame_stride_samples, int num_frames, int ctu_row_begin, int ctu_row_end,
+                                    int max_aq_depth, double* d_activity, void* stream);
+
 /* CTU-row band of rank `rank` out of `world`: rows [begin, end) */
 int  fhevc_band(int ctu_rows, int rank, int world, int* begin, int* end);
 
 /* average duration in ms of the dominant kernels over launches since the last reset, measured with HIP
- * events on the launch stream; which: 0 = depth CNN, 1 = source Hadamard, 2 = first pass */
+ * events on the launch stream; which: 0 = depth CNN, 1 = source Hadamard, 2 = first pass, 3 = pre-analysis */
 int  fhevc_kernel_timing(fhevc_ctx* ctx, int which, int reset, double* avg_ms, uint64_t* launches);
 int  fhevc_enable_kernel_timing(fhevc_ctx* ctx, int on);
 

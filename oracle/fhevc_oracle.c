@@ -173,6 +173,42 @@ void fho_frame_src_hadamard(const int16_t* luma, int stride, int width, int heig
                                                 imin(CTU, width - cx * CTU), imin(CTU, height - cy * CTU));
 }
 
+/* N3: TEncPreanalyzer.cpp:64-152.  Sums in 64-bit integers, variance in double exactly as the reference orders it. */
+double fho_preanalyze_layer(const int16_t* luma, int stride, int width, int height, int part, double* activity)
+{
+  const int nw = (width + part - 1) / part, nh = (height + part - 1) / part;
+  double sum_act = 0.0;
+  int idx = 0;
+  for (int y = 0; y < height; y += part) {
+    const int ch = imin(part, height - y);
+    for (int x = 0; x < width; x += part, idx++) {
+      const int cw = imin(part, width - x);
+      uint64_t sum[4] = { 0, 0, 0, 0 }, sq[4] = { 0, 0, 0, 0 };
+      for (int by = 0; by < ch; by++)
+        for (int bx = 0; bx < cw; bx++) {
+          const int q = (by < (ch >> 1) ? 0 : 2) + (bx < (cw >> 1) ? 0 : 1);
+          const int v = luma[(y + by) * stride + x + bx];
+          sum[q] += (uint64_t)v;
+          sq[q] += (uint64_t)(v * v);
+        }
+      const unsigned npix = (unsigned)(cw >> 1) * (unsigned)(ch >> 1);
+      double min_var = 1.7976931348623157e308;
+      if (npix != 0) {
+        for (int i = 0; i < 4; i++) {
+          const double avg = (double)sum[i] / npix;
+          const double var = (double)sq[i] / npix - avg * avg;
+          if (var < min_var) min_var = var;
+        }
+      } else {
+        min_var = 0.0;
+      }
+      activity[idx] = 1.0 + min_var;
+      sum_act += activity[idx];
+    }
+  }
+  return sum_act / (nw * nh);
+}
+
 /* A11: TEncSlice.cpp:433-527 with GOPSize 1 (no B frames), I slice, lambda modifiers 1.0,
  * FULL_NBIT 0 (bitdepth_luma_qp_scale = 0): lambda = 0.57 * 2^((qp-12)/3). */
 double fho_lambda_intra(int qp, int bit_depth)

@@ -50,6 +50,12 @@ int32_t fho_ctu_src_hadamard(const int16_t* ctu_org, int stride, int w, int h); 
 /* whole frame: one value per CTU in raster order; w/h per CTU = min(64, remaining) */
 void    fho_frame_src_hadamard(const int16_t* luma, int stride, int width, int height, int32_t* out);
 
+/* ---- N3: adaptive-QP pre-analysis (TEncPreanalyzer.cpp:64-152 xPreanalyze) -------------- */
+/* One layer: AQ parts of part x part samples (64 >> depth), cropped at the picture edge; per part the minimum of the
+ * four quadrant variances, activity = 1 + minVar.  activity: ceil(h/part) x ceil(w/part) doubles, raster order.
+ * Returns the layer's average activity (sum in raster order / number of parts). */
+double fho_preanalyze_layer(const int16_t* luma, int stride, int width, int height, int part, double* activity);
+
 /* ---- A11: lambda (TEncSlice.cpp:433-527 calculateLambda, all-intra path) ----------------- */
 double fho_lambda_intra(int qp, int bit_depth);
 

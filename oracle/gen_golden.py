@@ -111,7 +111,30 @@ def main():
     dst = os.path.join(os.path.dirname(HERE), "tests", "golden", "ref_vectors.npz")
     np.savez_compressed(dst, **out)
     print("wrote", dst, os.path.getsize(dst), "bytes")
+    preanalyze_golden(ref)
+
+
+PREANALYZE_CASES = (("texture16", 416, 240, 8, 3), ("hetero", 1000, 568, 10, 4), ("hetero", 64, 64, 8, 1))
+
+
+def preanalyze_golden(ref):
+    """TEncPreanalyzer::xPreanalyze outputs (N3) on the md5-pinned synthetic pictures: expected doubles only."""
+    out = {"cases": np.array([f"{c[0]}:{c[1]}x{c[2]}:bd{c[3]}:d{c[4]}" for c in PREANALYZE_CASES])}
+    for k, (content, w, h, bd, depth) in enumerate(PREANALYZE_CASES):
+        luma = frames.texture16_luma(w, h) if content == "texture16" else frames.hetero_luma(w, h)
+        buf, org, stride = frames.to_pel_plane(luma, bd)
+        n = sum(((w + (64 >> d) - 1) // (64 >> d)) * ((h + (64 >> d) - 1) // (64 >> d)) for d in range(depth))
+        act = np.zeros(n)
+        avg = np.zeros(depth)
+        assert ref.href_preanalyze(op.ptr(buf.reshape(-1), org), stride, w, h, bd, depth, act, avg) == n
+        out[f"act{k}"], out[f"avg{k}"] = act, avg
+    dst = os.path.join(os.path.dirname(HERE), "tests", "golden", "ref_preanalyze.npz")
+    np.savez_compressed(dst, **out)
+    print("wrote", dst, os.path.getsize(dst), "bytes")
 
 
 if __name__ == "__main__":
-    main()
+    if "--preanalyze-only" in sys.argv:
+        preanalyze_golden(op.load_ref())
+    else:
+        main()

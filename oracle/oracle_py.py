@@ -68,6 +68,8 @@ def load_oracle():
     lib.fho_ctu_src_hadamard.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
     lib.fho_ctu_src_hadamard.restype = C.c_int32
     lib.fho_frame_src_hadamard.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _i32p]
+    lib.fho_preanalyze_layer.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")]
+    lib.fho_preanalyze_layer.restype = C.c_double
     lib.fho_lambda_intra.argtypes = [C.c_int, C.c_int]
     lib.fho_lambda_intra.restype = C.c_double
     lib.fho_fill_ref.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _i16p]
@@ -127,6 +129,10 @@ def load_ref(hook=False):
     lib.href_use_filtered.argtypes = [C.c_int, C.c_int]
     lib.href_use_filtered.restype = C.c_int
     lib.href_pred_intra.argtypes = [_i16p, C.c_int, C.c_int, C.c_int, _i16p]
+    if hasattr(lib, "href_preanalyze"):
+        f64 = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+        lib.href_preanalyze.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f64, f64]
+        lib.href_preanalyze.restype = C.c_int
     return lib
 
 

@@ -48,6 +48,8 @@
 #include "TLibEncoder/TEncBinCoderCABAC.h"
 #include "TLibEncoder/TEncBinCoderCABACCounter.h"
 #include "TLibEncoder/TEncRateCtrl.h"
+#include "TLibEncoder/TEncPic.h"
+#include "TLibEncoder/TEncPreanalyzer.h"
 #undef private
 #undef protected
 
@@ -341,6 +343,31 @@ int href_rdo_encode_frame_yuv(const int16_t* luma, int stride, const int16_t* cb
     stats[5] = n;
   }
   return 0;
+}
+
+// TEncPreanalyzer::xPreanalyze (TEncPreanalyzer.cpp:64-152) on a TEncPic holding `luma`: activities of all layers
+// (layer d = parts of 64 >> d, raster order, layers concatenated) and the per-layer averages.
+int href_preanalyze(const int16_t* luma, int stride, int width, int height, int bit_depth, int max_aq_depth,
+                    double* activity, double* avg)
+{
+  Encoder* e = get_encoder(width, height, bit_depth);
+  TEncPic pic;
+  pic.create(e->sps, e->pps, (UInt)max_aq_depth);
+  Pel* dst = pic.getPicYuvOrg()->getAddr(COMPONENT_Y);
+  const int s = pic.getPicYuvOrg()->getStride(COMPONENT_Y);
+  for (int y = 0; y < height; y++)
+    for (int x = 0; x < width; x++) dst[y * s + x] = (Pel)luma[(size_t)y * stride + x];
+  TEncPreanalyzer pre;
+  pre.xPreanalyze(&pic);
+  size_t k = 0;
+  for (int d = 0; d < max_aq_depth; d++) {
+    TEncPicQPAdaptationLayer* layer = pic.getAQLayer(d);
+    const size_t n = (size_t)layer->getNumAQPartInWidth() * layer->getNumAQPartInHeight();
+    for (size_t i = 0; i < n; i++) activity[k++] = layer->getQPAdaptationUnit()[i].getActivity();
+    avg[d] = layer->getAvgActivity();
+  }
+  pic.destroy();
+  return (int)k;
 }
 
 // debugging aid: histograms of the decisions of the last encoded picture of that geometry
