@@ -22,7 +22,7 @@ SYMBOLS = [
     "fhevc_create", "fhevc_destroy", "fhevc_set_weights", "fhevc_predict_frame", "fhevc_satd",
     "fhevc_intra_first_pass", "fhevc_predict_frames_device", "fhevc_band", "fhevc_kernel_timing",
     "fhevc_enable_kernel_timing", "fhevc_get_stats", "fhevc_last_error", "fhevc_version",
-    "fhevc_expand_depth_flags_device", "fhevc_aq_parts", "fhevc_preanalyze", "fhevc_preanalyze_frames_device",
+    "fhevc_expand_depth_flags_device", "fhevc_aq_parts", "fhevc_preanalyze", "fhevc_preanalyze_frames_device", "fhevc_aq_qp",
 ]
 
 
@@ -77,6 +77,7 @@ def load_library():
     lib.fhevc_band.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.fhevc_aq_parts.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_longlong)]
     lib.fhevc_preanalyze.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
+    lib.fhevc_aq_qp.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     lib.fhevc_preanalyze_frames_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_int,
                                                    C.c_int, vp, vp]
     lib.fhevc_kernel_timing.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
@@ -174,6 +175,16 @@ class Context:
         self._check(self.lib.fhevc_preanalyze(self.h, flat.ctypes.data + 2 * origin, stride, max_aq_depth,
                                               act.ctypes.data, avg.ctypes.data))
         return act, avg
+
+    def aq_qp(self, activity, avg_activity, qp_adaptation_range=6, base_qp=32):
+        """TEncCu::xComputeQP for every AQ part (host side; no device work)."""
+        activity = np.ascontiguousarray(activity, np.float64)
+        avg_activity = np.ascontiguousarray(avg_activity, np.float64)
+        out = np.zeros(activity.size, np.int8)
+        self._check(self.lib.fhevc_aq_qp(activity.ctypes.data, avg_activity.ctypes.data, self.width, self.height,
+                                         avg_activity.size, qp_adaptation_range, base_qp, 6 * (self.bit_depth - 8),
+                                         out.ctypes.data))
+        return out
 
     def preanalyze_frames_device(self, d_luma, sample_bytes, stride, frame_stride, num_frames, d_activity,
                                  max_aq_depth=3, rows=None, stream=None):

@@ -449,6 +449,26 @@ int fhevc_aq_parts(int width, int height, int max_aq_depth, long long* layer_off
   return (int)off;
 }
 
+int fhevc_aq_qp(const double* activity, const double* avg_activity, int width, int height, int max_aq_depth,
+                int qp_adaptation_range, int base_qp, int qp_bd_offset, int8_t* qp)
+{
+  long long off[5];
+  if (!activity || !avg_activity || !qp || fhevc_aq_parts(width, height, max_aq_depth, off) < 0) return FHEVC_E_INVALID;
+  if (base_qp < -qp_bd_offset || base_qp > 51 || qp_bd_offset < 0 || qp_bd_offset > 48) return FHEVC_E_INVALID;
+  const double max_q_scale = std::pow(2.0, qp_adaptation_range / 6.0);
+  for (int d = 0; d < max_aq_depth; ++d) {
+    const double avg = avg_activity[d];
+    for (long long i = off[d]; i < off[d + 1]; ++i) {
+      const double act = activity[i];
+      const double norm = (max_q_scale * act + avg) / (act + max_q_scale * avg);
+      const double qoff = std::log(norm) / std::log(2.0) * 6.0;
+      const int v = base_qp + (int)std::floor(qoff + 0.49999);
+      qp[i] = (int8_t)std::min(51, std::max(-qp_bd_offset, v));
+    }
+  }
+  return FHEVC_OK;
+}
+
 int fhevc_preanalyze_frames_device(fhevc_ctx* c, const void* d_luma, int sample_bytes, int stride_samples,
                                    long long frame_stride_samples, int num_frames, int ctu_row_begin, int ctu_row_end,
                                    int max_aq_depth, double* d_activity, void* stream)

@@ -124,6 +124,11 @@ int  fhevc_expand_depth_flags_device(fhevc_ctx* ctx, const uint32_t* d_flags, in
 int  fhevc_aq_parts(int width, int height, int max_aq_depth, long long* layer_offsets /* max_aq_depth + 1, may be NULL */);
 int  fhevc_preanalyze(fhevc_ctx* ctx, const int16_t* luma, int stride_samples, int max_aq_depth,
                       double* activity, double* avg_activity);
+/* == TEncCu::xComputeQP (TEncCu.cpp:1093-1117) for every AQ part: qp[i] = Clip3(-qp_bd_offset, 51, base_qp +
+ * floor(6*log2(normalised activity) + 0.49999)); activity/avg_activity/qp in fhevc_preanalyze's layout.  Runs on
+ * the host with the same libm calls HM makes (pow, log, floor), so the integers are HM's. */
+int  fhevc_aq_qp(const double* activity, const double* avg_activity, int width, int height, int max_aq_depth,
+                 int qp_adaptation_range, int base_qp, int qp_bd_offset, int8_t* qp);
 /* device-resident batch; d_activity holds num_frames * fhevc_aq_parts() doubles in whole-picture layout, of which
  * this call writes the parts inside CTU rows [ctu_row_begin, ctu_row_end) */
 int  fhevc_preanalyze_frames_device(fhevc_ctx* ctx, const void* d_luma, int sample_bytes, int stride_samples,

@@ -209,6 +209,16 @@ double fho_preanalyze_layer(const int16_t* luma, int stride, int width, int heig
   return sum_act / (nw * nh);
 }
 
+/* TEncCu.cpp:1093-1117 */
+int fho_aq_qp(double activity, double avg_activity, int qp_adaptation_range, int base_qp, int qp_bd_offset)
+{
+  const double max_q_scale = pow(2.0, qp_adaptation_range / 6.0);
+  const double norm = (max_q_scale * activity + avg_activity) / (activity + max_q_scale * avg_activity);
+  const double off = log(norm) / log(2.0) * 6.0;
+  const int qp = base_qp + (int)floor(off + 0.49999);
+  return qp < -qp_bd_offset ? -qp_bd_offset : (qp > 51 ? 51 : qp);
+}
+
 /* A11: TEncSlice.cpp:433-527 with GOPSize 1 (no B frames), I slice, lambda modifiers 1.0,
  * FULL_NBIT 0 (bitdepth_luma_qp_scale = 0): lambda = 0.57 * 2^((qp-12)/3). */
 double fho_lambda_intra(int qp, int bit_depth)

@@ -56,6 +56,9 @@ void    fho_frame_src_hadamard(const int16_t* luma, int stride, int width, int h
  * Returns the layer's average activity (sum in raster order / number of parts). */
 double fho_preanalyze_layer(const int16_t* luma, int stride, int width, int height, int part, double* activity);
 
+/* TEncCu::xComputeQP (TEncCu.cpp:1093-1117): QP of a CU from its AQ part's activity and the layer average */
+int fho_aq_qp(double activity, double avg_activity, int qp_adaptation_range, int base_qp, int qp_bd_offset);
+
 /* ---- A11: lambda (TEncSlice.cpp:433-527 calculateLambda, all-intra path) ----------------- */
 double fho_lambda_intra(int qp, int bit_depth);
 

@@ -128,6 +128,10 @@ def preanalyze_golden(ref):
         avg = np.zeros(depth)
         assert ref.href_preanalyze(op.ptr(buf.reshape(-1), org), stride, w, h, bd, depth, act, avg) == n
         out[f"act{k}"], out[f"avg{k}"] = act, avg
+        for range_, qp in ((6, 32), (12, 3), (4, 50)):  # TEncCu::xComputeQP on those activities (clips at both ends)
+            q = np.zeros(n, np.int32)
+            assert ref.href_aq_qp(op.ptr(buf.reshape(-1), org), stride, w, h, bd, depth, range_, qp, q) == n
+            out[f"qp{k}_r{range_}_q{qp}"] = q.astype(np.int8)
     dst = os.path.join(os.path.dirname(HERE), "tests", "golden", "ref_preanalyze.npz")
     np.savez_compressed(dst, **out)
     print("wrote", dst, os.path.getsize(dst), "bytes")

@@ -70,6 +70,8 @@ def load_oracle():
     lib.fho_frame_src_hadamard.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _i32p]
     lib.fho_preanalyze_layer.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")]
     lib.fho_preanalyze_layer.restype = C.c_double
+    lib.fho_aq_qp.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int, C.c_int]
+    lib.fho_aq_qp.restype = C.c_int
     lib.fho_lambda_intra.argtypes = [C.c_int, C.c_int]
     lib.fho_lambda_intra.restype = C.c_double
     lib.fho_fill_ref.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _i16p]
@@ -133,6 +135,9 @@ def load_ref(hook=False):
         f64 = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
         lib.href_preanalyze.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f64, f64]
         lib.href_preanalyze.restype = C.c_int
+        lib.href_aq_qp.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")]
+        lib.href_aq_qp.restype = C.c_int
     return lib
 
 

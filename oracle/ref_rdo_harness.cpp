@@ -370,6 +370,48 @@ int href_preanalyze(const int16_t* luma, int stride, int width, int height, int 
   return (int)k;
 }
 
+// TEncCu::xComputeQP (TEncCu.cpp:1093-1117) for the CU at the origin of every AQ part of every layer, after the
+// reference's own pre-analysis of `luma`: qp_out has the layout of href_preanalyze's activity array.
+int href_aq_qp(const int16_t* luma, int stride, int width, int height, int bit_depth, int max_aq_depth,
+               int qp_adaptation_range, int base_qp, int* qp_out)
+{
+  Encoder* e = get_encoder(width, height, bit_depth);
+  TEncPic pic;
+  pic.create(e->sps, e->pps, (UInt)max_aq_depth);
+  Pel* dst = pic.getPicYuvOrg()->getAddr(COMPONENT_Y);
+  const int s = pic.getPicYuvOrg()->getStride(COMPONENT_Y);
+  for (int y = 0; y < height; y++)
+    for (int x = 0; x < width; x++) dst[y * s + x] = (Pel)luma[(size_t)y * stride + x];
+  TEncPreanalyzer pre;
+  pre.xPreanalyze(&pic);
+  const bool aq_was = e->cfg.getUseAdaptiveQP();
+  const int range_was = e->cfg.getQPAdaptationRange();
+  e->cfg.setUseAdaptiveQP(true);
+  e->cfg.setQPAdaptationRange(qp_adaptation_range);
+  TComSlice slice;
+  slice.setSPS(&e->sps);
+  slice.setSliceQp(base_qp);
+  TComDataCU cu;  // only the fields xComputeQP reads are set
+  cu.m_pcPic = &pic;
+  cu.m_pcSlice = &slice;
+  size_t k = 0;
+  for (int d = 0; d < max_aq_depth; d++) {
+    const int part = 64 >> d;
+    for (int y = 0; y < height; y += part)
+      for (int x = 0; x < width; x += part) {
+        cu.m_uiCUPelX = (UInt)x;
+        cu.m_uiCUPelY = (UInt)y;
+        qp_out[k++] = e->cu.xComputeQP(&cu, (UInt)d);
+      }
+  }
+  cu.m_pcPic = nullptr;
+  cu.m_pcSlice = nullptr;
+  e->cfg.setUseAdaptiveQP(aq_was);
+  e->cfg.setQPAdaptationRange(range_was);
+  pic.destroy();
+  return (int)k;
+}
+
 // debugging aid: histograms of the decisions of the last encoded picture of that geometry
 int href_rdo_debug_hist(int width, int height, int bit_depth, int* modes35, int* part2, int* trdepth4, int* tskip2, int* cbf2)
 {

@@ -21,6 +21,17 @@ def _cases():
         yield luma, w, h, int(bd[2:]), int(depth[1:]), g[f"act{k}"], g[f"avg{k}"]
 
 
+def _qp_cases():
+    g = np.load(os.path.join(ROOT, "tests", "golden", "ref_preanalyze.npz"))
+    for k, name in enumerate(g["cases"]):
+        _, size, bd, depth = str(name).split(":")
+        w, h = (int(v) for v in size.split("x"))
+        for key in g.files:
+            if key.startswith(f"qp{k}_"):
+                _, r, q = key.split("_")
+                yield w, h, int(bd[2:]), int(depth[1:]), g[f"act{k}"], g[f"avg{k}"], int(r[1:]), int(q[1:]), g[key]
+
+
 def _layer_sizes(w, h, depth):
     return [((w + (64 >> d) - 1) // (64 >> d)) * ((h + (64 >> d) - 1) // (64 >> d)) for d in range(depth)]
 
@@ -59,6 +70,25 @@ def test_layout_helper_needs_no_device():
     assert lib.fhevc_aq_parts(1000, 568, 4, off) == sum(_layer_sizes(1000, 568, 4))
     assert list(off)[:2] == [0, 16 * 9]
     assert lib.fhevc_aq_parts(1000, 568, 5, None) == capi.E_INVALID
+
+
+def test_cu_qp_matches_reference_xcomputeqp(oracle):
+    """TEncCu::xComputeQP on the reference's activities: the oracle's restatement and the C-ABI host function."""
+    import ctypes as C
+    lib = capi.load_library()
+    n = clipped = 0
+    for w, h, bd, depth, act, avg, range_, base_qp, want in _qp_cases():
+        sizes = _layer_sizes(w, h, depth)
+        layer_of = np.repeat(np.arange(depth), sizes)
+        got = np.array([oracle.fho_aq_qp(float(a), float(avg[d]), range_, base_qp, 6 * (bd - 8)) for a, d in zip(act, layer_of)])
+        assert np.array_equal(got, want), (w, h, range_, base_qp)
+        out = np.zeros(act.size, np.int8)
+        assert lib.fhevc_aq_qp(act.ctypes.data, avg.ctypes.data, w, h, depth, range_, base_qp, 6 * (bd - 8), out.ctypes.data) == 0
+        assert np.array_equal(out, want), (w, h, range_, base_qp)
+        clipped += int(np.sum((want == 51) | (want == -6 * (bd - 8))))
+        n += 1
+    assert n == 9 and clipped > 0  # both clip ends are exercised by the fixture
+    assert lib.fhevc_aq_qp(None, None, 64, 64, 1, 6, 32, 0, None) == capi.E_INVALID
 
 
 @pytest.mark.gpu
