@@ -22,7 +22,7 @@ SYMBOLS = [
     "fhevc_create", "fhevc_destroy", "fhevc_set_weights", "fhevc_predict_frame", "fhevc_satd",
     "fhevc_intra_first_pass", "fhevc_predict_frames_device", "fhevc_band", "fhevc_kernel_timing",
     "fhevc_enable_kernel_timing", "fhevc_get_stats", "fhevc_last_error", "fhevc_version",
-    "fhevc_expand_depth_flags_device", "fhevc_aq_parts", "fhevc_preanalyze", "fhevc_preanalyze_frames_device", "fhevc_aq_qp",
+    "fhevc_expand_depth_flags_device", "fhevc_aq_parts", "fhevc_preanalyze", "fhevc_preanalyze_frames_device", "fhevc_aq_qp", "fhevc_intra_first_pass_device",
 ]
 
 
@@ -71,6 +71,8 @@ def load_library():
     lib.fhevc_predict_frame.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]
     lib.fhevc_satd.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32)]
     lib.fhevc_intra_first_pass.argtypes = [vp, vp, C.c_int, C.c_int, vp]
+    lib.fhevc_intra_first_pass_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_int,
+                                                  C.c_int, vp, vp]
     lib.fhevc_predict_frames_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_int,
                                                 C.c_int, vp, vp, vp, vp, vp]
     lib.fhevc_expand_depth_flags_device.argtypes = [vp, vp, C.c_int, vp, vp]
@@ -191,6 +193,13 @@ class Context:
         rb, re = rows if rows is not None else (0, self.ctus_y)
         self._check(self.lib.fhevc_preanalyze_frames_device(self.h, d_luma, sample_bytes, stride, frame_stride,
                                                             num_frames, rb, re, max_aq_depth, d_activity, stream))
+
+    def intra_first_pass_device(self, d_luma, sample_bytes, stride, frame_stride, num_frames, d_out, rows=None,
+                                stream=None, qp=32):
+        """d_out: device buffer of num_frames * band CTUs * 85 NODE_DTYPE entries (16 bytes each); asynchronous."""
+        rb, re = rows if rows is not None else (0, self.ctus_y)
+        self._check(self.lib.fhevc_intra_first_pass_device(self.h, d_luma, sample_bytes, stride, frame_stride, num_frames,
+                                                           rb, re, qp, d_out, stream))
 
     def predict_frames_device(self, d_luma, sample_bytes, stride, frame_stride, num_frames, d_depth, d_hadamard=None,
                               d_logits=None, rows=None, stream=None, qp=32, d_flags=None):

@@ -514,6 +514,26 @@ int fhevc_preanalyze(fhevc_ctx* c, const int16_t* luma, int stride_samples, int 
   return FHEVC_OK;
 }
 
+int fhevc_intra_first_pass_device(fhevc_ctx* c, const void* d_luma, int sample_bytes, int stride_samples,
+                                  long long frame_stride_samples, int num_frames, int ctu_row_begin, int ctu_row_end,
+                                  int qp, fhevc_node_cost* d_out, void* stream)
+{
+  if (!c || !d_luma || !d_out) return FHEVC_E_INVALID;
+  if ((sample_bytes != 1 && sample_bytes != 2) || stride_samples < c->cfg.width || num_frames < 1 || qp < 0 || qp > 51 ||
+      ctu_row_begin < 0 || ctu_row_end > c->ctus_y || ctu_row_begin > ctu_row_end)
+    return fail(c, FHEVC_E_INVALID, "bad first-pass arguments");
+  if (sample_bytes == 1 && c->cfg.bit_depth != 8) return fail(c, FHEVC_E_INVALID, "uint8 samples need bit depth 8");
+  hipSetDevice(c->device);
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  const double sqrt_lambda = std::sqrt(0.57 * std::pow(2.0, ((double)qp - 12.0) / 3.0));
+  const FhevcFrames fr = frames_of(c, d_luma, sample_bytes, stride_samples, frame_stride_samples, num_frames, ctu_row_begin, ctu_row_end);
+  time_begin(c, st, 2);
+  HIP_TRY(c, fhevc_launch_first_pass(fr, sqrt_lambda, reinterpret_cast<FhevcNodeCost*>(d_out), st));
+  time_end(c, st);
+  c->stats.kernels_launched++;
+  return FHEVC_OK;
+}
+
 // Diagnostic (not part of include/fasthevc.h): run the stamped instantiation of the depth kernel over a
 // device-resident batch and return per-phase cycle sums averaged over workgroups (P0..P5) + CTUs per workgroup.
 int fhevc_debug_cnn_phase_cycles(fhevc_ctx* c, const void* d_luma, int sample_bytes, int stride_samples,

@@ -99,6 +99,12 @@ int  fhevc_satd(fhevc_ctx* ctx, const int16_t* org, int org_stride, const int16_
  * (TEncSlice.cpp:433-527) would give it for qp; pass qp. */
 int  fhevc_intra_first_pass(fhevc_ctx* ctx, const int16_t* luma, int stride_samples, int qp, fhevc_node_cost* out);
 
+/* first pass over a device-resident batch (layout and band arguments as fhevc_predict_frames_device below);
+ * d_out: (num_frames * band CTUs) * 85 entries in HBM.  Asynchronous with respect to the host. */
+int  fhevc_intra_first_pass_device(fhevc_ctx* ctx, const void* d_luma, int sample_bytes, int stride_samples,
+                                   long long frame_stride_samples, int num_frames, int ctu_row_begin, int ctu_row_end,
+                                   int qp, fhevc_node_cost* d_out, void* stream);
+
 /* Device-resident batch: num_frames pictures already in HBM, CTU rows [ctu_row_begin, ctu_row_end) of each.
  * d_luma: sample_bytes = 2 -> int16 Pel plane(s) as HM lays them out, 1 -> uint8 (8-bit content);
  * frame f starts at d_luma + f * frame_stride_samples.  Outputs are device pointers, compact over the band:

@@ -1,0 +1,126 @@
+"""GPU parity at BASELINE.json's full sizes: config 3 (3840x2160, CTU rows sharded in 8 bands), config 5 (10-bit
+1080p: 16-bit pel planes) and the bench workload (a 64-frame 1080p GOP resident in HBM).  Bit-exact against the CPU
+oracle where it finishes in seconds, size-independent properties (band assembly, flag-word round trip, determinism,
+batch == single-picture calls) over everything else."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle_py as op
+from fasthevc_amd import bands, capi, frames, weights
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHIPPED = os.path.join(ROOT, "fasthevc_amd", "weights", "depthnet_v1.fhw")
+
+
+def _oracle(oracle, w, buf, org, stride, W, H, bd, qp):
+    cw, ch = frames.ctu_grid(W, H)
+    depth = np.zeros(cw * ch * 256, np.uint8)
+    oracle.fho_predict_frame(op.weights_from_arrays(w), op.ptr(buf.reshape(-1), org), stride, W, H, bd, qp, depth, None)
+    had = np.zeros(cw * ch, np.int32)
+    oracle.fho_frame_src_hadamard(op.ptr(buf.reshape(-1), org), stride, W, H, had)
+    return depth.reshape(-1, 256), had
+
+
+def test_config3_4k_eight_bands(oracle):
+    """3840x2160: 60x34 CTUs, last row 48 px tall.  The 8 CTU-row bands of an 8-rank node, launched one after the
+    other on this GPU, must assemble (through the 4-byte flag words the ranks all-gather) into the oracle's map."""
+    import torch
+    dev = torch.device("cuda:0")
+    W, H, QP = 3840, 2160, 32
+    w = weights.load(SHIPPED)
+    buf, org, stride = frames.to_pel_plane(frames.hetero_luma(W, H), 8)
+    depth_ref, had_ref = _oracle(oracle, w, buf, org, stride, W, H, 8, QP)
+    ctx = capi.Context(W, H, 8, w)
+    assert (ctx.ctus_x, ctx.ctus_y) == (60, 34)
+    d16 = torch.from_numpy(buf).to(dev)
+    flags = torch.zeros(ctx.num_ctus, dtype=torch.int32, device=dev)
+    had = torch.zeros(ctx.num_ctus, dtype=torch.int32, device=dev)
+    covered = 0
+    for rank in range(8):
+        rb, re = bands.band(ctx.ctus_y, rank, 8)
+        n = (re - rb) * ctx.ctus_x
+        part = torch.full((max(n, 1), 256), 7, dtype=torch.uint8, device=dev)
+        ctx.predict_frames_device(d16.data_ptr() + 2 * org, 2, stride, 0, 1, part.data_ptr(),
+                                  had[rb * ctx.ctus_x:].data_ptr() if n else None, None, rows=(rb, re), qp=QP,
+                                  d_flags=flags[rb * ctx.ctus_x:].data_ptr() if n else None)
+        torch.cuda.synchronize()
+        assert np.array_equal(part[:n].cpu().numpy(), depth_ref[rb * ctx.ctus_x:re * ctx.ctus_x]), rank
+        covered += n
+    assert covered == ctx.num_ctus
+    full = torch.zeros((ctx.num_ctus, 256), dtype=torch.uint8, device=dev)
+    ctx.expand_depth_flags_device(flags.data_ptr(), 1, full.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(full.cpu().numpy(), depth_ref)
+    assert np.array_equal(had.cpu().numpy(), had_ref)
+    assert set(np.unique(depth_ref)) == {0, 1, 2, 3}
+    ctx.close()
+
+
+def test_config5_10bit_1080p(oracle, golden):
+    """encoder_intra_main10 geometry: 8-bit content at InternalBitDepth 10 (samples << 2) in 16-bit pel planes."""
+    W, H, QP = 1920, 1080, 27
+    w = weights.load(SHIPPED)
+    buf, org, stride = frames.to_pel_plane(frames.hetero_luma(W, H), 10)
+    assert int(buf.max()) > 255
+    depth_ref, had_ref = _oracle(oracle, w, buf, org, stride, W, H, 10, QP)
+    ctx = capi.Context(W, H, 10, w)
+    depth, had = ctx.predict_frame(buf, org, stride, qp=QP)
+    assert np.array_equal(depth, depth_ref) and np.array_equal(had, had_ref)
+    # native 10-bit content (low bits populated): the classifier sees samples rounded to 8 bits, Hadamard sees all 10
+    rng = np.random.default_rng(11)
+    buf2 = buf.copy()
+    m = org % stride  # HM margin: origin = m * stride + m
+    inner = buf2[m:m + H, m:m + W]
+    inner[:] = np.clip(inner + rng.integers(0, 4, (H, W)), 0, 1023).astype(np.int16)
+    depth_ref2, had_ref2 = _oracle(oracle, w, buf2, org, stride, W, H, 10, QP)
+    depth2, had2 = ctx.predict_frame(buf2, org, stride, qp=QP)
+    assert np.array_equal(depth2, depth_ref2) and np.array_equal(had2, had_ref2)
+    assert not np.array_equal(had2, had_ref)
+    ctx.close()
+
+
+def test_bench_gop_64_frames_properties(oracle):
+    """The bench.py workload: 64 panned 1080p frames as HM-layout int16 planes in HBM, one launch."""
+    import torch
+    dev = torch.device("cuda:0")
+    W, H, NF, QP = 1920, 1080, 64, 32
+    w = weights.load(SHIPPED)
+    base = frames.hetero_luma(W, H)
+    lumas = [np.roll(base, 3 * f, axis=1) for f in range(NF)]
+    planes = np.stack([frames.to_pel_plane(y, 8)[0] for y in lumas])
+    _, org, stride = frames.to_pel_plane(base, 8)
+    ctx = capi.Context(W, H, 8, w, max_frames=NF)
+    n = ctx.num_ctus
+    d16 = torch.from_numpy(planes).to(dev)
+    fs = planes.shape[1] * planes.shape[2]
+
+    def run():
+        depth = torch.zeros((NF, n, 256), dtype=torch.uint8, device=dev)
+        had = torch.zeros((NF, n), dtype=torch.int32, device=dev)
+        flags = torch.zeros((NF, n), dtype=torch.int32, device=dev)
+        ctx.predict_frames_device(d16.data_ptr() + 2 * org, 2, stride, fs, NF, depth.data_ptr(), had.data_ptr(), None,
+                                  qp=QP, d_flags=flags.data_ptr())
+        torch.cuda.synchronize()
+        return depth, had, flags
+
+    depth, had, flags = run()
+    depth_b, had_b, flags_b = run()
+    assert torch.equal(depth, depth_b) and torch.equal(had, had_b) and torch.equal(flags, flags_b)  # deterministic
+    expanded = torch.zeros_like(depth)
+    ctx.expand_depth_flags_device(flags.data_ptr(), NF, expanded.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(expanded, depth)  # flag words carry the whole map, all 32 640 CTUs
+    dh, hh = depth.cpu().numpy(), had.cpu().numpy()
+    for f in (0, 31, 63):  # bit-exact against the oracle on sampled frames
+        dref, href = _oracle(oracle, w, planes[f], org, stride, W, H, 8, QP)
+        assert np.array_equal(dh[f], dref) and np.array_equal(hh[f], href), f
+    for f in (1, 40):  # batch == single-picture host-buffer entry point
+        d1, h1 = ctx.predict_frame(planes[f], org, stride, qp=QP)
+        assert np.array_equal(dh[f], d1) and np.array_equal(hh[f], h1), f
+    # panning permutes columns: the source Hadamard total over interior CTU rows changes, the map is not constant
+    assert len({int(hh[f].sum()) for f in range(NF)}) > 1
+    assert len(np.unique(dh)) == 4
+    ctx.close()

@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Secondary kernels of the path, timed on the GPU with the library's own HIP events (fhevc_kernel_timing):
+AQ pre-analysis (N3), source Hadamard on uint8 and int16 planes, and the 35-mode first pass (A4/A5).
+Prints one JSON object; bench.py remains the contract benchmark for the headline metric."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fasthevc_amd import capi, frames, weights  # noqa: E402
+
+W, H, NF = 1920, 1080, 64
+REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+dev = torch.device("cuda:0")
+torch.cuda.init()
+ctx = capi.Context(W, H, 8, weights.random_weights(0), max_frames=NF)
+ctx.enable_kernel_timing(True)
+base = frames.hetero_luma(W, H)
+planes = np.stack([frames.to_pel_plane(np.roll(base, 3 * f, axis=1), 8)[0] for f in range(NF)])
+_, org, stride = frames.to_pel_plane(base, 8)
+d16 = torch.from_numpy(planes).to(dev)
+fs = planes.shape[1] * planes.shape[2]
+d8 = torch.from_numpy(np.stack([np.roll(base, 3 * f, axis=1) for f in range(NF)])).to(dev)
+out = {"workload": f"{NF} frames {W}x{H}", "reps": REPS}
+
+# --- AQ pre-analysis, all four layers
+off = ctx.aq_layout(4)
+act = torch.zeros((NF, off[-1]), dtype=torch.float64, device=dev)
+for layout, ptr, sb, st, fstride in (("int16 HM planes", d16.data_ptr() + 2 * org, 2, stride, fs), ("uint8 packed", d8.data_ptr(), 1, W, W * H)):
+    for _ in range(3):
+        ctx.preanalyze_frames_device(ptr, sb, st, fstride, NF, act.data_ptr(), 4)
+    torch.cuda.synchronize()
+    ctx.kernel_timing(3, reset=True)
+    for _ in range(REPS):
+        ctx.preanalyze_frames_device(ptr, sb, st, fstride, NF, act.data_ptr(), 4)
+    torch.cuda.synchronize()
+    ms, n = ctx.kernel_timing(3, reset=True)
+    alg = NF * (W * H * sb + off[-1] * 8)
+    out[f"preanalyze[{layout}]"] = {"ms": ms, "launches": n, "algorithmic_bytes": alg, "GB/s": alg / ms / 1e6,
+                                    "frac_of_8TB/s": alg / ms / 1e6 / 8000}
+
+# --- source Hadamard alone (no CNN): d_depth is required by the entry point, so time through kernel_timing(1)
+depth = torch.zeros((NF, ctx.num_ctus, 256), dtype=torch.uint8, device=dev)
+had = torch.zeros((NF, ctx.num_ctus), dtype=torch.int32, device=dev)
+for layout, ptr, sb, st, fstride in (("int16 HM planes", d16.data_ptr() + 2 * org, 2, stride, fs), ("uint8 packed", d8.data_ptr(), 1, W, W * H)):
+    for _ in range(2):
+        ctx.predict_frames_device(ptr, sb, st, fstride, NF, depth.data_ptr(), had.data_ptr())
+    torch.cuda.synchronize()
+    ctx.kernel_timing(0, reset=True); ctx.kernel_timing(1, reset=True)
+    for _ in range(REPS):
+        ctx.predict_frames_device(ptr, sb, st, fstride, NF, depth.data_ptr(), had.data_ptr())
+    torch.cuda.synchronize()
+    ms_c, _ = ctx.kernel_timing(0, reset=True)
+    ms_h, n = ctx.kernel_timing(1, reset=True)
+    alg = NF * (W * H * sb + ctx.num_ctus * 4)
+    out[f"src_hadamard[{layout}]"] = {"ms": ms_h, "launches": n, "algorithmic_bytes": alg, "GB/s": alg / ms_h / 1e6}
+    out[f"depth_cnn[{layout}]"] = {"ms": ms_c, "Mctu/s": NF * ctx.num_ctus / ms_c / 1e3}
+
+# --- 35-mode first pass, one picture per call (host-buffer entry point; the kernel time excludes the copies)
+for _ in range(2):
+    ctx.intra_first_pass(planes[0], org, stride, qp=32)
+ctx.kernel_timing(2, reset=True)
+for f in range(min(REPS, 8)):
+    ctx.intra_first_pass(planes[f], org, stride, qp=32)
+ms, n = ctx.kernel_timing(2, reset=True)
+# integer work per CTU: 4 levels x 35 modes x 64 tiles x (64 predicted samples + ~575 Hadamard ops)
+ops = ctx.num_ctus * 4 * 35 * 64 * (64 + 575)
+out["first_pass[1 picture]"] = {"ms": ms, "launches": n, "ctu/s": ctx.num_ctus / ms * 1e3, "approx_int_ops": ops,
+                                "Tint-op/s": ops / ms / 1e9}
+# the same over a device-resident batch of 8 pictures in one launch
+NB = 8
+nodes = torch.zeros((NB * ctx.num_ctus * 85, 2), dtype=torch.float64, device=dev)  # 16 bytes per node
+for _ in range(2):
+    ctx.intra_first_pass_device(d16.data_ptr() + 2 * org, 2, stride, fs, NB, nodes.data_ptr(), qp=32)
+torch.cuda.synchronize()
+ctx.kernel_timing(2, reset=True)
+for _ in range(5):
+    ctx.intra_first_pass_device(d16.data_ptr() + 2 * org, 2, stride, fs, NB, nodes.data_ptr(), qp=32)
+torch.cuda.synchronize()
+ms, n = ctx.kernel_timing(2, reset=True)
+out[f"first_pass[{NB} pictures, device batch]"] = {"ms": ms, "launches": n, "ctu/s": NB * ctx.num_ctus / ms * 1e3,
+                                                  "Tint-op/s": NB * ops / ms / 1e9}
+print(json.dumps(out, indent=1))
+ctx.close()
