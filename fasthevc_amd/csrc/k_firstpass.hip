@@ -7,21 +7,41 @@
 //   cost = satd + modeBits * sqrt(lambda), strict '<' keeps the lower mode on ties (TEncSearch.cpp:2288,
 //   5385-5408).  Bit-exact against oracle/fhevc_oracle.c: fho_first_pass_ctu.
 //
-// One workgroup (256 threads) per CTU.  Integer VALU/LDS bound: no HBM re-reads (the CTU and the 85 reference
-// lines are staged in LDS once), work item = (level, mode, 8x8 tile): 4 levels x 35 modes x 64 tiles = 8960
-// items = exactly 35 per thread, the mode is wave-uniform, partial SATDs meet in LDS with integer atomics.
+// One workgroup (256 threads) per CTU, persistent over CTUs.  Integer VALU/LDS bound, no HBM re-reads:
+//   * the CTU, the row above it and the column left of it are staged in LDS once; the 85 reference lines are
+//     built from LDS (one thread per 4-sample unit for availability + copy, one thread per node for HM's
+//     substitution walk, one thread per sample for the smoothing);
+//   * lane = one 8x8 tile of the CTU for the whole CTU: the tile's original samples stay in registers as packed
+//     16-bit pairs; their transpose lives in LDS for the horizontal modes (sum|WHT(X^T)| = sum|WHT(X)|, so those are
+//     evaluated in the transposed frame without transposing the prediction back);
+//   * wave = one (mode, level) pair at a time, 140 pairs = 35 per wave: everything that depends on the mode is
+//     wave-uniform;
+//   * angular prediction, residual and Hadamard run on packed 16-bit VALU (two samples per lane-op) when the
+//     bit depth is <= 10 (the same boundary at which HM uses its 16-bit SIMD Hadamard, TComRdCost.cpp:1783):
+//     five butterfly stages between registers, the sixth (inside a packed pair) folded into the absolute sum with
+//     |a+b| + |a-b| = 2 max(|a|,|b|); 12-bit content takes the 32-bit path;
+//   * negative-angle modes read a per-wave projected main reference (HM's refMain extension) built once per
+//     (mode, level); tile SATDs meet per node through lane shuffles, no atomics.
 #include "fhevc_internal.h"
 
 namespace {
 
+typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
+typedef __attribute__((ext_vector_type(2))) short i16x2;
+
 constexpr int kLineTotal = 257 + 4 * 129 + 16 * 65 + 64 * 33;  // 3925 samples: all 85 lines of 4n+1
-// first sample of a level's lines / first node index of a level (levels: 64, 32, 16, 8)
+constexpr int kLinePad = 8;                                    // the unconditional second tap may touch one sample past a line
+constexpr int kUnits = 65 + 4 * 33 + 16 * 17 + 64 * 9;         // 1045 four-sample units (n+1 per node: TL is a unit)
+constexpr int kMainPerWave = 1088;                             // max over levels of nodes * (2n+1) projected samples
+// first sample of a level's lines / first node / first unit of a level (levels: 64, 32, 16, 8)
 __device__ __forceinline__ int line_off(int level) { return level == 0 ? 0 : (level == 1 ? 257 : (level == 2 ? 773 : 1813)); }
 __device__ __forceinline__ int node_off(int level) { return level == 0 ? 0 : (level == 1 ? 1 : (level == 2 ? 5 : 21)); }
+__device__ __forceinline__ int unit_off(int level) { return level == 0 ? 0 : (level == 1 ? 65 : (level == 2 ? 197 : 469)); }
 
 __constant__ int c_angTable[9] = { 0, 2, 5, 9, 13, 17, 21, 26, 32 };
 __constant__ int c_invAngTable[9] = { 0, 4096, 1638, 910, 630, 482, 390, 315, 256 };
 __constant__ int c_filterThr[5] = { 10, 7, 1, 0, 10 };  // TComPrediction.cpp:50-58 (4,8,16,32,64)
+
 // raster 16x16 -> z-order (Morton) of the 4x4 units of a CTU (TComRom.cpp:290-323)
 __device__ __forceinline__ int zorder_of(int ux, int uy)
 {
@@ -39,10 +59,22 @@ __device__ __forceinline__ bool unit_available(int ux, int uy, int x0, int y0, i
   return zorder_of((ux & 63) >> 2, (uy & 63) >> 2) < zorder_of((x0 & 63) >> 2, (y0 & 63) >> 2);
 }
 
-template <typename T>
-__device__ __forceinline__ int sample_at(const T* frame, int stride, int x, int y)
+// position (ux, uy) of 4-sample unit u of a node at (x0, y0) of size n, in HM's walk order: bottom-left unit first,
+// then up the left column, the top-left corner (one sample), then the row above left to right
+__device__ __forceinline__ void unit_pos(int u, int n, int x0, int y0, int& ux, int& uy)
 {
-  return (int)frame[(long long)y * stride + x];
+  const int L = n >> 1;
+  if (u < L) { ux = x0 - 4; uy = y0 + 4 * (L - 1 - u); }
+  else if (u == L) { ux = x0 - 4; uy = y0 - 4; }
+  else { ux = x0 + 4 * (u - L - 1); uy = y0 - 4; }
+}
+
+// a sample that an AVAILABLE unit covers: inside this CTU, in the row above it, or in the column left of it
+__device__ __forceinline__ short staged(const short* s_org, const short* s_above, const short* s_left, int px, int py, int ox, int oy)
+{
+  if (py >= oy && px >= ox) return s_org[(py - oy) * 64 + (px - ox)];
+  if (py < oy) return s_above[px - ox + 1];
+  return s_left[py - oy];
 }
 
 __device__ __forceinline__ void wht8x8(int d[64])
@@ -71,23 +103,150 @@ __device__ __forceinline__ void wht8x8(int d[64])
         }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void fhevc_first_pass_kernel(FhevcFrames F, double sqrt_lambda,
+__device__ __forceinline__ unsigned pk_sub(unsigned a, unsigned b)
+{
+  return __builtin_bit_cast(unsigned, (i16x2)(__builtin_bit_cast(i16x2, a) - __builtin_bit_cast(i16x2, b)));
+}
+__device__ __forceinline__ unsigned pk_add(unsigned a, unsigned b)
+{
+  return __builtin_bit_cast(unsigned, (i16x2)(__builtin_bit_cast(i16x2, a) + __builtin_bit_cast(i16x2, b)));
+}
+__device__ __forceinline__ unsigned pk_abs(unsigned a)
+{
+  const i16x2 v = __builtin_bit_cast(i16x2, a);
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(v, (i16x2)(-v)));
+}
+
+// (sum|WHT8x8(o - p)| + 2) >> 2 of one tile, rows packed as 4 dwords of two 16-bit samples.  |o - p| <= 1023, so the
+// five register-to-register stages stay below 2^15; the stage inside a packed pair is |a+b| + |a-b| = 2 max(|a|,|b|).
+__device__ __forceinline__ int satd8x8_packed(const unsigned (&o)[32], const unsigned (&p)[32])
+{
+  unsigned d[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) d[i] = pk_sub(o[i], p[i]);
+#pragma unroll
+  for (int hs = 1; hs < 8; hs <<= 1)  // vertical: rows y, y + hs
+#pragma unroll
+    for (int i = 0; i < 8; i += hs << 1)
+#pragma unroll
+      for (int y = i; y < i + hs; ++y)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const unsigned a = d[y * 4 + j], b = d[(y + hs) * 4 + j];
+          d[y * 4 + j] = pk_add(a, b); d[(y + hs) * 4 + j] = pk_sub(a, b);
+        }
+#pragma unroll
+  for (int hs = 1; hs < 4; hs <<= 1)  // horizontal distance 2 and 4: pairs j, j + hs
+#pragma unroll
+    for (int y = 0; y < 8; ++y)
+#pragma unroll
+      for (int i = 0; i < 4; i += hs << 1)
+#pragma unroll
+        for (int j = i; j < i + hs; ++j) {
+          const unsigned a = d[y * 4 + j], b = d[y * 4 + j + hs];
+          d[y * 4 + j] = pk_add(a, b); d[y * 4 + j + hs] = pk_sub(a, b);
+        }
+  unsigned acc = 0;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    const unsigned a = pk_abs(d[i]);
+    acc += max(a & 0xFFFFu, a >> 16);
+  }
+  return (int)((acc + 1) >> 1);  // (2 * acc + 2) >> 2
+}
+
+// general path (12-bit content): 32-bit butterflies
+__device__ __forceinline__ int satd8x8_wide(const unsigned (&o)[32], const unsigned (&p)[32])
+{
+  int d[64];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    d[2 * i] = (int)(short)(o[i] & 0xFFFF) - (int)(p[i] & 0xFFFF);
+    d[2 * i + 1] = (int)(short)(o[i] >> 16) - (int)(p[i] >> 16);
+  }
+  wht8x8(d);
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < 64; ++i) s += abs(d[i]);
+  return (s + 2) >> 2;
+}
+
+// eight rows of an angular predictor in the "vertical" frame: row yy reads nine consecutive main-reference samples
+// R[i0 .. i0+8] (STEP = +1 ascending in memory, -1 descending) and blends neighbours with weights (32 - df, df)
+template <int STEP>
+__device__ __forceinline__ void angular_rows(const short* mainp, int bxx, int byy, int angle, unsigned (&p)[32])
+{
+#pragma unroll
+  for (int yy = 0; yy < 8; ++yy) {
+    const int delta = (byy + yy + 1) * angle;
+    const int di = delta >> 5, df = delta & 31;
+    const short* rp = mainp + STEP * (bxx + di + 1);
+    unsigned short r[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) r[k] = (unsigned short)rp[STEP * k];
+    const u16x2 w0 = { (unsigned short)(32 - df), (unsigned short)(32 - df) }, w1 = { (unsigned short)df, (unsigned short)df };
+    const u16x2 c16 = { 16, 16 };
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const u16x2 a = { r[2 * j], r[2 * j + 1] }, b = { r[2 * j + 1], r[2 * j + 2] };
+      const u16x2 t = a * w0 + c16;  // two v_pk_mad_u16 and a shift; <= 32*1023 + 16: no 16-bit overflow up to 10 bits
+      const u16x2 v = (u16x2)((b * w1 + t) >> (u16x2){ 5, 5 });
+      p[yy * 4 + j] = __builtin_bit_cast(unsigned, v);
+    }
+  }
+}
+// the same with 32-bit arithmetic (12-bit content)
+template <int STEP>
+__device__ __forceinline__ void angular_rows_wide(const short* mainp, int bxx, int byy, int angle, unsigned (&p)[32])
+{
+#pragma unroll
+  for (int yy = 0; yy < 8; ++yy) {
+    const int delta = (byy + yy + 1) * angle;
+    const int di = delta >> 5, df = delta & 31;
+    const short* rp = mainp + STEP * (bxx + di + 1);
+    int r[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) r[k] = (int)rp[STEP * k];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int v0 = ((32 - df) * r[2 * j] + df * r[2 * j + 1] + 16) >> 5;
+      const int v1 = ((32 - df) * r[2 * j + 1] + df * r[2 * j + 2] + 16) >> 5;
+      p[yy * 4 + j] = (unsigned)v0 | ((unsigned)v1 << 16);
+    }
+  }
+}
+
+template <bool PACKED>
+__device__ __forceinline__ int satd8x8(const unsigned (&o)[32], const unsigned (&p)[32])
+{
+  return PACKED ? satd8x8_packed(o, p) : satd8x8_wide(o, p);
+}
+
+template <typename T, bool PACKED>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PACKED ? 3 : 1, PACKED ? 3 : 2))) void fhevc_first_pass_kernel(FhevcFrames F, double sqrt_lambda,
                                                                 FhevcNodeCost* __restrict__ out)
 {
-  __shared__ short s_org[64 * 64];
-  __shared__ short s_ref[kLineTotal];    // unfiltered lines, ref[2n] = TL, +i above, -j left
-  __shared__ short s_flt[kLineTotal];    // smoothed lines
+  // s_org holds the CTU while the lines are built; afterwards the same bytes are the four per-wave projected references
+  __shared__ __attribute__((aligned(16))) short s_org[4 * kMainPerWave];
+  __shared__ short s_refbuf[kLinePad + kLineTotal + kLinePad + 1];  // unfiltered lines, line[2n] = TL, +i above, -j left
+  __shared__ short s_fltbuf[kLinePad + kLineTotal + kLinePad + 1];  // smoothed lines
+  __shared__ __attribute__((aligned(16))) short s_orgT[64 * 64];     // the CTU transposed: row x, column y
+  __shared__ short s_above[132], s_left[64];
   __shared__ int s_satd[85 * 35];
   __shared__ int s_dc[85];
+  __shared__ unsigned char s_av[kUnits + 3];
   __shared__ unsigned char s_valid[85];
+  static_assert(4 * kMainPerWave >= 64 * 64, "the CTU must fit the shared region");
+  short* const s_ref = s_refbuf + kLinePad;
+  short* const s_flt = s_fltbuf + kLinePad;
 
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int band_rows = F.row_end - F.row_begin;
   const int per_frame = band_rows * F.ctus_x;
   const int total = per_frame * F.num_frames;
   const int bd = F.bit_depth;
   const int maxval = (1 << bd) - 1;
+  const int tx = (lane & 7) * 8, ty = (lane >> 3) * 8;  // this lane's tile inside the CTU
 
   for (int work = blockIdx.x; work < total; work += gridDim.x) {
     const int f = work / per_frame;
@@ -96,101 +255,118 @@ __global__ __launch_bounds__(256) void fhevc_first_pass_kernel(FhevcFrames F, do
     const T* frame = reinterpret_cast<const T*>(F.luma) + (long long)f * F.frame_stride;
     const int ox = cx * 64, oy = cy * 64;
 
-    // ---- A: stage the CTU, clear the SATD table, fill the 85 unfiltered reference lines ----
-    for (int i = tid; i < 64 * 64; i += 256) {
-      const int x = ox + (i & 63), y = oy + (i >> 6);
-      s_org[i] = (x < F.width && y < F.height) ? (short)sample_at(frame, F.stride, x, y) : (short)0;
+    // ---- A1: stage the CTU (16 samples per thread), the row above (129 samples) and the left column (64) ----
+    {
+      const int row = tid >> 2, seg = (tid & 3) * 16;
+      const int y = oy + row;
+      const T* src = frame + (long long)y * F.stride + ox + seg;
+      short* dst = &s_org[row * 64 + seg];
+      const bool whole = y < F.height && ox + seg + 16 <= F.width;
+      if (whole && sizeof(T) == 2 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        reinterpret_cast<uint4*>(dst)[0] = reinterpret_cast<const uint4*>(src)[0];
+        reinterpret_cast<uint4*>(dst)[1] = reinterpret_cast<const uint4*>(src)[1];
+      } else if (whole && sizeof(T) == 1 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        const uint4 q = *reinterpret_cast<const uint4*>(src);
+        const unsigned w[4] = { q.x, q.y, q.z, q.w };
+        unsigned o8[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o8[k] = ((w[k >> 1] >> (16 * (k & 1))) & 0xFF) | (((w[k >> 1] >> (16 * (k & 1) + 8)) & 0xFF) << 16);
+        reinterpret_cast<uint4*>(dst)[0] = make_uint4(o8[0], o8[1], o8[2], o8[3]);
+        reinterpret_cast<uint4*>(dst)[1] = make_uint4(o8[4], o8[5], o8[6], o8[7]);
+      } else {
+#pragma unroll 4
+        for (int k = 0; k < 16; ++k) dst[k] = (y < F.height && ox + seg + k < F.width) ? (short)src[k] : (short)0;
+      }
+      if (tid < 129) {
+        const int x = ox - 1 + tid;
+        s_above[tid] = (oy > 0 && x >= 0 && x < F.width) ? (short)frame[(long long)(oy - 1) * F.stride + x] : (short)0;
+      } else if (tid >= 192) {
+        const int yl = oy + tid - 192;
+        s_left[tid - 192] = (ox > 0 && yl < F.height) ? (short)frame[(long long)yl * F.stride + ox - 1] : (short)0;
+      }
+      if (tid < 85) {
+        const int level = tid < 1 ? 0 : (tid < 5 ? 1 : (tid < 21 ? 2 : 3));
+        const int n = 64 >> level, cnt = 1 << level, ni = tid - node_off(level);
+        s_valid[tid] = ((ox + (ni % cnt) * n + n <= F.width) && (oy + (ni / cnt) * n + n <= F.height)) ? 1 : 0;
+      }
     }
-    for (int i = tid; i < 85 * 35; i += 256) s_satd[i] = 0;
-    if (tid < 85) {
-      const int level = tid < 1 ? 0 : (tid < 5 ? 1 : (tid < 21 ? 2 : 3));
-      const int n = 64 >> level, cnt = 1 << level, ni = tid - node_off(level);
+    __syncthreads();
+
+    // ---- A2: one thread per 4-sample unit: availability (coding order) and, if available, its samples ----
+    for (int ug = tid; ug < kUnits; ug += 256) {
+      const int level = ug < 65 ? 0 : (ug < 197 ? 1 : (ug < 469 ? 2 : 3));
+      const int n = 64 >> level, cnt = 1 << level, upn = n + 1;
+      const int ni = (ug - unit_off(level)) / upn, u = (ug - unit_off(level)) - ni * upn;
       const int x0 = ox + (ni % cnt) * n, y0 = oy + (ni / cnt) * n;
-      const bool valid = (x0 + n <= F.width) && (y0 + n <= F.height);
-      s_valid[tid] = valid ? 1 : 0;
-      if (valid) {
-        short* ref = s_ref + line_off(level) + ni * (4 * n + 1);
-        // walk the line in HM's order: bottom-left unit first ... above-right unit last (4-sample units,
-        // TL is one unit of its own); unavailable units copy the previous sample, leading unavailable units
-        // copy the first available one (TComPattern.cpp:461-524); nothing available -> 1 << (bd-1) (:343-354)
-        const int L = n / 2, totalUnits = 2 * L + 1;
-        int firstAvail = -1;
-        for (int u = 0; u < totalUnits && firstAvail < 0; ++u) {
-          int ux, uy;
-          if (u < L) { ux = x0 - 4; uy = y0 + 4 * (L - 1 - u); }
-          else if (u == L) { ux = x0 - 4; uy = y0 - 4; }
-          else { ux = x0 + 4 * (u - L - 1); uy = y0 - 4; }
-          if (unit_available(ux, uy, x0, y0, F.width, F.height, F.ctus_x)) firstAvail = u;
-        }
-        if (firstAvail < 0) {
-          for (int i = 0; i < 4 * n + 1; ++i) ref[i] = (short)(1 << (bd - 1));
+      int ux, uy;
+      unit_pos(u, n, x0, y0, ux, uy);
+      const bool av = s_valid[node_off(level) + ni] && unit_available(ux, uy, x0, y0, F.width, F.height, F.ctus_x);
+      s_av[ug] = av ? 1 : 0;
+      if (av) {
+        short* line = s_ref + line_off(level) + ni * (4 * n + 1);
+        const int L = n >> 1;
+        if (u < L) {  // line[4u + i] = left sample 2n-1 - (4u+i), counted downwards from the top
+#pragma unroll
+          for (int i = 0; i < 4; ++i) line[4 * u + i] = staged(s_org, s_above, s_left, x0 - 1, y0 + 2 * n - 1 - (4 * u + i), ox, oy);
+        } else if (u == L) {
+          line[2 * n] = staged(s_org, s_above, s_left, x0 - 1, y0 - 1, ox, oy);
         } else {
-          int prev = 0;
-          for (int pass = 0; pass < 2; ++pass) {
-            // pass 0: find the value the leading unavailable units take; pass 1: fill
-            if (pass == 0) {
-              const int u = firstAvail;
-              if (u < L) prev = sample_at(frame, F.stride, x0 - 1, y0 + 4 * (L - 1 - u) + 3);        // bottom-most sample of the unit
-              else if (u == L) prev = sample_at(frame, F.stride, x0 - 1, y0 - 1);
-              else prev = sample_at(frame, F.stride, x0 + 4 * (u - L - 1), y0 - 1);
-              continue;
-            }
-            for (int u = 0; u < totalUnits; ++u) {
-              int ux, uy;
-              if (u < L) { ux = x0 - 4; uy = y0 + 4 * (L - 1 - u); }
-              else if (u == L) { ux = x0 - 4; uy = y0 - 4; }
-              else { ux = x0 + 4 * (u - L - 1); uy = y0 - 4; }
-              const bool av = unit_available(ux, uy, x0, y0, F.width, F.height, F.ctus_x);
-              if (u < L) {
-                // samples of this unit in line order (bottom -> top): ref[4u + i] = left sample (2n-1 - (4u+i))
-                for (int i = 0; i < 4; ++i) {
-                  const int j = 2 * n - 1 - (4 * u + i);  // left sample index counted downwards from the top
-                  if (av) prev = sample_at(frame, F.stride, x0 - 1, y0 + j);
-                  ref[4 * u + i] = (short)prev;
-                  if (!av) { /* keeps prev */ }
-                }
-              } else if (u == L) {
-                if (av) prev = sample_at(frame, F.stride, x0 - 1, y0 - 1);
-                ref[2 * n] = (short)prev;
-              } else {
-                for (int i = 0; i < 4; ++i) {
-                  const int k = 4 * (u - L - 1) + i;
-                  if (av) prev = sample_at(frame, F.stride, x0 + k, y0 - 1);
-                  ref[2 * n + 1 + k] = (short)prev;
-                }
-              }
-            }
-          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) line[4 * u - 3 + i] = staged(s_org, s_above, s_left, x0 + 4 * (u - L - 1) + i, y0 - 1, ox, oy);
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- A3: HM's substitution walk (TComPattern.cpp:461-524), one thread per node: unavailable units copy the last
+    // sample before them, leading unavailable units the first available sample; nothing available -> 1 << (bd-1) ----
+    if (tid < 85 && s_valid[tid]) {
+      const int level = tid < 1 ? 0 : (tid < 5 ? 1 : (tid < 21 ? 2 : 3));
+      const int n = 64 >> level, ni = tid - node_off(level), upn = n + 1, L = n >> 1;
+      short* line = s_ref + line_off(level) + ni * (4 * n + 1);
+      const unsigned char* av = s_av + unit_off(level) + ni * upn;
+      int first = -1;
+      for (int u = 0; u < upn && first < 0; ++u) if (av[u]) first = u;
+      if (first < 0) {
+        for (int i = 0; i < 4 * n + 1; ++i) line[i] = (short)(1 << (bd - 1));
+      } else {
+        short prev = line[first <= L ? 4 * first : 4 * first - 3];
+        for (int u = 0; u < upn; ++u) {
+          const int s = u <= L ? 4 * u : 4 * u - 3, c = (u == L) ? 1 : 4;
+          if (av[u]) prev = line[s + c - 1];
+          else for (int i = 0; i < c; ++i) line[s + i] = prev;
         }
       }
     }
     __syncthreads();
 
     // ---- B: smoothed lines (one thread per sample) and DC values (one thread per node) ----
-    for (int i = tid; i < kLineTotal; i += 256) {
-      const int level = i < 257 ? 0 : (i < 773 ? 1 : (i < 1813 ? 2 : 3));
-      const int n = 64 >> level, len = 4 * n + 1;
-      const int ni = (i - line_off(level)) / len, k = (i - line_off(level)) - ni * len;
-      if (!s_valid[node_off(level) + ni]) continue;
-      const short* ref = s_ref + line_off(level) + ni * len;
-      int v;
-      if (k == 0 || k == 4 * n) v = ref[k];
-      else {
-        bool strong = false;
-        if (n >= 32) {  // strong intra smoothing is on in the reference's configs (sps.getUseStrongIntraSmoothing)
-          const int thr = 1 << (bd - 5);
-          const int bl = ref[0], tl = ref[2 * n], tr = ref[4 * n];
-          strong = (abs(bl + tl - 2 * ref[n]) < thr) && (abs(tl + tr - 2 * ref[3 * n]) < thr);
-          if (strong) {
-            const int lg = (n == 32) ? 6 : 7;
-            if (k < 2 * n) v = ((2 * n - k) * bl + k * tl + n) >> lg;
-            else if (k == 2 * n) v = tl;
-            else v = ((2 * n - (k - 2 * n)) * tl + (k - 2 * n) * tr + n) >> lg;
+#pragma unroll
+    for (int level = 0; level < 4; ++level) {  // unrolled: sizes are compile-time constants, no runtime division
+      const int n = 64 >> level, len = 4 * n + 1, cnt = (1 << (2 * level)) * len;
+      for (int i = tid; i < cnt; i += 256) {
+        const int ni = i / len, k = i - ni * len;
+        if (!s_valid[node_off(level) + ni]) continue;
+        const short* ref = s_ref + line_off(level) + ni * len;
+        int v;
+        if (k == 0 || k == 4 * n) v = ref[k];
+        else {
+          bool strong = false;
+          if (n >= 32) {  // strong intra smoothing is on in the reference's configs (sps.getUseStrongIntraSmoothing)
+            const int thr = 1 << (bd - 5);
+            const int bl = ref[0], tl = ref[2 * n], tr = ref[4 * n];
+            strong = (abs(bl + tl - 2 * ref[n]) < thr) && (abs(tl + tr - 2 * ref[3 * n]) < thr);
+            if (strong) {
+              const int lg = (n == 32) ? 6 : 7;
+              if (k < 2 * n) v = ((2 * n - k) * bl + k * tl + n) >> lg;
+              else if (k == 2 * n) v = tl;
+              else v = ((2 * n - (k - 2 * n)) * tl + (k - 2 * n) * tr + n) >> lg;
+            }
           }
+          if (!strong) v = (ref[k - 1] + 2 * ref[k] + ref[k + 1] + 2) >> 2;
         }
-        if (!strong) v = (ref[k - 1] + 2 * ref[k] + ref[k + 1] + 2) >> 2;
+        s_flt[line_off(level) + i] = (short)v;
       }
-      s_flt[i] = (short)v;
     }
     if (tid < 85 && s_valid[tid]) {
       const int level = tid < 1 ? 0 : (tid < 5 ? 1 : (tid < 21 ? 2 : 3));
@@ -200,52 +376,79 @@ __global__ __launch_bounds__(256) void fhevc_first_pass_kernel(FhevcFrames F, do
       for (int i = 0; i < n; ++i) sum += ref[2 * n + 1 + i] + ref[2 * n - 1 - i];
       s_dc[tid] = (sum + n) / (2 * n);
     }
-    __syncthreads();
+    // this lane's tile stays in registers as packed pairs (low half = even column); its transpose goes to LDS
+    unsigned O[32];
+#pragma unroll
+    for (int y = 0; y < 8; ++y) {
+      const uint4 q = *reinterpret_cast<const uint4*>(&s_org[(ty + y) * 64 + tx]);
+      O[4 * y] = q.x; O[4 * y + 1] = q.y; O[4 * y + 2] = q.z; O[4 * y + 3] = q.w;
+    }
+#pragma unroll
+    for (int xx = 0; xx < 8; ++xx) {
+      unsigned t[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        t[j] = __builtin_amdgcn_perm(O[4 * (2 * j + 1) + (xx >> 1)], O[4 * (2 * j) + (xx >> 1)], (xx & 1) ? 0x07060302u : 0x05040100u);
+      *reinterpret_cast<uint4*>(&s_orgT[(tx + xx) * 64 + ty]) = make_uint4(t[0], t[1], t[2], t[3]);
+    }
+    __syncthreads();  // from here on s_org is the per-wave projected-reference scratch
 
-    // ---- C: 8960 (level, mode, tile) items ----
+    // ---- C: 140 (mode, level) pairs, 35 per wave; lane = tile ----
+    short* const wmain = s_org + wave * kMainPerWave;
+#pragma unroll 1
     for (int it = 0; it < 35; ++it) {
-      const int q = it * 256 + tid;
-      const int level = q / 2240, rq = q - level * 2240;
-      const int mode = rq >> 6, tile = rq & 63;
-      const int n = 64 >> level, lg = 6 - level, cnt = 1 << level;
-      const int tx = (tile & 7) * 8, ty = (tile >> 3) * 8;          // tile origin inside the CTU
-      const int ni = (ty / n) * cnt + (tx / n);
+      const int pr = __builtin_amdgcn_readfirstlane(wave + 4 * it);
+      const int mode = pr % 35, level = pr / 35;
+      const int n = 64 >> level, lg = 6 - level;
+      const int ni = ((ty >> lg) << level) + (tx >> lg);
       const int node = node_off(level) + ni;
-      if (!s_valid[node]) continue;
-      const int bx = tx & (n - 1), by = ty & (n - 1);                // tile origin inside the node
-      const int idx = 4 - level;  // size index of m_aucIntraFilter: 64->4, 32->3, 16->2, 8->1
-      bool use_flt = false;
-      if (mode != 1) use_flt = min(abs(mode - 10), abs(mode - 26)) > c_filterThr[idx];
-      const short* ref = (use_flt ? s_flt : s_ref) + line_off(level) + ni * (4 * n + 1) + 2 * n;  // ref[0] = TL
-      int d[64];
+      const int bx = tx & (n - 1), by = ty & (n - 1);  // tile origin inside the node
+      const int idx = 4 - level;                       // size index of m_aucIntraFilter: 64->4, 32->3, 16->2, 8->1
+      const bool use_flt = (mode != 1) && (min(abs(mode - 10), abs(mode - 26)) > c_filterThr[idx]);
+      const short* lines = (use_flt ? s_flt : s_ref) + line_off(level);
+      const short* ref = lines + ni * (4 * n + 1) + 2 * n;  // ref[0] = TL
+      // every branch ends in its own copy of the Hadamard: merging the branches first costs ~64 register moves per item
+      unsigned P[32];
+      int s;
       if (mode == 0) {
         const int topRight = ref[n + 1], bottomLeft = ref[-(n + 1)];
 #pragma unroll
         for (int y = 0; y < 8; ++y) {
           const int left = ref[-(by + y + 1)];
 #pragma unroll
-          for (int x = 0; x < 8; ++x) {
-            const int top = ref[bx + x + 1];
-            const int hor = (left << lg) + n + (bx + x + 1) * (topRight - left);
-            const int ver = (top << lg) + (by + y + 1) * (bottomLeft - top);
-            d[y * 8 + x] = (hor + ver) >> (lg + 1);
+          for (int j = 0; j < 4; ++j) {
+            unsigned v2[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              const int x = 2 * j + e;
+              const int top = ref[bx + x + 1];
+              const int hor = (left << lg) + n + (bx + x + 1) * (topRight - left);
+              const int ver = (top << lg) + (by + y + 1) * (bottomLeft - top);
+              v2[e] = (unsigned)((hor + ver) >> (lg + 1));
+            }
+            P[4 * y + j] = v2[0] | (v2[1] << 16);
           }
         }
+        s = satd8x8<PACKED>(O, P);
       } else if (mode == 1) {
-        const int dc = s_dc[node];
+        const unsigned dc = (unsigned)s_dc[node];
 #pragma unroll
-        for (int i = 0; i < 64; ++i) d[i] = dc;
+        for (int i = 0; i < 32; ++i) P[i] = dc | (dc << 16);
         if (n <= 16) {
           if (by == 0) {
 #pragma unroll
-            for (int x = 0; x < 8; ++x) d[x] = (ref[bx + x + 1] + 3 * dc + 2) >> 2;
+            for (int j = 0; j < 4; ++j) {
+              const unsigned a = (unsigned)((ref[bx + 2 * j + 1] + 3 * (int)dc + 2) >> 2), b = (unsigned)((ref[bx + 2 * j + 2] + 3 * (int)dc + 2) >> 2);
+              P[j] = a | (b << 16);
+            }
           }
           if (bx == 0) {
 #pragma unroll
-            for (int y = 0; y < 8; ++y) d[y * 8] = (ref[-(by + y + 1)] + 3 * dc + 2) >> 2;
+            for (int y = 0; y < 8; ++y) P[4 * y] = (P[4 * y] & 0xFFFF0000u) | (unsigned)((ref[-(by + y + 1)] + 3 * (int)dc + 2) >> 2);
           }
-          if (bx == 0 && by == 0) d[0] = (ref[1] + ref[-1] + 2 * dc + 2) >> 2;
+          if (bx == 0 && by == 0) P[0] = (P[0] & 0xFFFF0000u) | (unsigned)((ref[1] + ref[-1] + 2 * (int)dc + 2) >> 2);
         }
+        s = satd8x8<PACKED>(O, P);
       } else {
         const bool is_ver = mode >= 18;
         const int ang_mode = is_ver ? mode - 26 : -(mode - 10);
@@ -253,39 +456,51 @@ __global__ __launch_bounds__(256) void fhevc_first_pass_kernel(FhevcFrames F, do
         const int angle = (ang_mode < 0 ? -1 : 1) * c_angTable[abs_mode];
         const int inv_angle = c_invAngTable[abs_mode];
         const int sgn = is_ver ? 1 : -1;  // main(i) = ref[sgn*i], side(i) = ref[-sgn*i]
-        // coordinates in the "vertical" frame: (xx, yy) = is_ver ? (x, y) : (y, x)
+        // (xx, yy) = is_ver ? (x, y) : (y, x): horizontal modes are evaluated against the transposed tile
         const int bxx = is_ver ? bx : by, byy = is_ver ? by : bx;
+        if (angle < 0) {
+          // HM's refMain with its projected extension (TComPrediction.cpp:278-300), once per node of this level:
+          // entries k = (n*angle)>>5 .. n of node v at wmain[v*(2n+1) + n + k]
+          const int kmin = (n * angle) >> 5, span = 2 * n + 1;
+          const int v = lane & ((1 << (2 * level)) - 1), g = lane >> (2 * level), groups = 64 >> (2 * level);
+          const short* l = lines + v * (4 * n + 1) + 2 * n;
+          __builtin_amdgcn_wave_barrier();
+          for (int k = kmin + g; k <= n; k += groups)  // lane = (node v, every groups-th entry): no division
+            wmain[v * span + n + k] = (k >= 0) ? l[sgn * k] : l[-sgn * ((128 - k * inv_angle) >> 8)];
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          const short* mp = wmain + ni * span + n;
+          if (PACKED) angular_rows<1>(mp, bxx, byy, angle, P); else angular_rows_wide<1>(mp, bxx, byy, angle, P);
+        } else if (is_ver) {
+          if (PACKED) angular_rows<1>(ref, bxx, byy, angle, P); else angular_rows_wide<1>(ref, bxx, byy, angle, P);
+        } else {
+          if (PACKED) angular_rows<-1>(ref, bxx, byy, angle, P); else angular_rows_wide<-1>(ref, bxx, byy, angle, P);
+        }
+        if (angle == 0 && n <= 16 && bxx == 0) {  // edge filter of the pure vertical / horizontal modes (first column)
+          const int tl = ref[0];
 #pragma unroll
-        for (int yy = 0; yy < 8; ++yy) {
-          const int delta = (byy + yy + 1) * angle;
-          const int di = delta >> 5, df = delta & 31;
-#pragma unroll
-          for (int xx = 0; xx < 8; ++xx) {
-            const int i0 = bxx + xx + di + 1;
-            int a, b = 0;
-            a = (i0 >= 0) ? ref[sgn * i0] : ref[-sgn * ((128 - i0 * inv_angle) >> 8)];
-            int v = a;
-            if (df) {
-              const int i1 = i0 + 1;
-              b = (i1 >= 0) ? ref[sgn * i1] : ref[-sgn * ((128 - i1 * inv_angle) >> 8)];
-              v = ((32 - df) * a + df * b + 16) >> 5;
-            }
-            if (angle == 0 && n <= 16 && (bxx + xx) == 0)
-              v = min(maxval, max(0, v + ((ref[-sgn * (byy + yy + 1)] - ref[0]) >> 1)));
-            d[is_ver ? (yy * 8 + xx) : (xx * 8 + yy)] = v;
+          for (int yy = 0; yy < 8; ++yy) {
+            const int v = (int)(P[4 * yy] & 0xFFFF) + ((ref[-sgn * (byy + yy + 1)] - tl) >> 1);
+            P[4 * yy] = (P[4 * yy] & 0xFFFF0000u) | (unsigned)min(maxval, max(0, v));
           }
         }
+        if (is_ver) s = satd8x8<PACKED>(O, P);
+        else {
+          unsigned OT[32];
+#pragma unroll
+          for (int xx = 0; xx < 8; ++xx) {
+            const uint4 q = *reinterpret_cast<const uint4*>(&s_orgT[(tx + xx) * 64 + ty]);
+            OT[4 * xx] = q.x; OT[4 * xx + 1] = q.y; OT[4 * xx + 2] = q.z; OT[4 * xx + 3] = q.w;
+          }
+          s = satd8x8<PACKED>(OT, P);
+        }
       }
-      const short* org = s_org + ty * 64 + tx;
-#pragma unroll
-      for (int y = 0; y < 8; ++y)
-#pragma unroll
-        for (int x = 0; x < 8; ++x) d[y * 8 + x] = (int)org[y * 64 + x] - d[y * 8 + x];
-      wht8x8(d);
-      int s = 0;
-#pragma unroll
-      for (int i = 0; i < 64; ++i) s += abs(d[i]);
-      atomicAdd(&s_satd[node * 35 + mode], (s + 2) >> 2);
+      // tiles of one node meet through lane shuffles (lane = 8 * tile_row + tile_col)
+      if (level <= 2) { s += __shfl_xor(s, 1); s += __shfl_xor(s, 8); }
+      if (level <= 1) { s += __shfl_xor(s, 2); s += __shfl_xor(s, 16); }
+      if (level == 0) { s += __shfl_xor(s, 4); s += __shfl_xor(s, 32); }
+      const int own = level == 3 ? 0 : (level == 2 ? 9 : (level == 1 ? 27 : 63));
+      if ((lane & own) == 0 && s_valid[node]) s_satd[node * 35 + mode] = s;
     }
     __syncthreads();
 
@@ -315,10 +530,13 @@ hipError_t fhevc_launch_first_pass(const FhevcFrames& fr, double sqrt_lambda, Fh
 {
   const long long total = (long long)(fr.row_end - fr.row_begin) * fr.ctus_x * fr.num_frames;
   if (total <= 0) return hipSuccess;
-  const int grid = (int)(total < 4096 ? total : 4096);
-  if (fr.sample_bytes == 2)
-    hipLaunchKernelGGL(fhevc_first_pass_kernel<int16_t>, dim3(grid), dim3(256), 0, stream, fr, sqrt_lambda, d_out);
-  else
-    hipLaunchKernelGGL(fhevc_first_pass_kernel<uint8_t>, dim3(grid), dim3(256), 0, stream, fr, sqrt_lambda, d_out);
+  const int grid = (int)(total < 2048 ? total : 2048);
+  const bool packed = fr.bit_depth <= 10;
+  if (fr.sample_bytes == 2) {
+    if (packed) hipLaunchKernelGGL((fhevc_first_pass_kernel<int16_t, true>), dim3(grid), dim3(256), 0, stream, fr, sqrt_lambda, d_out);
+    else hipLaunchKernelGGL((fhevc_first_pass_kernel<int16_t, false>), dim3(grid), dim3(256), 0, stream, fr, sqrt_lambda, d_out);
+  } else {
+    hipLaunchKernelGGL((fhevc_first_pass_kernel<uint8_t, true>), dim3(grid), dim3(256), 0, stream, fr, sqrt_lambda, d_out);
+  }
   return hipGetLastError();
 }

@@ -7,8 +7,11 @@
 // average (a sequential double sum in raster order in the reference) is formed by the caller in that same order.
 //
 // One pass over the planar-Y picture for ALL layers: HBM-bound (each sample read once).  One lane owns one 8x8
-// block and reduces it to four 4x4-cell (sum, sum of squares) pairs in LDS; because picture sizes are multiples of
-// the minimum CU size (8), every quadrant of every (cropped) part is a rectangle of whole 4x4 cells.
+// block (one wave = one CTU) and reduces it to four 4x4-cell (sum, sum of squares) pairs.  Whole CTUs never touch
+// LDS: the quadrants of the 8/16/32/64 parts are the 4x4 / 8x8 / 16x16 / 32x32 sums, which meet through lane
+// shuffles (lane = 8 * block_row + block_col).  CTUs cropped by the picture edge take the general path: because
+// picture sizes are multiples of the minimum CU size (8), every quadrant of every cropped part is a rectangle of
+// whole 4x4 cells, summed from a per-wave LDS image.  No workgroup barriers: waves are independent.
 #include "fhevc_internal.h"
 
 namespace {
@@ -30,6 +33,13 @@ __device__ __forceinline__ double quad_var(QuadSum a, unsigned npix)
 {
   const double avg = __ddiv_rn((double)a.s, (double)npix);
   return __dsub_rn(__ddiv_rn((double)a.q, (double)npix), __dmul_rn(avg, avg));
+}
+
+// npix a power of two: x / npix == x * (1 / npix) bit for bit (scaling by a power of two is exact), no f64 division
+__device__ __forceinline__ double quad_var_pow2(QuadSum a, double inv_npix)
+{
+  const double avg = __dmul_rn((double)a.s, inv_npix);
+  return __dsub_rn(__dmul_rn((double)a.q, inv_npix), __dmul_rn(avg, avg));
 }
 
 template <typename T>
@@ -83,55 +93,79 @@ __global__ __launch_bounds__(256) void fhevc_preanalyze_kernel(FhevcFrames F, in
         }
       }
     }
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int ci = (2 * by + (c >> 1)) * 16 + 2 * bx + (c & 1);
-      cs[ci] = s4[c];
-      cq[ci] = q4[c];
-    }
-    // layer offsets of the caller's layout: layer d holds ceil(H/P) x ceil(W/P) doubles, P = 64 >> d
     double* fout = out + (long long)f * parts_per_frame;
-    if (layers > 3) {  // 8x8 parts: the lane's own four cells
-      long long off3 = 0;
-      for (int d = 0; d < 3; ++d) off3 += (long long)((F.width + (64 >> d) - 1) >> (6 - d)) * ((F.height + (64 >> d) - 1) >> (6 - d));
-      if (ok) {
-        double mv = 1.7976931348623157e308;
+    long long loff[4];  // layer offsets of the caller's layout: layer d holds ceil(H/P) x ceil(W/P) doubles, P = 64 >> d
+    loff[0] = 0;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) mv = fmin(mv, quad_var(QuadSum{ s4[c], q4[c] }, 16u));
-        const int nw = (F.width + 7) >> 3;
-        fout[off3 + (long long)(cy * 8 + by) * nw + cx * 8 + bx] = __dadd_rn(1.0, mv);
-      }
+    for (int d = 0; d < 3; ++d) loff[d + 1] = loff[d] + (long long)((F.width + (64 >> d) - 1) >> (6 - d)) * ((F.height + (64 >> d) - 1) >> (6 - d));
+    if (layers > 3 && ok) {  // 8x8 parts: the lane's own four cells (same on both paths)
+      double mv = 1.7976931348623157e308;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) mv = fmin(mv, quad_var_pow2(QuadSum{ s4[c], q4[c] }, 1.0 / 16.0));
+      fout[loff[3] + (long long)(cy * 8 + by) * ((F.width + 7) >> 3) + cx * 8 + bx] = __dadd_rn(1.0, mv);
     }
-    __syncthreads();
-    // layers 0..2: 1 + 4 + 16 parts x 4 quadrants = 84 (part, quadrant) items, two passes over the wave
+    const bool whole = live && vw == 64 && vh == 64;  // wave-uniform
+    if (whole) {
+      // quadrant sums by doubling: 8x8 (this lane), 16x16 (lanes ^1, ^8), 32x32 (lanes ^2, ^16); minima over the four
+      // quadrants of a part with the next pair of lane bits
+      unsigned long long S = (unsigned long long)s4[0] + s4[1] + s4[2] + s4[3];
+      unsigned long long Q = (unsigned long long)q4[0] + q4[1] + q4[2] + q4[3];
+#pragma unroll
+      for (int d = 2; d >= 0; --d) {
+        const int lo = 1 << (2 - d), hi = 8 << (2 - d);       // lane bits that enumerate the quadrants of a layer-d part
+        const double inv_npix = d == 2 ? 1.0 / 64.0 : (d == 1 ? 1.0 / 256.0 : 1.0 / 1024.0);  // quadrants of 8x8, 16x16, 32x32
+        if (d < layers) {
+          double var = quad_var_pow2(QuadSum{ S, Q }, inv_npix);
+          var = fmin(var, __shfl_xor(var, lo));
+          var = fmin(var, __shfl_xor(var, hi));
+          if ((bx & (2 * lo - 1)) == 0 && (by & (2 * lo - 1)) == 0) {  // one lane per part writes
+            const int nw = (F.width + (64 >> d) - 1) >> (6 - d);
+            const int gx = (cx << d) + (bx >> (3 - d)), gy = (cy << d) + (by >> (3 - d));
+            fout[loff[d] + (long long)gy * nw + gx] = __dadd_rn(1.0, var);
+          }
+        }
+        if (d > 0) {  // merge the four quadrants into the next size up
+          S += __shfl_xor(S, lo); S += __shfl_xor(S, hi);
+          Q += __shfl_xor(Q, lo); Q += __shfl_xor(Q, hi);
+        }
+      }
+    } else if (live) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int ci = (2 * by + (c >> 1)) * 16 + 2 * bx + (c & 1);
+        cs[ci] = s4[c];
+        cq[ci] = q4[c];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      // layers 0..2: 1 + 4 + 16 parts x 4 quadrants = 84 (part, quadrant) items, two passes over the wave
 #pragma unroll 1
-    for (int pass = 0; pass < 2; ++pass) {
-      const int it = pass * 64 + lane;
-      const int d = it < 4 ? 0 : (it < 20 ? 1 : 2);
-      const int first = d == 0 ? 0 : (d == 1 ? 4 : 20);
-      const int part = (it - first) >> 2, quad = it & 3;
-      const int pc = 16 >> d;                     // part size in cells
-      const int ox = (part & ((1 << d) - 1)) * pc, oy = (part >> d) * pc;
-      const int cw = min(pc, (vw >> 2) - ox), ch = min(pc, (vh >> 2) - oy);  // cropped part, in cells
-      const bool valid = live && it < 84 && d < layers && cw > 0 && ch > 0;
-      double var = 0.0;
-      if (valid) {
-        const int hw = cw >> 1, hh = ch >> 1;
-        const int x0 = ox + ((quad & 1) ? hw : 0), x1 = ox + ((quad & 1) ? cw : hw);
-        const int y0 = oy + ((quad & 2) ? hh : 0), y1 = oy + ((quad & 2) ? ch : hh);
-        var = quad_var(rect_sum(cs, cq, x0, x1, y0, y1), (unsigned)(hw * 4) * (unsigned)(hh * 4));
+      for (int pass = 0; pass < 2; ++pass) {
+        const int it = pass * 64 + lane;
+        const int d = it < 4 ? 0 : (it < 20 ? 1 : 2);
+        const int first = d == 0 ? 0 : (d == 1 ? 4 : 20);
+        const int part = (it - first) >> 2, quad = it & 3;
+        const int pc = 16 >> d;                     // part size in cells
+        const int ox = (part & ((1 << d) - 1)) * pc, oy = (part >> d) * pc;
+        const int cw = min(pc, (vw >> 2) - ox), ch = min(pc, (vh >> 2) - oy);  // cropped part, in cells
+        const bool valid = it < 84 && d < layers && cw > 0 && ch > 0;
+        double var = 0.0;
+        if (valid) {
+          const int hw = cw >> 1, hh = ch >> 1;
+          const int x0 = ox + ((quad & 1) ? hw : 0), x1 = ox + ((quad & 1) ? cw : hw);
+          const int y0 = oy + ((quad & 2) ? hh : 0), y1 = oy + ((quad & 2) ? ch : hh);
+          var = quad_var(rect_sum(cs, cq, x0, x1, y0, y1), (unsigned)(hw * 4) * (unsigned)(hh * 4));
+        }
+        var = fmin(var, __shfl_xor(var, 1));
+        var = fmin(var, __shfl_xor(var, 2));
+        if (valid && quad == 0) {
+          const int nw = (F.width + (64 >> d) - 1) >> (6 - d);
+          const int gx = cx * (1 << d) + (part & ((1 << d) - 1)), gy = cy * (1 << d) + (part >> d);
+          fout[loff[d] + (long long)gy * nw + gx] = __dadd_rn(1.0, var);
+        }
       }
-      var = fmin(var, __shfl_xor(var, 1));
-      var = fmin(var, __shfl_xor(var, 2));
-      if (valid && quad == 0) {
-        long long off = 0;
-        for (int e = 0; e < d; ++e) off += (long long)((F.width + (64 >> e) - 1) >> (6 - e)) * ((F.height + (64 >> e) - 1) >> (6 - e));
-        const int nw = (F.width + (64 >> d) - 1) >> (6 - d);
-        const int gx = cx * (1 << d) + (part & ((1 << d) - 1)), gy = cy * (1 << d) + (part >> d);
-        fout[off + (long long)gy * nw + gx] = __dadd_rn(1.0, var);
-      }
+      __builtin_amdgcn_wave_barrier();  // the next CTU of this wave overwrites the cell image
     }
-    __syncthreads();
   }
 }
 

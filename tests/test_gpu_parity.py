@@ -135,23 +135,68 @@ def test_device_batch_logits_and_bands(oracle, torch_cuda):
     ctx.close()
 
 
-def test_first_pass_vs_oracle(oracle):
+def _oracle_first_pass(oracle, buf, org, stride, W, H, bd, qp):
+    sl = oracle.fho_lambda_intra(qp, bd) ** 0.5
+    cw, ch = frames.ctu_grid(W, H)
+    exp = (op.NodeCost * 85)()
+    out = np.zeros((cw * ch, 85), capi.NODE_DTYPE)
+    for cy in range(ch):
+        for cx in range(cw):
+            oracle.fho_first_pass_ctu(op.ptr(buf.reshape(-1), org), stride, W, H, cx, cy, bd, sl, exp)
+            out[cy * cw + cx] = np.frombuffer(exp, dtype=capi.NODE_DTYPE)
+    return out
+
+
+def _same_nodes(got, exp, what):
+    for k in ("satd", "mode", "cost"):
+        bad = np.argwhere(got[k] != exp[k])
+        assert bad.size == 0, (what, k, bad[:4].tolist(), got[k][tuple(bad[0])], exp[k][tuple(bad[0])])
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+def test_first_pass_vs_oracle(oracle, bd):
+    """config 1 geometry (partial last CTU column and row); 8/10-bit take the packed 16-bit path, 12-bit the wide one."""
     luma = frames.texture16_luma(416, 240)
-    for bd in (8, 10):
-        buf, org, stride = frames.to_pel_plane(luma, bd)
-        ctx = capi.Context(416, 240, bd)
-        got = ctx.intra_first_pass(buf, org, stride, qp=32)
-        sl = oracle.fho_lambda_intra(32, bd) ** 0.5
-        exp = (op.NodeCost * 85)()
-        for cy in range(4):
-            for cx in range(7):
-                oracle.fho_first_pass_ctu(op.ptr(buf.reshape(-1), org), stride, 416, 240, cx, cy, bd, sl, exp)
-                e = np.frombuffer(exp, dtype=capi.NODE_DTYPE)
-                g = got[cy * 7 + cx]
-                assert np.array_equal(g["satd"], e["satd"]), (bd, cx, cy)
-                assert np.array_equal(g["mode"], e["mode"]), (bd, cx, cy)
-                assert np.array_equal(g["cost"], e["cost"]), (bd, cx, cy)
-        ctx.close()
+    buf, org, stride = frames.to_pel_plane(luma, bd)
+    if bd > 8:  # populate the low bits so that the arithmetic really runs at that depth
+        m = org % stride
+        rng = np.random.default_rng(bd)
+        buf[m:m + 240, m:m + 416] += rng.integers(0, 1 << (bd - 8), (240, 416)).astype(np.int16)
+    ctx = capi.Context(416, 240, bd)
+    for qp in (22, 37):
+        _same_nodes(ctx.intra_first_pass(buf, org, stride, qp=qp), _oracle_first_pass(oracle, buf, org, stride, 416, 240, bd, qp), (bd, qp))
+    ctx.close()
+
+
+def test_first_pass_1080p_and_device_batch(oracle, torch_cuda):
+    """config 2 geometry, all 510 CTUs (availability across CTU borders, above-right CTUs, the 56-px last row);
+    then the device-batch entry point: 3 pictures, a CTU-row band, uint8 and int16 layouts."""
+    torch = torch_cuda
+    dev = torch.device("cuda:0")
+    W, H, NF = 1920, 1080, 3
+    lumas = [frames.hetero_luma(W, H), frames.texture16_luma(W, H), np.random.default_rng(9).integers(0, 256, (H, W)).astype(np.uint8)]
+    planes = np.stack([frames.to_pel_plane(y, 8)[0] for y in lumas])
+    _, org, stride = frames.to_pel_plane(lumas[0], 8)
+    exp = [_oracle_first_pass(oracle, planes[f], org, stride, W, H, 8, 32) for f in range(NF)]
+    ctx = capi.Context(W, H, 8)
+    _same_nodes(ctx.intra_first_pass(planes[0], org, stride, qp=32), exp[0], "host")
+    n = ctx.num_ctus
+    d16 = torch.from_numpy(planes).to(dev)
+    out = torch.zeros((NF, n * 85, 2), dtype=torch.float64, device=dev)  # 16 bytes per node
+    ctx.intra_first_pass_device(d16.data_ptr() + 2 * org, 2, stride, planes.shape[1] * planes.shape[2], NF, out.data_ptr(), qp=32)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().view(capi.NODE_DTYPE).reshape(NF, n, 85)
+    for f in range(NF):
+        _same_nodes(got[f], exp[f], ("int16 batch", f))
+    d8 = torch.from_numpy(np.stack(lumas)).to(dev)
+    rb, re = 5, 11
+    band = torch.zeros((NF, (re - rb) * ctx.ctus_x * 85, 2), dtype=torch.float64, device=dev)
+    ctx.intra_first_pass_device(d8.data_ptr(), 1, W, W * H, NF, band.data_ptr(), rows=(rb, re), qp=32)
+    torch.cuda.synchronize()
+    gb = band.cpu().numpy().view(capi.NODE_DTYPE).reshape(NF, (re - rb) * ctx.ctus_x, 85)
+    for f in range(NF):
+        _same_nodes(gb[f], exp[f][rb * ctx.ctus_x:re * ctx.ctus_x], ("uint8 band", f))
+    ctx.close()
 
 
 def test_errors_are_status_codes():
