@@ -22,6 +22,7 @@ MAC_PER_CTU = 4096 * 9 * 16 + 1024 * 144 * 32 + 256 * 288 * 64 + (4096 + 4 * 409
 FLOP_PER_CTU = 2 * MAC_PER_CTU
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
+PEAK_INT32_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12  # 256 CUs x 4 SIMD x 16 lanes x 2.4 GHz: one 32-bit integer op per lane-cycle (39.3)
 
 
 def cpu_baseline(width, height, bit_depth, w, seconds=12.0):
@@ -89,6 +90,7 @@ def main():
     ap.add_argument("--bit-depth", type=int, default=8)
     ap.add_argument("--sample-bytes", type=int, default=2, help="2 = int16 Pel planes as HM holds them, 1 = uint8")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stages", action="store_true", help="skip the first-pass / pre-analysis stage report")
     args = ap.parse_args()
 
     import torch
@@ -167,6 +169,34 @@ def main():
         dt = float(t.item())
     cnn_ms, cnn_n = ctx.kernel_timing(0)
     had_ms, had_n = ctx.kernel_timing(1)
+
+    # the path's other stages (SURVEY 8(d) stage 3 and 8(f) N3), measured AFTER the timed region on the same GOP: the
+    # 35-mode SATD first pass over 8 of the frames and the AQ pre-analysis over all of them -- reported, never in `value`
+    stages = None
+    if rank == 0 and not args.no_stages:
+        nb = min(NF, 8)
+        nodes = torch.zeros((nb * n_ctus * 85, 2), dtype=torch.float64, device=dev)
+        act = torch.zeros((NF, ctx.aq_layout(4)[-1]), dtype=torch.float64, device=dev)
+        for timed in (False, True):
+            ctx.kernel_timing(2, reset=True)
+            ctx.kernel_timing(3, reset=True)
+            for _ in range(3):
+                ctx.intra_first_pass_device(luma_ptr, args.sample_bytes, stride, frame_stride, nb, nodes.data_ptr(), stream=stream, qp=32)
+                ctx.preanalyze_frames_device(luma_ptr, args.sample_bytes, stride, frame_stride, NF, act.data_ptr(), 4, stream=stream)
+            torch.cuda.synchronize()
+        fp_ms, _ = ctx.kernel_timing(2)
+        pre_ms, _ = ctx.kernel_timing(3)
+        int_ops = nb * n_ctus * 4 * 35 * 64 * (64 + 575)  # per (level, mode, 8x8 tile) 64 predicted samples + ~575 Hadamard ops
+        pre_bytes = NF * (W * H * args.sample_bytes + act.shape[1] * 8)
+        stages = {
+            "first_pass": {"kernel": "fhevc_first_pass_kernel", "frames": nb, "avg_launch_ms": fp_ms, "ctu_per_s": nb * n_ctus / (fp_ms * 1e-3),
+                           "bound": "int VALU/LDS", "achieved_Tintop_s": int_ops / (fp_ms * 1e-3) / 1e12, "peak_Tintop_s": PEAK_INT32_TOPS,
+                           "frac": int_ops / (fp_ms * 1e-3) / 1e12 / PEAK_INT32_TOPS,
+                           "vs_hadamard_time_per_frame": (fp_ms / nb) / (had_ms / NF) if had_ms else None},
+            "preanalyze": {"kernel": "fhevc_preanalyze_kernel", "frames": NF, "avg_launch_ms": pre_ms, "bound": "hbm",
+                           "achieved_GB_s": pre_bytes / (pre_ms * 1e-3) / 1e9, "peak_GB_s": PEAK_HBM_GBS,
+                           "frac": pre_bytes / (pre_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
+        }
     ctx.enable_kernel_timing(False)
 
     def measured_traffic(kernel):
@@ -207,6 +237,8 @@ def main():
                        "sharding": "frames dealt to ranks + one all-gather of the depth maps (as 4-byte split-flag words per CTU, expanded on every rank)" if world > 1 else "single GPU"},
             "roofline": roof, "roofline_hbm_kernel": hbm,
         }
+        if stages:
+            line["stages"] = stages
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(W, H, bd, w)
         print(json.dumps(line), flush=True)

@@ -15,7 +15,7 @@ for p in sorted(glob.glob(src + "/pass*/*/*_counter_collection.csv")):
     for r in csv.DictReader(open(p)):
         if "fhevc" not in r["Kernel_Name"]:
             continue
-        k = r["Kernel_Name"].split("(anonymous namespace)::")[-1].split("(")[0]
+        k = r["Kernel_Name"].split("(anonymous namespace)::")[-1].split("(")[0] + "@grid" + r["Grid_Size"]
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         seen[k].add(r["Dispatch_Id"])
     for k in agg:

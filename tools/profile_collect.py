@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Copy the summaries of gpurun_out/<tag>/ (tools/profile_round.sh) into profiles/ under the round's names."""
+import glob
+import os
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src, dst = os.path.join(root, "gpurun_out", tag), os.path.join(root, "profiles")
+pairs = {
+    "bench_default.log": f"{tag}_bench_default.log",
+    "bench_under_rocprof.json": f"{tag}_bench_under_rocprof.json",
+    "bench_kernels.json": f"{tag}_bench_kernels.json",
+    "pmc_bench.json": f"{tag}_pmc_bench_frames64_int16.json",
+    "pmc_kernels.json": f"{tag}_pmc_kernels.json",
+}
+for a, b in pairs.items():
+    shutil.copyfile(os.path.join(src, a), os.path.join(dst, b))
+stats = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))
+assert len(stats) == 1, stats
+shutil.copyfile(stats[0], os.path.join(dst, f"{tag}_kernel_stats_bench_default.csv"))
+print("collected", sorted(os.listdir(dst)))
