@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--sample-bytes", type=int, default=2, help="2 = int16 Pel planes as HM holds them, 1 = uint8")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stages", action="store_true", help="skip the first-pass / pre-analysis stage report")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse)")
+    ap.add_argument("--one-device", action="store_true", help="rehearsal on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
 
     import torch
@@ -102,10 +104,16 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.one_device:
+        assert args.backend != "nccl", "RCCL refuses two ranks on one GPU"
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     W, H, NF, bd = args.width, args.height, args.frames, args.bit_depth
     trained = os.path.join(ROOT, "fasthevc_amd", "weights", "depthnet_v1.fhw")
