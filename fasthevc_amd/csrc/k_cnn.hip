@@ -21,6 +21,7 @@
 //     lane holds all four pre-pool outputs of its pooled position: the pool is three in-lane max, no DPP;
 //   * the next CTU's samples are prefetched into registers while the heads of the current one run.
 #include "fhevc_internal.h"
+#include <cstdlib>
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -136,13 +137,12 @@ __device__ __forceinline__ void conv1_store(const f32x16& acc0, const f32x16& ac
 }
 // conv2: two output rows -> 2x2 max-pool, requant, store: the even lane of a horizontal pair finishes planes 0-1
 // (regs 0-7), the odd lane planes 2-3 (regs 8-15): 8 requants and two 8-byte stores per lane
-__device__ __forceinline__ void conv2_store(const f32x16& acc0, const f32x16& acc1, const float* bias32, float scale,
+// bb: the pre-scaled biases of the 8 channels this lane stores, read ONCE per phase: an LDS read inside the epilogue
+// makes the compiler drain lgkmcnt to 0 there, i.e. wait for every fragment read the ring has in flight
+__device__ __forceinline__ void conv2_store(const f32x16& acc0, const f32x16& acc1, const float (&bb)[8], float scale,
                                             unsigned char* lds, int yp, int r, int h)
 {
   const bool odd = r & 1;
-  const float* bp = bias32 + (odd ? 16 : 0) + 4 * h;   // pre-scaled bias of the channels this lane stores
-  const float4 bA = *reinterpret_cast<const float4*>(bp), bB = *reinterpret_cast<const float4*>(bp + 8);
-  const float bb[8] = { bA.x, bA.y, bA.z, bA.w, bB.x, bB.y, bB.z, bB.w };
   float v[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
@@ -159,10 +159,8 @@ __device__ __forceinline__ void conv2_store(const f32x16& acc0, const f32x16& ac
 // floor() for every multiple of 2^-s (exact while shift <= 14): fma + cvt = floor + ReLU + clamp + pack
 // dst = start of the position's 64-byte row + 4*h; channel 32*tile + 8*g + 4*h + k lives in logical 16-B chunk
 // 2*tile + (g >> 1), at byte 8*(g & 1) + 4*h + k; psw = chunk swizzle of this position
-__device__ __forceinline__ void conv3_store(const f32x16& acc, const float* bias32, int h, float scale, unsigned char* dst,
-                                            int tile, int psw)
+__device__ __forceinline__ void conv3_store(const f32x16& acc, const f32x16& b, float scale, unsigned char* dst, int tile, int psw)
 {
-  const f32x16 b = bias_tile(bias32, h);
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     unsigned d = 0;
@@ -188,40 +186,59 @@ __device__ __forceinline__ void sched_chain18()
   }
 }
 // conv2 MFMA chain of one unit = output rows 2yp, 2yp+1 (32 positions each), K = 9 taps x 16 channels:
-// 12 fragments (4 input rows x 3 kx), 18 MFMAs (rows 1, 2 feed both accumulators)
-__device__ __forceinline__ void conv2_unit(const unsigned char* a1, int yp, const bf16x8 (&wA2)[9], f32x16& acc0, f32x16& acc1)
+// 12 fragments (4 input rows x 3 kx), 18 MFMAs (rows 1, 2 feed both accumulators).  The fragment ring runs ACROSS
+// units: the last RING reads of a unit fetch the first fragments of the next one, so only the first unit of a phase
+// exposes the LDS latency (a per-unit preload costs ~4 exposed reads = ~500 cycles per unit).
+__device__ __forceinline__ const unsigned char* conv2_frag(const unsigned char* base, int f)
+{
+  return base + ((f / 3) * A1_PITCH + (f % 3)) * 16;
+}
+template <bool FIRST, bool LAST>
+__device__ __forceinline__ void conv2_unit(const unsigned char* a1, int yp, int yp_next, const bf16x8 (&wA2)[9], bf16x8 (&ring)[RING],
+                                           f32x16& acc0, f32x16& acc1)
 {
 #pragma unroll
   for (int k = 0; k < 16; ++k) { acc0[k] = 0.0f; acc1[k] = 0.0f; }
   const unsigned char* base = a1 + (2 * yp) * A1_PITCH * 16;  // halo rows 2yp .. 2yp+3
-  bf16x8 ring[RING];
+  const unsigned char* next = a1 + (2 * yp_next) * A1_PITCH * 16;
+  if (FIRST) {
 #pragma unroll
-  for (int f = 0; f < RING; ++f) ring[f] = lds_frag(base + ((f / 3) * A1_PITCH + (f % 3)) * 16);
+    for (int f = 0; f < RING; ++f) ring[f] = lds_frag(conv2_frag(base, f));
+  }
 #pragma unroll
-  for (int f = 0; f < 12; ++f) {
+  for (int f = 0; f < 12; ++f) {  // 12 % RING == 0: ring slots line up from unit to unit
     const int ir = f / 3, kx = f % 3;
     const bf16x8 b = ring[f % RING];
     if (ir < 3) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA2[ir * 3 + kx], b, acc0, 0, 0, 0);
     if (ir > 0) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA2[(ir - 1) * 3 + kx], b, acc1, 0, 0, 0);
-    if (f + RING < 12) ring[f % RING] = lds_frag(base + (((f + RING) / 3) * A1_PITCH + ((f + RING) % 3)) * 16);
+    if (f + RING < 12) ring[f % RING] = lds_frag(conv2_frag(base, f + RING));
+    else if (!LAST) ring[f % RING] = lds_frag(conv2_frag(next, f + RING - 12));
   }
 }
-// conv3 MFMA chain of one unit = 32 output channels x 32 positions (rows 2yp, 2yp+1), K = 9 taps x 32 channels
-__device__ __forceinline__ f32x16 conv3_unit(const unsigned char* a2, int yp, const bf16x8 (&wA3)[18])
+// conv3 MFMA chain of one unit = 32 output channels x 32 positions (rows 2yp, 2yp+1), K = 9 taps x 32 channels;
+// the ring runs across units as in conv2 (18 % RING == 2: PHASE = ring slot of this unit's fragment 0)
+__device__ __forceinline__ const unsigned char* conv3_frag(const unsigned char* base, int s)
+{
+  return base + 2 * (s & 1) * A2_PLANE + (((s >> 1) / 3) * A2_PITCH + ((s >> 1) % 3)) * 16;
+}
+template <bool FIRST, bool LAST, int PHASE>
+__device__ __forceinline__ f32x16 conv3_unit(const unsigned char* a2, int yp, int yp_next, const bf16x8 (&wA3)[18], bf16x8 (&ring)[RING])
 {
   f32x16 acc;
 #pragma unroll
   for (int k = 0; k < 16; ++k) acc[k] = 0.0f;
   const unsigned char* base = a2 + (2 * yp) * A2_PITCH * 16;
-  bf16x8 ring[RING];
+  const unsigned char* next = a2 + (2 * yp_next) * A2_PITCH * 16;
+  if (FIRST) {
 #pragma unroll
-  for (int s = 0; s < RING; ++s)
-    ring[s] = lds_frag(base + 2 * (s & 1) * A2_PLANE + (((s >> 1) / 3) * A2_PITCH + ((s >> 1) % 3)) * 16);
+    for (int s = 0; s < RING; ++s) ring[(s + PHASE) % RING] = lds_frag(conv3_frag(base, s));
+  }
 #pragma unroll
   for (int s = 0; s < 18; ++s) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA3[s], ring[s % RING], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA3[s], ring[(s + PHASE) % RING], acc, 0, 0, 0);
     const int n = s + RING;
-    if (n < 18) ring[s % RING] = lds_frag(base + 2 * (n & 1) * A2_PLANE + (((n >> 1) / 3) * A2_PITCH + ((n >> 1) % 3)) * 16);
+    if (n < 18) ring[(s + PHASE) % RING] = lds_frag(conv3_frag(base, n));
+    else if (!LAST) ring[(s + PHASE) % RING] = lds_frag(conv3_frag(next, n - 18));
   }
   return acc;
 }
@@ -341,8 +358,11 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
   const int r = lane & 31, h = lane >> 5;
 
   // ---- resident weight fragments (A operands) ----
-  const bf16x8 wA1a = __builtin_bit_cast(bf16x8, W.frag[FHEVC_FRAG_CONV1 + lane]);
-  const bf16x8 wA1b = __builtin_bit_cast(bf16x8, W.frag[FHEVC_FRAG_CONV1 + 64 + lane]);
+  // conv1's two fragments are only live from the end of a CTU's heads to its conv1: they are re-fetched (L2-hot) under
+  // the heads of the previous CTU, which frees 8 registers in the conv2 phase, the tightest one
+  const uint4* frag1p = W.frag + FHEVC_FRAG_CONV1 + lane;
+  bf16x8 wA1a = __builtin_bit_cast(bf16x8, frag1p[0]);
+  bf16x8 wA1b = __builtin_bit_cast(bf16x8, frag1p[64]);
   bf16x8 wA2[9];
 #pragma unroll
   for (int s = 0; s < 9; ++s) wA2[s] = __builtin_bit_cast(bf16x8, W.frag[FHEVC_FRAG_CONV2 + s * 64 + lane]);
@@ -457,19 +477,27 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
       const unsigned char* a1p = lds + R1_OFF + h * A1_PLANE + r * 16;
       // straight-line software pipeline over the wave's 4 units: the MFMA chain of unit i+1 is issued before the
       // VALU epilogue of unit i, so the scheduler can interleave them (separate pipes)
+      float bb2[8];  // pre-scaled bias of the channels this lane stores (even lane: planes 0-1, odd lane: planes 2-3)
+      {
+        const float* bp = biasL + 16 + ((r & 1) ? 16 : 0) + 4 * h;
+        const float4 bA = *reinterpret_cast<const float4*>(bp), bB = *reinterpret_cast<const float4*>(bp + 8);
+        bb2[0] = bA.x; bb2[1] = bA.y; bb2[2] = bA.z; bb2[3] = bA.w; bb2[4] = bB.x; bb2[5] = bB.y; bb2[6] = bB.z; bb2[7] = bB.w;
+      }
       f32x16 a0, a1, b0, b1;
-      conv2_unit(a1p, wave, wA2, a0, a1);
+      bf16x8 ring[RING];
+      conv2_unit<true, false>(a1p, wave, wave + 4, wA2, ring, a0, a1);
+      __builtin_amdgcn_sched_group_barrier(0x100, RING + 2, 0);  // bias + the ring's first fragments go out together
       sched_chain18<0>();
-      conv2_unit(a1p, wave + 4, wA2, b0, b1);
-      conv2_store(a0, a1, biasL + 16, W.scale[1], lds, wave, r, h);
+      conv2_unit<false, false>(a1p, wave + 4, wave + 8, wA2, ring, b0, b1);
+      conv2_store(a0, a1, bb2, W.scale[1], lds, wave, r, h);
       sched_chain18<5>();
-      conv2_unit(a1p, wave + 8, wA2, a0, a1);
-      conv2_store(b0, b1, biasL + 16, W.scale[1], lds, wave + 4, r, h);
+      conv2_unit<false, false>(a1p, wave + 8, wave + 12, wA2, ring, a0, a1);
+      conv2_store(b0, b1, bb2, W.scale[1], lds, wave + 4, r, h);
       sched_chain18<5>();
-      conv2_unit(a1p, wave + 12, wA2, b0, b1);
-      conv2_store(a0, a1, biasL + 16, W.scale[1], lds, wave + 8, r, h);
+      conv2_unit<false, true>(a1p, wave + 12, wave + 12, wA2, ring, b0, b1);
+      conv2_store(a0, a1, bb2, W.scale[1], lds, wave + 8, r, h);
       sched_chain18<5>();
-      conv2_store(b0, b1, biasL + 16, W.scale[1], lds, wave + 12, r, h);
+      conv2_store(b0, b1, bb2, W.scale[1], lds, wave + 12, r, h);
     }
     __syncthreads();
     FHEVC_STAMP(2)
@@ -486,18 +514,21 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
       const int psw = (x >> 2) & 3;  // ((yy * 16 + x) >> 2) & 3, rows are 16 positions
       unsigned char* a3dst = lds + A3_OFF + (yy * 16 + x) * 64 + 4 * h;
       const int yp0 = wave >> 1;
-      f32x16 accA = conv3_unit(a2, yp0, wA3);
+      const f32x16 b3 = bias_tile(bias3, h);  // once per phase (see conv2_store)
+      bf16x8 ring[RING];
+      f32x16 accA = conv3_unit<true, false, 0>(a2, yp0, yp0 + 2, wA3, ring);
+      __builtin_amdgcn_sched_group_barrier(0x100, RING + 4, 0);
       sched_chain18<0>();
-      f32x16 accB = conv3_unit(a2, yp0 + 2, wA3);
-      conv3_store(accA, bias3, h, W.scale[2], a3dst + (yp0 + 0) * 2048, tile3, psw);
+      f32x16 accB = conv3_unit<false, false, 2>(a2, yp0 + 2, yp0 + 4, wA3, ring);
+      conv3_store(accA, b3, W.scale[2], a3dst + (yp0 + 0) * 2048, tile3, psw);
       sched_chain18<4>();
-      accA = conv3_unit(a2, yp0 + 4, wA3);
-      conv3_store(accB, bias3, h, W.scale[2], a3dst + (yp0 + 2) * 2048, tile3, psw);
+      accA = conv3_unit<false, false, 0>(a2, yp0 + 4, yp0 + 6, wA3, ring);
+      conv3_store(accB, b3, W.scale[2], a3dst + (yp0 + 2) * 2048, tile3, psw);
       sched_chain18<4>();
-      accB = conv3_unit(a2, yp0 + 6, wA3);
-      conv3_store(accA, bias3, h, W.scale[2], a3dst + (yp0 + 4) * 2048, tile3, psw);
+      accB = conv3_unit<false, true, 2>(a2, yp0 + 6, yp0 + 6, wA3, ring);
+      conv3_store(accA, b3, W.scale[2], a3dst + (yp0 + 4) * 2048, tile3, psw);
       sched_chain18<4>();
-      conv3_store(accB, bias3, h, W.scale[2], a3dst + (yp0 + 6) * 2048, tile3, psw);
+      conv3_store(accB, b3, W.scale[2], a3dst + (yp0 + 6) * 2048, tile3, psw);
     }
     __syncthreads();
     FHEVC_STAMP(3)
@@ -555,6 +586,12 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
         atomicAdd(&logitL[0], q64a);      // four waves meet in the 64-level logits
         atomicAdd(&logitL[1], q64b);
       }
+    }
+    {
+      const uint4* fp = frag1p;
+      asm volatile("" : "+v"(fp));  // opaque address: keeps the re-fetch inside the loop
+      wA1a = __builtin_bit_cast(bf16x8, fp[0]);
+      wA1b = __builtin_bit_cast(bf16x8, fp[64]);
     }
     // the A2/input region (R2) is free since the P3 barrier: stage the next CTU now, its P1 needs no extra barrier
     if (work + (int)gridDim.x < total) stage_ctu(lds, pre, F, work + gridDim.x, per_frame, tid, ld_row, ld_seg, shift_in);
@@ -661,7 +698,9 @@ hipError_t fhevc_launch_cnn_stamped(const FhevcFrames& fr, const FhevcCnnWeights
                                     unsigned long long* d_stamps, int* grid_out, hipStream_t stream)
 {
   const long long total = (long long)(fr.row_end - fr.row_begin) * fr.ctus_x * fr.num_frames;
-  int grid = 2 * num_cus;
+  // FHEVC_DEBUG_WG_PER_CU=1: one workgroup per CU, i.e. the phase times without a second workgroup on the same SIMDs
+  const char* per_cu = getenv("FHEVC_DEBUG_WG_PER_CU");
+  int grid = ((per_cu && per_cu[0] == '1') ? 1 : 2) * num_cus;
   if (total < grid) grid = (int)total;
   *grid_out = grid;
   if (total <= 0) return hipSuccess;
