@@ -208,6 +208,27 @@ def test_errors_are_status_codes():
     with pytest.raises(capi.FastHevcError) as e:
         ctx.set_weights(b"nope")
     assert e.value.code == capi.E_WEIGHTS
+    # device entry points: bad bands, layouts and depths are refused with a status code, nothing is launched
+    for call in (lambda: ctx.preanalyze_frames_device(1, 2, stride, 0, 1, 1, 5),                   # max_aq_depth > 4
+                 lambda: ctx.preanalyze_frames_device(1, 2, stride, 0, 1, 1, 3, rows=(3, 2)),      # empty/inverted band
+                 lambda: ctx.preanalyze_frames_device(1, 3, stride, 0, 1, 1, 3),                   # sample_bytes
+                 lambda: ctx.intra_first_pass_device(1, 2, 100, 0, 1, 1),                          # stride < width
+                 lambda: ctx.intra_first_pass_device(1, 2, stride, 0, 1, 1, rows=(0, 9)),          # band past the picture
+                 lambda: ctx.intra_first_pass_device(1, 2, stride, 0, 1, 1, qp=52),
+                 lambda: ctx.intra_first_pass_device(0, 2, stride, 0, 1, 1)):                      # NULL plane
+        with pytest.raises(capi.FastHevcError) as e:
+            call()
+        assert e.value.code == capi.E_INVALID
     ctx.close()
+    ctx10 = capi.Context(416, 240, 10)
+    with pytest.raises(capi.FastHevcError) as e:   # uint8 samples only make sense at bit depth 8
+        ctx10.intra_first_pass_device(1, 1, 416, 0, 1, 1)
+    assert e.value.code == capi.E_INVALID
+    ctx10.close()
+    odd = capi.Context(420, 244, 8)                # not a multiple of 8: HM pads such pictures; the AQ twin refuses them
+    with pytest.raises(capi.FastHevcError) as e:
+        odd.preanalyze_frames_device(1, 2, 600, 0, 1, 1, 3)
+    assert e.value.code == capi.E_INVALID
+    odd.close()
     with pytest.raises(capi.FastHevcError):
         capi.Context(416, 240, 7)
