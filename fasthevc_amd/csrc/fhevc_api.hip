@@ -37,6 +37,7 @@ struct fhevc_ctx {
   double sum_ms[4] = { 0, 0, 0, 0 };
   uint64_t launches[4] = { 0, 0, 0, 0 };
   double* d_act = nullptr;
+  uint8_t* d_depth_max = nullptr;
   fhevc_stats stats{};
   std::string err;
 };
@@ -291,7 +292,7 @@ void fhevc_destroy(fhevc_ctx* c)
   for (auto& p : c->pool) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
   for (auto& e : c->ev) if (e) hipEventDestroy(e);
   hipFree(c->d_frag); hipFree(c->d_bias); hipFree(c->d_whead); hipFree(c->d_bhead);
-  hipFree(c->d_luma); hipFree(c->d_depth); hipFree(c->d_had); hipFree(c->d_nodes); hipFree(c->d_satd); hipFree(c->d_satd_out); hipFree(c->d_act);
+  hipFree(c->d_luma); hipFree(c->d_depth); hipFree(c->d_had); hipFree(c->d_nodes); hipFree(c->d_satd); hipFree(c->d_satd_out); hipFree(c->d_act); hipFree(c->d_depth_max);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
 }
@@ -331,11 +332,21 @@ int fhevc_predict_frames_device(fhevc_ctx* c, const void* d_luma, int sample_byt
                                 long long frame_stride_samples, int num_frames, int ctu_row_begin, int ctu_row_end, int qp,
                                 uint8_t* d_depth_map, int32_t* d_hadamard, int32_t* d_logits, uint32_t* d_flags, void* stream)
 {
+  return fhevc_predict_frames_device_range(c, d_luma, sample_bytes, stride_samples, frame_stride_samples, num_frames, ctu_row_begin,
+                                           ctu_row_end, qp, 0, d_depth_map, nullptr, d_hadamard, d_logits, d_flags, stream);
+}
+
+int fhevc_predict_frames_device_range(fhevc_ctx* c, const void* d_luma, int sample_bytes, int stride_samples,
+                                      long long frame_stride_samples, int num_frames, int ctu_row_begin, int ctu_row_end, int qp,
+                                      int margin, uint8_t* d_depth_map, uint8_t* d_depth_max, int32_t* d_hadamard, int32_t* d_logits,
+                                      uint32_t* d_flags, void* stream)
+{
   if (!c || !d_luma || !d_depth_map) return FHEVC_E_INVALID;
   if (!c->have_weights) return fail(c, FHEVC_E_STATE, "weights not set");
   if ((sample_bytes != 1 && sample_bytes != 2) || stride_samples < c->cfg.width || num_frames < 1) return fail(c, FHEVC_E_INVALID, "bad frame layout");
   if (sample_bytes == 1 && c->cfg.bit_depth != 8) return fail(c, FHEVC_E_INVALID, "uint8 samples need bit_depth 8");
   if (ctu_row_begin < 0 || ctu_row_end > c->ctus_y || ctu_row_begin > ctu_row_end) return fail(c, FHEVC_E_INVALID, "bad CTU-row band");
+  if (margin < 0 || margin > (1 << 30)) return fail(c, FHEVC_E_INVALID, "bad decision margin");
   if (num_frames > 1 && frame_stride_samples < (long long)stride_samples * (c->cfg.height - 1) + c->cfg.width) return fail(c, FHEVC_E_INVALID, "frames overlap");
   if (ctu_row_begin == ctu_row_end) return FHEVC_OK;
   hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
@@ -347,7 +358,7 @@ int fhevc_predict_frames_device(fhevc_ctx* c, const void* d_luma, int sample_byt
     c->stats.kernels_launched++;
   }
   time_begin(c, s, 0);
-  HIP_TRY(c, fhevc_launch_cnn(fr, cnn_weights(c), d_depth_map, d_logits, d_flags, c->num_cus, s));
+  HIP_TRY(c, fhevc_launch_cnn(fr, cnn_weights(c), d_depth_map, d_logits, d_flags, d_depth_max, margin, c->num_cus, s));
   time_end(c, s);
   c->stats.kernels_launched++;
   c->stats.frames += (uint64_t)num_frames;
@@ -398,6 +409,27 @@ int fhevc_predict_frame(fhevc_ctx* c, const int16_t* luma, int stride_samples, i
   if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) c->stats.ms_kernels += ms;
   if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) c->stats.ms_d2h += ms;
   c->stats.bytes_d2h += (uint64_t)c->num_ctus * (256 + (ctu_src_hadamard ? 4 : 0));
+  return FHEVC_OK;
+}
+
+int fhevc_predict_frame_range(fhevc_ctx* c, const int16_t* luma, int stride_samples, int qp, int slice_type, int margin,
+                              uint8_t* depth_min, uint8_t* depth_max, int32_t* ctu_src_hadamard)
+{
+  (void)slice_type;
+  if (!c || !luma || !depth_min || !depth_max || stride_samples < c->cfg.width) return FHEVC_E_INVALID;
+  if (!c->have_weights) return fail(c, FHEVC_E_STATE, "weights not set");
+  hipSetDevice(c->device);
+  if (!c->d_depth_max) HIP_TRY(c, hipMalloc(&c->d_depth_max, (size_t)c->num_ctus * 256));
+  int rc = upload_frame(c, luma, stride_samples);
+  if (rc != FHEVC_OK) return rc;
+  rc = fhevc_predict_frames_device_range(c, c->d_luma, 2, c->dev_stride, 0, 1, 0, c->ctus_y, qp, margin, c->d_depth, c->d_depth_max,
+                                         ctu_src_hadamard ? c->d_had : nullptr, nullptr, nullptr, c->stream);
+  if (rc != FHEVC_OK) return rc;
+  HIP_TRY(c, hipMemcpyAsync(depth_min, c->d_depth, (size_t)c->num_ctus * 256, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(depth_max, c->d_depth_max, (size_t)c->num_ctus * 256, hipMemcpyDeviceToHost, c->stream));
+  if (ctu_src_hadamard) HIP_TRY(c, hipMemcpyAsync(ctu_src_hadamard, c->d_had, (size_t)c->num_ctus * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->stats.bytes_d2h += (uint64_t)c->num_ctus * (512 + (ctu_src_hadamard ? 4 : 0));
   return FHEVC_OK;
 }
 

@@ -13,10 +13,13 @@
 #endif
 
 TEncFastDepth::TEncFastDepth()
-  : m_enabled(false), m_valid(false), m_external(false), m_ctx(NULL), m_width(0), m_height(0), m_bitDepth(0)
+  : m_enabled(false), m_valid(false), m_external(false), m_ctx(NULL), m_width(0), m_height(0), m_bitDepth(0), m_margin(0)
 {
   const char* en = std::getenv("FHEVC_ENABLE");
   m_enabled = en != NULL && en[0] == '1';
+  const char* mg = std::getenv("FHEVC_MARGIN");
+  m_margin = mg ? std::atoi(mg) : 0;
+  if (m_margin < 0) m_margin = 0;
 }
 
 TEncFastDepth::~TEncFastDepth()
@@ -26,11 +29,15 @@ TEncFastDepth::~TEncFastDepth()
 #endif
 }
 
-void TEncFastDepth::setExternalMap(const unsigned char* map, int numCtus)
+void TEncFastDepth::setExternalRange(const unsigned char* mapMin, const unsigned char* mapMax, int numCtus)
 {
-  m_external = map != NULL;
+  m_external = mapMin != NULL && mapMax != NULL;
   m_valid = m_external;
-  if (m_external) m_depth.assign(map, map + (size_t)numCtus * 256);
+  if (m_external)
+  {
+    m_depth.assign(mapMin, mapMin + (size_t)numCtus * 256);
+    m_depthMax.assign(mapMax, mapMax + (size_t)numCtus * 256);
+  }
 }
 
 bool TEncFastDepth::predictPicture(TComPic* pcPic, int sliceQp, int sliceType)
@@ -63,8 +70,9 @@ bool TEncFastDepth::predictPicture(TComPic* pcPic, int sliceQp, int sliceType)
     m_width = w; m_height = h; m_bitDepth = bd;
   }
   m_depth.resize((size_t)pcPic->getNumberOfCtusInFrame() * 256);
-  const int rc = fhevc_predict_frame(m_ctx, org->getAddr(COMPONENT_Y), org->getStride(COMPONENT_Y), sliceQp, sliceType,
-                                     &m_depth[0], NULL);
+  m_depthMax.resize(m_depth.size());
+  const int rc = fhevc_predict_frame_range(m_ctx, org->getAddr(COMPONENT_Y), org->getStride(COMPONENT_Y), sliceQp, sliceType,
+                                           m_margin, &m_depth[0], &m_depthMax[0], NULL);
   if (rc != FHEVC_OK)
   {
     std::fprintf(stderr, "[fasthevc] picture falls back to full RDO: %s\n", fhevc_last_error(m_ctx));
@@ -75,11 +83,14 @@ bool TEncFastDepth::predictPicture(TComPic* pcPic, int sliceQp, int sliceType)
 #endif
 }
 
-int TEncFastDepth::forcedDepth(const TComDataCU* pcCU) const
+bool TEncFastDepth::forcedRange(const TComDataCU* pcCU, int& dmin, int& dmax) const
 {
-  if (!m_valid) return -1;
+  if (!m_valid) return false;
   const size_t idx = (size_t)pcCU->getCtuRsAddr() * 256 + g_auiZscanToRaster[pcCU->getZorderIdxInCtu()];
-  return idx < m_depth.size() ? (int)m_depth[idx] : -1;
+  if (idx >= m_depth.size() || idx >= m_depthMax.size()) return false;
+  dmin = (int)m_depth[idx];
+  dmax = (int)m_depthMax[idx];
+  return dmax >= dmin;
 }
 
 /* C entry for the oracle harness (oracle/ref_rdo_harness.cpp, FHEVC_HOOK builds) */
@@ -88,4 +99,8 @@ void fhevc_hook_register(TEncFastDepth* p) { g_hookInstance = p; }
 extern "C" void fhevc_hook_set_external_map(const unsigned char* map, int num_ctus)
 {
   if (g_hookInstance != NULL) g_hookInstance->setExternalMap(map, num_ctus);
+}
+extern "C" void fhevc_hook_set_external_range(const unsigned char* map_min, const unsigned char* map_max, int num_ctus)
+{
+  if (g_hookInstance != NULL) g_hookInstance->setExternalRange(map_min, map_max, num_ctus);
 }

@@ -2,13 +2,14 @@
  *
  * New file for source/Lib/TLibEncoder (nothing in HM is replaced).  One instance lives in TEncCu.  Per picture,
  * TEncSlice::compressSlice calls predictPicture() before its CTU loop (TEncSlice.cpp:792); per CU node,
- * TEncCu::xCompressCU asks forcedDepth() right after bBoundary is known (TEncCu.cpp:574).  If the library is
- * disabled, missing or returns an error, forcedDepth() is -1 and HM runs its stock full RDO: never aborts.
+ * TEncCu::xCompressCU asks forcedRange() right after bBoundary is known (TEncCu.cpp:574).  If the library is
+ * disabled, missing or returns an error, forcedRange() is false and HM runs its stock full RDO: never aborts.
  *
  * Knobs arrive through the environment so that TAppEncCfg stays untouched:
  *   FHEVC_ENABLE=1            turn the path on
  *   FHEVC_WEIGHTS=<file>      FHW1 weight blob
  *   FHEVC_DEVICE=<ordinal>    HIP device (default 0)
+ *   FHEVC_MARGIN=<int>        soft decisions: logit margin inside which a split decision is left to HM's RDO (default 0)
  */
 #ifndef __TENCFASTDEPTH__
 #define __TENCFASTDEPTH__
@@ -27,17 +28,20 @@ public:
 
   /// one GPU pass over the original luma plane of pcPic; false -> this picture runs stock RDO
   bool predictPicture(TComPic* pcPic, int sliceQp, int sliceType);
-  /// predicted depth (0..3) of the CU whose top-left 4x4 unit is (ctuRsAddr, zorderIdx), or -1
-  int  forcedDepth(const TComDataCU* pcCU) const;
-  /// validation feed (oracle harness): use this map instead of the GPU for the next picture; NULL clears it
-  void setExternalMap(const unsigned char* map, int numCtus);
+  /// depth range [dmin, dmax] (each 0..3) of the CU whose top-left 4x4 unit is (ctuRsAddr, zorderIdx): the caller
+  /// forces a split while uiDepth < dmin and forbids one once uiDepth >= dmax; false -> no prediction
+  bool forcedRange(const TComDataCU* pcCU, int& dmin, int& dmax) const;
+  /// validation feed (oracle harness): use these maps instead of the GPU for the next picture; NULL clears them
+  void setExternalMap(const unsigned char* map, int numCtus) { setExternalRange(map, map, numCtus); }
+  void setExternalRange(const unsigned char* mapMin, const unsigned char* mapMax, int numCtus);
   const std::vector<unsigned char>& depthMap() const { return m_depth; }
 
 private:
   bool       m_enabled, m_valid, m_external;
   fhevc_ctx* m_ctx;
-  int        m_width, m_height, m_bitDepth;
-  std::vector<unsigned char> m_depth;   // numCtus * 256, raster 16x16 per CTU
+  int        m_width, m_height, m_bitDepth, m_margin;
+  std::vector<unsigned char> m_depth;     // numCtus * 256, raster 16x16 per CTU: depth_min
+  std::vector<unsigned char> m_depthMax;  // depth_max (== m_depth when the margin is 0)
 };
 
 #endif

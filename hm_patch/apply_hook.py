@@ -27,9 +27,10 @@ def patch_cu_h(s):
 def patch_cu_cpp(s):
     # 1. after bBoundary is computed: the two forcing flags
     s = sub_once(s, r'(^\s*const Bool bBoundary = .*;\n)',
-                 r'\1\n    const Int  iForcedDepth = m_fastDepth.forcedDepth( rpcBestCU );   // -1: no prediction\n'
-                 r'    const Bool bForceSplit  = !bBoundary && iForcedDepth > (Int)uiDepth;  // skip the mode loop at this depth\n'
-                 r'    const Bool bForceStop   = !bBoundary && iForcedDepth == (Int)uiDepth; // do not recurse below it\n',
+                 r'\1\n    Int iDepthMin = 0, iDepthMax = 0;                                        // predicted depth range of this CU\n'
+                 r'    const Bool bHaveRange   = m_fastDepth.forcedRange( rpcBestCU, iDepthMin, iDepthMax );\n'
+                 r'    const Bool bForceSplit  = bHaveRange && !bBoundary && iDepthMin > (Int)uiDepth;   // skip the mode loop at this depth\n'
+                 r'    const Bool bForceStop   = bHaveRange && !bBoundary && iDepthMax <= (Int)uiDepth;  // do not recurse below it\n',
                  "bBoundary")
     # 2. the mode loop runs only when the node is not forced to split
     s = sub_once(s, r'^(\s*)if \( !bBoundary \)\n', r'\1if ( !bBoundary && !bForceSplit )\n', "mode loop guard")

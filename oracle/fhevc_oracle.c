@@ -606,11 +606,13 @@ void fho_cnn_ctu(const fho_weights* w, const int8_t* ctu, int qp, int32_t logits
 
 /* split decision: class 1 ("div", sortToDirLabels.m:11-19) wins only on a strict majority. */
 static inline int is_split(const int32_t l[2]) { return l[1] > l[0]; }
+/* split when the logit difference exceeds thr (thr = 0: the plain decision) */
+static inline int is_split_thr(const int32_t l[2], int thr) { return l[1] - l[0] > thr; }
 
-void fho_depth_from_logits(const int32_t logits[21][2], int vw, int vh, uint8_t depth[256])
+static void depth_from_logits_thr(const int32_t logits[21][2], int vw, int vh, int thr, uint8_t depth[256])
 {
   memset(depth, 0, 256);
-  const int s64 = (vw < 64 || vh < 64) ? 1 : is_split(logits[0]);
+  const int s64 = (vw < 64 || vh < 64) ? 1 : is_split_thr(logits[0], thr);
   for (int q = 0; q < 4; q++) {
     const int qx = (q & 1) * 32, qy = (q >> 1) * 32;
     if (qx >= vw || qy >= vh) continue; /* quadrant entirely outside the picture */
@@ -618,7 +620,7 @@ void fho_depth_from_logits(const int32_t logits[21][2], int vw, int vh, uint8_t 
     if (!s64) d32 = 0;
     else {
       const int cross = (qx + 32 > vw) || (qy + 32 > vh);
-      d32 = (cross || is_split(logits[1 + q])) ? 2 : 1;
+      d32 = (cross || is_split_thr(logits[1 + q], thr)) ? 2 : 1;
     }
     for (int b = 0; b < 4; b++) {
       const int bx = qx + (b & 1) * 16, by = qy + (b >> 1) * 16;
@@ -627,7 +629,7 @@ void fho_depth_from_logits(const int32_t logits[21][2], int vw, int vh, uint8_t 
       if (d32 == 2) {
         const int cross = (bx + 16 > vw) || (by + 16 > vh);
         const int bi = (by / 16) * 4 + bx / 16;
-        d = (cross || is_split(logits[5 + bi])) ? 3 : 2;
+        d = (cross || is_split_thr(logits[5 + bi], thr)) ? 3 : 2;
       }
       for (int uy = 0; uy < 4; uy++)
         for (int ux = 0; ux < 4; ux++) {
@@ -636,6 +638,20 @@ void fho_depth_from_logits(const int32_t logits[21][2], int vw, int vh, uint8_t 
         }
     }
   }
+}
+
+void fho_depth_from_logits(const int32_t logits[21][2], int vw, int vh, uint8_t depth[256])
+{
+  depth_from_logits_thr(logits, vw, vh, 0, depth);
+}
+
+/* Soft decisions: depth_min follows only the splits the classifier is sure of (difference > margin), depth_max every
+ * split it is not sure to reject (difference > -margin); the hook forces a split above depth_min, forbids one at
+ * depth_max and leaves the depths in between to HM's RDO.  margin = 0: both equal fho_depth_from_logits. */
+void fho_depth_range_from_logits(const int32_t logits[21][2], int vw, int vh, int margin, uint8_t depth_min[256], uint8_t depth_max[256])
+{
+  depth_from_logits_thr(logits, vw, vh, margin, depth_min);
+  depth_from_logits_thr(logits, vw, vh, -margin, depth_max);
 }
 
 uint32_t fho_flags_from_logits(const int32_t logits[21][2], int vw, int vh)

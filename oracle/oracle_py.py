@@ -87,6 +87,7 @@ def load_oracle():
     lib.fho_cnn_ctu.argtypes = [C.POINTER(Weights), _i8p, C.c_int, _i32p]
     lib.fho_cnn_ctu_debug.argtypes = [C.POINTER(Weights), _i8p, C.c_int, _u8p, _u8p, _u8p, _i32p]
     lib.fho_depth_from_logits.argtypes = [_i32p, C.c_int, C.c_int, _u8p]
+    lib.fho_depth_range_from_logits.argtypes = [_i32p, C.c_int, C.c_int, C.c_int, _u8p, _u8p]
     lib.fho_flags_from_logits.argtypes = [_i32p, C.c_int, C.c_int]
     lib.fho_flags_from_logits.restype = C.c_uint32
     lib.fho_depth_from_flags.argtypes = [C.c_uint32, C.c_int, C.c_int, _u8p]
@@ -185,7 +186,7 @@ def bind_rdo(lib):
     return lib
 
 
-def rdo_encode(lib, plane, origin, stride, width, height, bit_depth, qp, forced_depth=None, chroma=None):
+def rdo_encode(lib, plane, origin, stride, width, height, bit_depth, qp, forced_depth=None, chroma=None, forced_depth_max=None):
     """-> (depth [numCtus,256] uint8, stats dict).  plane: int16 Pel buffer; chroma: optional (cb, cr) int16 arrays
     [H/2, W/2] at the internal bit depth (default: flat mid-grey)."""
     n = ((width + 63) // 64) * ((height + 63) // 64)
@@ -195,6 +196,14 @@ def rdo_encode(lib, plane, origin, stride, width, height, bit_depth, qp, forced_
     if forced_depth is not None:
         fd = np.ascontiguousarray(forced_depth, np.uint8).reshape(-1)
         assert fd.size == n * 256
+    fdmax = None
+    if forced_depth_max is not None:  # soft hook: forced_depth is then the depth_min map
+        assert fd is not None
+        fdmax = np.ascontiguousarray(forced_depth_max, np.uint8).reshape(-1)
+        assert fdmax.size == n * 256
+        lib.href_rdo_set_forced_max.argtypes = [C.c_void_p]
+        if lib.href_rdo_set_forced_max(C.c_void_p(fdmax.ctypes.data)) != 0:
+            raise RuntimeError("soft hook needs the hook build of the reference library")
     if chroma is not None:
         cb, cr = (np.ascontiguousarray(c, np.int16) for c in chroma)
         assert cb.shape == (height // 2, width // 2) and cr.shape == cb.shape

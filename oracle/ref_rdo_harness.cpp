@@ -56,6 +56,7 @@
 #ifdef FHEVC_HOOK
 // provided by the hook build (hm_patch/TEncFastDepth.cpp compiled into this library): explicit depth map feed
 extern "C" void fhevc_hook_set_external_map(const unsigned char* map, int num_ctus);
+extern "C" void fhevc_hook_set_external_range(const unsigned char* map_min, const unsigned char* map_max, int num_ctus);
 void fhevc_hook_register(TEncFastDepth* p);
 #endif
 
@@ -299,6 +300,19 @@ extern "C" {
 int href_rdo_encode_frame_yuv(const int16_t* luma, int stride, const int16_t* cb, const int16_t* cr, int width, int height,
                               int bit_depth, int qp, const uint8_t* forced_depth, uint8_t* depth_out, double* stats);
 
+// soft hook: depth_max map for the NEXT encode call (forced_depth is then depth_min); hook builds only
+static const uint8_t* g_forced_max = nullptr;
+int href_rdo_set_forced_max(const uint8_t* depth_max)
+{
+#ifdef FHEVC_HOOK
+  g_forced_max = depth_max;
+  return 0;
+#else
+  (void)depth_max;
+  return -2;
+#endif
+}
+
 int href_rdo_encode_frame(const int16_t* luma, int stride, int width, int height, int bit_depth, int qp,
                           const uint8_t* forced_depth, uint8_t* depth_out, double* stats)
 {
@@ -315,7 +329,9 @@ int href_rdo_encode_frame_yuv(const int16_t* luma, int stride, const int16_t* cb
   init_slice(*e, qp);
 #ifdef FHEVC_HOOK
   fhevc_hook_register(&e->cu.getFastDepth());
-  fhevc_hook_set_external_map(forced_depth, forced_depth ? (int)e->pic->getNumberOfCtusInFrame() : 0);
+  if (forced_depth && g_forced_max) fhevc_hook_set_external_range(forced_depth, g_forced_max, (int)e->pic->getNumberOfCtusInFrame());
+  else fhevc_hook_set_external_map(forced_depth, forced_depth ? (int)e->pic->getNumberOfCtusInFrame() : 0);
+  g_forced_max = nullptr;  // one-shot
 #else
   if (forced_depth) return -2;
 #endif

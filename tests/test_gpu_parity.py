@@ -135,6 +135,44 @@ def test_device_batch_logits_and_bands(oracle, torch_cuda):
     ctx.close()
 
 
+def test_soft_decision_ranges(oracle, torch_cuda):
+    """fhevc_predict_frame_range / _device_range against the oracle's fho_depth_range_from_logits."""
+    torch = torch_cuda
+    w = weights.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fasthevc_amd", "weights", "depthnet_v1.fhw"))
+    W, H, QP = 416, 240, 27
+    luma = frames.texture16_luma(W, H)
+    buf, org, stride, depth_ref, logits_ref, _ = _oracle_frame(oracle, w, luma, 8, QP)
+    ctx = capi.Context(W, H, 8, w)
+    n = ctx.num_ctus
+    differ = 0
+    for margin in (0, 3000, 20000, 1 << 30):
+        emin, emax = np.zeros((n, 256), np.uint8), np.zeros((n, 256), np.uint8)
+        for c in range(n):
+            vw, vh = min(64, W - (c % ctx.ctus_x) * 64), min(64, H - (c // ctx.ctus_x) * 64)
+            oracle.fho_depth_range_from_logits(np.ascontiguousarray(logits_ref[c]), vw, vh, margin, emin[c], emax[c])
+        gmin, gmax = ctx.predict_frame_range(buf, org, stride, qp=QP, margin=margin)
+        assert np.array_equal(gmin, emin) and np.array_equal(gmax, emax), margin
+        if margin == 0:
+            assert np.array_equal(gmin, depth_ref) and np.array_equal(gmax, depth_ref)
+        differ += int((gmin != gmax).sum())
+    assert differ > 0
+    # device entry point: flags follow depth_min
+    dev = torch.device("cuda:0")
+    d16 = torch.from_numpy(buf).to(dev)
+    dmin = torch.zeros((n, 256), dtype=torch.uint8, device=dev)
+    dmax = torch.zeros((n, 256), dtype=torch.uint8, device=dev)
+    flags = torch.zeros(n, dtype=torch.int32, device=dev)
+    ctx._check(ctx.lib.fhevc_predict_frames_device_range(ctx.h, d16.data_ptr() + 2 * org, 2, stride, 0, 1, 0, ctx.ctus_y, QP, 20000,
+                                                         dmin.data_ptr(), dmax.data_ptr(), None, None, flags.data_ptr(), None))
+    expanded = torch.zeros_like(dmin)
+    ctx.expand_depth_flags_device(flags.data_ptr(), 1, expanded.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(expanded, dmin) and bool((dmin <= dmax).all())
+    with pytest.raises(capi.FastHevcError):
+        ctx.predict_frame_range(buf, org, stride, qp=QP, margin=-1)
+    ctx.close()
+
+
 def _oracle_first_pass(oracle, buf, org, stride, W, H, bd, qp):
     sl = oracle.fho_lambda_intra(qp, bd) ** 0.5
     cw, ch = frames.ctu_grid(W, H)

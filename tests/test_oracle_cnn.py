@@ -94,6 +94,31 @@ def test_depth_from_logits_rules(oracle):
     assert (m[12:, :] == 0).all() and (m[:, 8:] == 0).all()  # outside the picture
 
 
+def test_depth_range_from_logits(oracle):
+    """Soft decisions: margin 0 is the plain map; ranges nest as the margin grows; forced splits at the picture edge
+    are in both maps; a huge margin frees every decision the picture edge does not force."""
+    rng = np.random.default_rng(4)
+    for t in range(300):
+        lg = rng.integers(-60, 60, (21, 2)).astype(np.int32)
+        vw, vh = [(64, 64), (32, 64), (64, 48), (16, 8), (40, 64)][t % 5]
+        plain, a0, b0 = (np.zeros(256, np.uint8) for _ in range(3))
+        oracle.fho_depth_from_logits(lg.reshape(-1), vw, vh, plain)
+        oracle.fho_depth_range_from_logits(lg.reshape(-1), vw, vh, 0, a0, b0)
+        assert np.array_equal(a0, plain) and np.array_equal(b0, plain)
+        prev_a, prev_b = a0, b0
+        for m in (5, 25, 1000):
+            a, b = np.zeros(256, np.uint8), np.zeros(256, np.uint8)
+            oracle.fho_depth_range_from_logits(lg.reshape(-1), vw, vh, m, a, b)
+            assert np.all(a <= prev_a) and np.all(prev_b <= b)
+            prev_a, prev_b = a, b
+        forced = np.zeros(256, np.uint8)  # what the picture edge alone forces: all logits say "stop"
+        oracle.fho_depth_from_logits(np.tile(np.array([1, 0], np.int32), 21), vw, vh, forced)
+        assert np.array_equal(prev_a, forced)
+        inside = np.zeros((16, 16), bool)
+        inside[:vh // 4, :vw // 4] = True
+        assert np.all(prev_b.reshape(16, 16)[inside] == 3) and np.all(prev_b.reshape(16, 16)[~inside] == 0)
+
+
 def test_predict_frame_edge_ctus(oracle):
     w = weights.random_weights(5)
     ws = op.weights_from_arrays(w)
