@@ -246,13 +246,22 @@ __device__ __forceinline__ f32x16 conv3_unit(const unsigned char* a2, int yp, in
 // One thread's 16 samples of a CTU (picture row ld_row, columns 16*ld_seg..) fetched ahead of use.  fast = 0:
 // picture edge or unaligned plane, P0 falls back to guarded scalar loads.
 struct Prefetched { uint4 a, b; int fast; };
-__device__ __forceinline__ Prefetched prefetch_ctu(const FhevcFrames& F, int wk, int total, int per_frame, int ld_row, int ld_seg)
+// CTU coordinates of a work item: frame, CTU row inside the band, CTU column.  A workgroup walks its items with a
+// mixed-radix increment (advance) instead of dividing the work index: integer division costs ~40 VALU instructions.
+struct CtuPos { int f, ry, cx; };
+__device__ __forceinline__ CtuPos advance(CtuPos c, const CtuPos& step, int band_rows, int ctus_x)
+{
+  c.cx += step.cx; c.ry += step.ry; c.f += step.f;
+  if (c.cx >= ctus_x) { c.cx -= ctus_x; c.ry++; }
+  if (c.ry >= band_rows) { c.ry -= band_rows; c.f++; }
+  return c;
+}
+__device__ __forceinline__ Prefetched prefetch_ctu(const FhevcFrames& F, bool live, CtuPos c, int ld_row, int ld_seg)
 {
   Prefetched p;
   p.a = make_uint4(0, 0, 0, 0); p.b = make_uint4(0, 0, 0, 0); p.fast = 0;
-  if (wk >= total) return p;
-  const int pf = wk / per_frame, prem = wk - pf * per_frame;
-  const int pcy = F.row_begin + prem / F.ctus_x, pcx = prem % F.ctus_x;
+  if (!live) return p;
+  const int pf = c.f, pcy = F.row_begin + c.ry, pcx = c.cx;
   const int py = pcy * 64 + ld_row, px0 = pcx * 64 + ld_seg * 16;
   if (py >= F.height || px0 + 16 > F.width) return p;
   const long long base = (long long)pf * F.frame_stride + (long long)py * F.stride + px0;
@@ -272,8 +281,8 @@ __device__ __forceinline__ Prefetched prefetch_ctu(const FhevcFrames& F, int wk,
 
 // Stage one CTU into LDS (region R2): centred 8-bit samples as bf16, two picture rows per dword, zero halo.
 // halo coordinates: hy = row + 1, hx = col + 1; dword (hy >> 1) * IN_PITCH + hx, half (hy & 1)
-__device__ __forceinline__ void stage_ctu(unsigned char* lds, const Prefetched& pre, const FhevcFrames& F, int wk,
-                                          int per_frame, int tid, int ld_row, int ld_seg, int shift_in)
+__device__ __forceinline__ void stage_ctu(unsigned char* lds, const Prefetched& pre, const FhevcFrames& F, CtuPos c,
+                                          int tid, int ld_row, int ld_seg, int shift_in)
 {
   unsigned short* inh = reinterpret_cast<unsigned short*>(lds + R2_OFF);
   const int hy = ld_row + 1;
@@ -296,8 +305,7 @@ __device__ __forceinline__ void stage_ctu(unsigned char* lds, const Prefetched& 
       }
     }
   } else {  // picture edge or unaligned plane: guarded scalar loads
-    const int f = wk / per_frame, rem = wk - f * per_frame;
-    const int cy = F.row_begin + rem / F.ctus_x, cx = rem % F.ctus_x;
+    const int f = c.f, cy = F.row_begin + c.ry, cx = c.cx;
     const int py = cy * 64 + ld_row, px0 = cx * 64 + ld_seg * 16;
     const long long base = (long long)f * F.frame_stride + (long long)py * F.stride + px0;
     const bool row_ok = py < F.height;
@@ -407,9 +415,15 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
   // XCD-aware order (speed only): blockIdx % 8 share an L2, give each XCD a contiguous run of CTUs per sweep so that the
   // 128-byte lines shared by horizontally adjacent CTUs (HM's unaligned margins) are fetched into one L2, not two
   const int vblock = (gridDim.x & 7) ? (int)blockIdx.x : (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));
-  Prefetched pre = prefetch_ctu(F, vblock, total, per_frame, ld_row, ld_seg);
+  CtuPos pos, step;  // this workgroup's current item and its stride (the only divisions of the kernel)
+  {
+    const int vb = min(vblock, total - 1), g = (int)gridDim.x;
+    pos.f = vb / per_frame; pos.ry = (vb - pos.f * per_frame) / F.ctus_x; pos.cx = (vb - pos.f * per_frame) - pos.ry * F.ctus_x;
+    step.f = g / per_frame; step.ry = (g - step.f * per_frame) / F.ctus_x; step.cx = (g - step.f * per_frame) - step.ry * F.ctus_x;
+  }
+  Prefetched pre = prefetch_ctu(F, vblock < total, pos, ld_row, ld_seg);
   if (vblock < total) {  // prologue: first CTU of this workgroup
-    stage_ctu(lds, pre, F, vblock, per_frame, tid, ld_row, ld_seg, shift_in);
+    stage_ctu(lds, pre, F, pos, tid, ld_row, ld_seg, shift_in);
     zero_a1_halo(lds, tid);
   }
   __syncthreads();
@@ -418,10 +432,8 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
   // Per CTU: P1 conv1 | P2 conv2 | P3 conv3 (next CTU's samples are requested) | P4 heads + next CTU staged into LDS |
   // P5 depth map + conv1 halo re-zeroed -- four barriers; P5 runs into the next P1 without one (disjoint LDS).
   for (int work = vblock; work < total; work += gridDim.x) {
-    const int f = work / per_frame;
-    const int rem = work - f * per_frame;
-    const int cy = F.row_begin + rem / F.ctus_x;
-    const int cx = rem % F.ctus_x;
+    const int f = pos.f, cy = F.row_begin + pos.ry, cx = pos.cx;
+    const CtuPos next = advance(pos, step, band_rows, F.ctus_x);
 
     // (the samples of this CTU were staged into LDS during the previous iteration's P4, or by the prologue)
 
@@ -504,6 +516,7 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
     FHEVC_STAMP(2)
 
     // ================= P3: conv3 (32 -> 64), K = 9 taps x 32 ch, requant to u8 =================
+    pre = prefetch_ctu(F, work + (int)gridDim.x < total, next, ld_row, ld_seg);  // next CTU's samples travel under conv3 and the heads
     {
       // column rotation of the second row: with an 18-position (288 B) row pitch the 16 lanes of every ds_read_b128
       // group then cover 16 distinct 16-byte slots modulo 256 B
@@ -535,7 +548,6 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
     FHEVC_STAMP(3)
 
     // ================= P4: FC heads on v_dot4_u32_u8 (weights stored as w+128, resident in LDS) =================
-    pre = prefetch_ctu(F, work + gridDim.x, total, per_frame, ld_row, ld_seg);  // next CTU's samples travel under the heads
     {
       // wave = 32x32 quadrant q; 16-lane DPP row = one 16x16 block of it; lane bits [1:0] = x & 3, [3:2] = y & 3
       const int q = wave, blk = lane >> 4;
@@ -595,7 +607,7 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
       wA1b = __builtin_bit_cast(bf16x8, fp[64]);
     }
     // the A2/input region (R2) is free since the P3 barrier: stage the next CTU now, its P1 needs no extra barrier
-    if (work + (int)gridDim.x < total) stage_ctu(lds, pre, F, work + gridDim.x, per_frame, tid, ld_row, ld_seg, shift_in);
+    if (work + (int)gridDim.x < total) stage_ctu(lds, pre, F, next, tid, ld_row, ld_seg, shift_in);
     __syncthreads();
     FHEVC_STAMP(4)
 
@@ -647,6 +659,7 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
       zero_a1_halo(lds, tid);  // R1 held the conv3 output until the P4 barrier; conv1 of the next CTU needs a zero halo
     }
     FHEVC_STAMP(5)
+    pos = next;
     // no barrier here: the next P1 reads R2 (staged before the P4 barrier) and writes the A1 interior (R1, last read
     // before the P4 barrier, halo rewritten above by disjoint addresses); the logits are re-initialised in P2.
   }
