@@ -70,9 +70,9 @@ def load_library():
     lib.fhevc_destroy.restype = None
     lib.fhevc_set_weights.argtypes = [vp, C.c_char_p, C.c_size_t]
     lib.fhevc_predict_frame.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]
-    lib.fhevc_predict_frame_range.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]
+    lib.fhevc_predict_frame_range.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]
     lib.fhevc_predict_frames_device_range.argtypes = [vp, vp, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_int,
-                                                      C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
+                                                      C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
     lib.fhevc_satd.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32)]
     lib.fhevc_intra_first_pass.argtypes = [vp, vp, C.c_int, C.c_int, vp]
     lib.fhevc_intra_first_pass_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_int,
@@ -149,7 +149,7 @@ class Context:
                                                  depth.ctypes.data, had.ctypes.data if want_hadamard else None))
         return depth.reshape(self.num_ctus, 256), had
 
-    def predict_frame_range(self, plane, origin=0, stride=None, qp=32, margin=0, slice_type=2):
+    def predict_frame_range(self, plane, origin=0, stride=None, qp=32, margin=0, slice_type=2, margin_stop=None):
         """Soft decisions: (depth_min, depth_max), each [numCtus, 256]."""
         flat = np.ascontiguousarray(plane).reshape(-1)
         assert flat.dtype == np.int16
@@ -157,6 +157,7 @@ class Context:
         dmin = np.zeros(self.num_ctus * 256, np.uint8)
         dmax = np.zeros(self.num_ctus * 256, np.uint8)
         self._check(self.lib.fhevc_predict_frame_range(self.h, flat.ctypes.data + 2 * origin, stride, qp, slice_type, margin,
+                                                       margin if margin_stop is None else margin_stop,
                                                        dmin.ctypes.data, dmax.ctypes.data, None))
         return dmin.reshape(self.num_ctus, 256), dmax.reshape(self.num_ctus, 256)
 

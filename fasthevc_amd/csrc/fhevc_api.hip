@@ -333,12 +333,12 @@ int fhevc_predict_frames_device(fhevc_ctx* c, const void* d_luma, int sample_byt
                                 uint8_t* d_depth_map, int32_t* d_hadamard, int32_t* d_logits, uint32_t* d_flags, void* stream)
 {
   return fhevc_predict_frames_device_range(c, d_luma, sample_bytes, stride_samples, frame_stride_samples, num_frames, ctu_row_begin,
-                                           ctu_row_end, qp, 0, d_depth_map, nullptr, d_hadamard, d_logits, d_flags, stream);
+                                           ctu_row_end, qp, 0, 0, d_depth_map, nullptr, d_hadamard, d_logits, d_flags, stream);
 }
 
 int fhevc_predict_frames_device_range(fhevc_ctx* c, const void* d_luma, int sample_bytes, int stride_samples,
                                       long long frame_stride_samples, int num_frames, int ctu_row_begin, int ctu_row_end, int qp,
-                                      int margin, uint8_t* d_depth_map, uint8_t* d_depth_max, int32_t* d_hadamard, int32_t* d_logits,
+                                      int margin_split, int margin_stop, uint8_t* d_depth_map, uint8_t* d_depth_max, int32_t* d_hadamard, int32_t* d_logits,
                                       uint32_t* d_flags, void* stream)
 {
   if (!c || !d_luma || !d_depth_map) return FHEVC_E_INVALID;
@@ -346,7 +346,7 @@ int fhevc_predict_frames_device_range(fhevc_ctx* c, const void* d_luma, int samp
   if ((sample_bytes != 1 && sample_bytes != 2) || stride_samples < c->cfg.width || num_frames < 1) return fail(c, FHEVC_E_INVALID, "bad frame layout");
   if (sample_bytes == 1 && c->cfg.bit_depth != 8) return fail(c, FHEVC_E_INVALID, "uint8 samples need bit_depth 8");
   if (ctu_row_begin < 0 || ctu_row_end > c->ctus_y || ctu_row_begin > ctu_row_end) return fail(c, FHEVC_E_INVALID, "bad CTU-row band");
-  if (margin < 0 || margin > (1 << 30)) return fail(c, FHEVC_E_INVALID, "bad decision margin");
+  if (margin_split < 0 || margin_split > (1 << 30) || margin_stop < 0 || margin_stop > (1 << 30)) return fail(c, FHEVC_E_INVALID, "bad decision margin");
   if (num_frames > 1 && frame_stride_samples < (long long)stride_samples * (c->cfg.height - 1) + c->cfg.width) return fail(c, FHEVC_E_INVALID, "frames overlap");
   if (ctu_row_begin == ctu_row_end) return FHEVC_OK;
   hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
@@ -358,7 +358,7 @@ int fhevc_predict_frames_device_range(fhevc_ctx* c, const void* d_luma, int samp
     c->stats.kernels_launched++;
   }
   time_begin(c, s, 0);
-  HIP_TRY(c, fhevc_launch_cnn(fr, cnn_weights(c), d_depth_map, d_logits, d_flags, d_depth_max, margin, c->num_cus, s));
+  HIP_TRY(c, fhevc_launch_cnn(fr, cnn_weights(c), d_depth_map, d_logits, d_flags, d_depth_max, margin_split, margin_stop, c->num_cus, s));
   time_end(c, s);
   c->stats.kernels_launched++;
   c->stats.frames += (uint64_t)num_frames;
@@ -412,7 +412,7 @@ int fhevc_predict_frame(fhevc_ctx* c, const int16_t* luma, int stride_samples, i
   return FHEVC_OK;
 }
 
-int fhevc_predict_frame_range(fhevc_ctx* c, const int16_t* luma, int stride_samples, int qp, int slice_type, int margin,
+int fhevc_predict_frame_range(fhevc_ctx* c, const int16_t* luma, int stride_samples, int qp, int slice_type, int margin_split, int margin_stop,
                               uint8_t* depth_min, uint8_t* depth_max, int32_t* ctu_src_hadamard)
 {
   (void)slice_type;
@@ -422,7 +422,7 @@ int fhevc_predict_frame_range(fhevc_ctx* c, const int16_t* luma, int stride_samp
   if (!c->d_depth_max) HIP_TRY(c, hipMalloc(&c->d_depth_max, (size_t)c->num_ctus * 256));
   int rc = upload_frame(c, luma, stride_samples);
   if (rc != FHEVC_OK) return rc;
-  rc = fhevc_predict_frames_device_range(c, c->d_luma, 2, c->dev_stride, 0, 1, 0, c->ctus_y, qp, margin, c->d_depth, c->d_depth_max,
+  rc = fhevc_predict_frames_device_range(c, c->d_luma, 2, c->dev_stride, 0, 1, 0, c->ctus_y, qp, margin_split, margin_stop, c->d_depth, c->d_depth_max,
                                          ctu_src_hadamard ? c->d_had : nullptr, nullptr, nullptr, c->stream);
   if (rc != FHEVC_OK) return rc;
   HIP_TRY(c, hipMemcpyAsync(depth_min, c->d_depth, (size_t)c->num_ctus * 256, hipMemcpyDeviceToHost, c->stream));

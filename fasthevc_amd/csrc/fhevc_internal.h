@@ -36,9 +36,9 @@ struct FhevcCnnWeights {
   float scale[3];            // 2^-shift per conv layer
 };
 
-// d_depth_max / margin: soft decisions (nullptr / 0 = the plain map only)
+// d_depth_max / margins: soft decisions (nullptr / 0, 0 = the plain map only)
 hipError_t fhevc_launch_cnn(const FhevcFrames& fr, const FhevcCnnWeights& w, uint8_t* d_depth, int32_t* d_logits,
-                            uint32_t* d_flags, uint8_t* d_depth_max, int margin, int num_cus, hipStream_t stream);
+                            uint32_t* d_flags, uint8_t* d_depth_max, int margin_split, int margin_stop, int num_cus, hipStream_t stream);
 hipError_t fhevc_launch_expand_flags(const FhevcFrames& fr, const uint32_t* d_flags, uint8_t* d_depth, hipStream_t stream);
 
 hipError_t fhevc_launch_cnn_stamped(const FhevcFrames& fr, const FhevcCnnWeights& w, uint8_t* d_depth, int num_cus,

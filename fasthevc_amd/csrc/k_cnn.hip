@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
                                                                   int32_t* __restrict__ d_logits,
                                                                   uint32_t* __restrict__ d_flags,
                                                                   unsigned long long* __restrict__ d_stamps,
-                                                                  uint8_t* __restrict__ d_depth_max, int margin)
+                                                                  uint8_t* __restrict__ d_depth_max, int margin_split, int margin_stop)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x;
@@ -619,20 +619,20 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
       const int2 l32 = *reinterpret_cast<const int2*>(logitL + 2 * (1 + (uy >> 3) * 2 + (ux >> 3)));
       const int2 l16 = *reinterpret_cast<const int2*>(logitL + 2 * (5 + (uy >> 2) * 4 + (ux >> 2)));
       const bool inside = (ux * 4 < vw) && (uy * 4 < vh);
-      // soft decisions: d_depth follows the splits surer than +margin, d_depth_max those not rejected by more than
-      // -margin (margin = 0: the plain map in both); CUs crossing the picture edge are split either way
+      // soft decisions: d_depth follows the splits surer than +margin_split, d_depth_max those not rejected by more
+      // than -margin_stop (both 0: the plain map in both); CUs crossing the picture edge are split either way
       const bool e64 = (vw < 64) || (vh < 64);
       const bool e32 = ((ux >> 3) * 32 + 32 > vw) || ((uy >> 3) * 32 + 32 > vh);
       const bool e16 = ((ux >> 2) * 16 + 16 > vw) || ((uy >> 2) * 16 + 16 > vh);
       const int d64 = l64.y - l64.x, d32 = l32.y - l32.x, d16 = l16.y - l16.x;
       const long long o = (long long)(f * band_rows + (cy - F.row_begin)) * F.ctus_x + cx;
       {
-        const bool s64 = e64 || d64 > margin, s32 = e32 || d32 > margin, s16 = e16 || d16 > margin;
+        const bool s64 = e64 || d64 > margin_split, s32 = e32 || d32 > margin_split, s16 = e16 || d16 > margin_split;
         const int d = (inside && s64) ? (s32 ? (s16 ? 3 : 2) : 1) : 0;
         d_depth[o * 256 + tid] = (uint8_t)d;
       }
       if (d_depth_max != nullptr) {
-        const bool s64 = e64 || d64 > -margin, s32 = e32 || d32 > -margin, s16 = e16 || d16 > -margin;
+        const bool s64 = e64 || d64 > -margin_stop, s32 = e32 || d32 > -margin_stop, s16 = e16 || d16 > -margin_stop;
         const int d = (inside && s64) ? (s32 ? (s16 ? 3 : 2) : 1) : 0;
         d_depth_max[o * 256 + tid] = (uint8_t)d;
       }
@@ -642,15 +642,15 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
         const int bi = k - 5, qq = k < 5 ? k - 1 : (bi >> 3) * 2 + ((bi >> 1) & 1);  // own / parent quadrant
         const int qx = (qq & 1) * 32, qy = (qq >> 1) * 32, bxx = (bi & 3) * 16, byy = (bi >> 2) * 16;
         const int2 a64 = *reinterpret_cast<const int2*>(logitL);
-        const bool n64 = (vw < 64) || (vh < 64) || (a64.y - a64.x > margin);
+        const bool n64 = (vw < 64) || (vh < 64) || (a64.y - a64.x > margin_split);
         bool bit = n64;
         if (k >= 1 && k < 21) {
           const int2 a32 = *reinterpret_cast<const int2*>(logitL + 2 * (1 + qq));
-          const bool n32 = n64 && (qx < vw) && (qy < vh) && ((qx + 32 > vw) || (qy + 32 > vh) || (a32.y - a32.x > margin));
+          const bool n32 = n64 && (qx < vw) && (qy < vh) && ((qx + 32 > vw) || (qy + 32 > vh) || (a32.y - a32.x > margin_split));
           bit = n32;
           if (k >= 5) {
             const int2 a16 = *reinterpret_cast<const int2*>(logitL + 2 * k);
-            bit = n32 && (bxx < vw) && (byy < vh) && ((bxx + 16 > vw) || (byy + 16 > vh) || (a16.y - a16.x > margin));
+            bit = n32 && (bxx < vw) && (byy < vh) && ((bxx + 16 > vw) || (byy + 16 > vh) || (a16.y - a16.x > margin_split));
           }
         }
         const unsigned long long m = __ballot(bit && k < 21);
@@ -700,7 +700,7 @@ hipError_t fhevc_launch_expand_flags(const FhevcFrames& fr, const uint32_t* d_fl
 }
 
 hipError_t fhevc_launch_cnn(const FhevcFrames& fr, const FhevcCnnWeights& w, uint8_t* d_depth, int32_t* d_logits,
-                            uint32_t* d_flags, uint8_t* d_depth_max, int margin, int num_cus, hipStream_t stream)
+                            uint32_t* d_flags, uint8_t* d_depth_max, int margin_split, int margin_stop, int num_cus, hipStream_t stream)
 {
   const long long total = (long long)(fr.row_end - fr.row_begin) * fr.ctus_x * fr.num_frames;
   if (total <= 0) return hipSuccess;
@@ -714,7 +714,7 @@ hipError_t fhevc_launch_cnn(const FhevcFrames& fr, const FhevcCnnWeights& w, uin
     attr_set = true;
   }
   hipLaunchKernelGGL(fhevc_cnn_depth_kernel<false>, dim3(grid), dim3(256), LDS_BYTES, stream, fr, w, d_depth, d_logits,
-                     d_flags, (unsigned long long*)nullptr, d_depth_max, margin);
+                     d_flags, (unsigned long long*)nullptr, d_depth_max, margin_split, margin_stop);
   return hipGetLastError();
 }
 
@@ -733,6 +733,6 @@ hipError_t fhevc_launch_cnn_stamped(const FhevcFrames& fr, const FhevcCnnWeights
                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(fhevc_cnn_depth_kernel<true>, dim3(grid), dim3(256), LDS_BYTES, stream, fr, w, d_depth, (int32_t*)nullptr,
-                     (uint32_t*)nullptr, d_stamps, (uint8_t*)nullptr, 0);
+                     (uint32_t*)nullptr, d_stamps, (uint8_t*)nullptr, 0, 0);
   return hipGetLastError();
 }

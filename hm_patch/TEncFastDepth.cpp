@@ -13,13 +13,17 @@
 #endif
 
 TEncFastDepth::TEncFastDepth()
-  : m_enabled(false), m_valid(false), m_external(false), m_ctx(NULL), m_width(0), m_height(0), m_bitDepth(0), m_margin(0)
+  : m_enabled(false), m_valid(false), m_external(false), m_ctx(NULL), m_width(0), m_height(0), m_bitDepth(0), m_marginSplit(0), m_marginStop(0)
 {
   const char* en = std::getenv("FHEVC_ENABLE");
   m_enabled = en != NULL && en[0] == '1';
   const char* mg = std::getenv("FHEVC_MARGIN");
-  m_margin = mg ? std::atoi(mg) : 0;
-  if (m_margin < 0) m_margin = 0;
+  const char* ms = std::getenv("FHEVC_MARGIN_SPLIT");
+  const char* mt = std::getenv("FHEVC_MARGIN_STOP");
+  m_marginSplit = ms ? std::atoi(ms) : (mg ? std::atoi(mg) : 0);
+  m_marginStop  = mt ? std::atoi(mt) : (mg ? std::atoi(mg) : 0);
+  if (m_marginSplit < 0) m_marginSplit = 0;
+  if (m_marginStop < 0) m_marginStop = 0;
 }
 
 TEncFastDepth::~TEncFastDepth()
@@ -72,7 +76,7 @@ bool TEncFastDepth::predictPicture(TComPic* pcPic, int sliceQp, int sliceType)
   m_depth.resize((size_t)pcPic->getNumberOfCtusInFrame() * 256);
   m_depthMax.resize(m_depth.size());
   const int rc = fhevc_predict_frame_range(m_ctx, org->getAddr(COMPONENT_Y), org->getStride(COMPONENT_Y), sliceQp, sliceType,
-                                           m_margin, &m_depth[0], &m_depthMax[0], NULL);
+                                           m_marginSplit, m_marginStop, &m_depth[0], &m_depthMax[0], NULL);
   if (rc != FHEVC_OK)
   {
     std::fprintf(stderr, "[fasthevc] picture falls back to full RDO: %s\n", fhevc_last_error(m_ctx));

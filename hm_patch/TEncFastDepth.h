@@ -9,7 +9,9 @@
  *   FHEVC_ENABLE=1            turn the path on
  *   FHEVC_WEIGHTS=<file>      FHW1 weight blob
  *   FHEVC_DEVICE=<ordinal>    HIP device (default 0)
- *   FHEVC_MARGIN=<int>        soft decisions: logit margin inside which a split decision is left to HM's RDO (default 0)
+ *   FHEVC_MARGIN=<int>        soft decisions: logit margin inside which a split decision is left to HM's RDO (default 0);
+ *   FHEVC_MARGIN_SPLIT / FHEVC_MARGIN_STOP set the two sides separately (not forcing unsure splits is almost free,
+ *                             not forbidding unsure ones costs the recursion it allows)
  */
 #ifndef __TENCFASTDEPTH__
 #define __TENCFASTDEPTH__
@@ -39,7 +41,7 @@ public:
 private:
   bool       m_enabled, m_valid, m_external;
   fhevc_ctx* m_ctx;
-  int        m_width, m_height, m_bitDepth, m_margin;
+  int        m_width, m_height, m_bitDepth, m_marginSplit, m_marginStop;
   std::vector<unsigned char> m_depth;     // numCtus * 256, raster 16x16 per CTU: depth_min
   std::vector<unsigned char> m_depthMax;  // depth_max (== m_depth when the margin is 0)
 };

@@ -90,11 +90,13 @@ int  fhevc_predict_frame(fhevc_ctx* ctx, const int16_t* luma, int stride_samples
                          uint8_t* depth_map, int32_t* ctu_src_hadamard);
 
 /* Soft decisions for the xCompressCU hook (hm_patch/): depth_min holds only the splits whose logit difference exceeds
- * +margin, depth_max every split not rejected by more than -margin (margin >= 0, logit units; 0: both equal the map of
- * fhevc_predict_frame).  The hook forces a split while depth < depth_min, forbids one at depth >= depth_max and leaves
- * the depths in between to HM's own RD search (TEncCu.cpp:576-849, 892). */
-int  fhevc_predict_frame_range(fhevc_ctx* ctx, const int16_t* luma, int stride_samples, int qp, int slice_type, int margin,
-                               uint8_t* depth_min, uint8_t* depth_max, int32_t* ctu_src_hadamard);
+ * +margin_split, depth_max every split not rejected by more than -margin_stop (both >= 0, logit units; 0, 0: both maps
+ * equal the map of fhevc_predict_frame).  The hook forces a split while depth < depth_min, forbids one at
+ * depth >= depth_max and leaves the depths in between to HM's own RD search (TEncCu.cpp:576-849, 892).  margin_split
+ * costs almost no time (the parent CU is evaluated as well), margin_stop costs the recursion it allows. */
+int  fhevc_predict_frame_range(fhevc_ctx* ctx, const int16_t* luma, int stride_samples, int qp, int slice_type,
+                               int margin_split, int margin_stop, uint8_t* depth_min, uint8_t* depth_max,
+                               int32_t* ctu_src_hadamard);
 
 /* == TComRdCost::calcHAD(bitDepth, org, strideOrg, cur, strideCur, w, h) (TComRdCost.cpp:297-334) and
  * xGetHADs (:1753-1824); host buffers, w,h <= 64.  Parity entry point. */
@@ -125,7 +127,7 @@ int  fhevc_predict_frames_device(fhevc_ctx* ctx, const void* d_luma, int sample_
 /* the same with soft decisions (see fhevc_predict_frame_range); d_depth_max may be NULL; d_flags follow d_depth_map */
 int  fhevc_predict_frames_device_range(fhevc_ctx* ctx, const void* d_luma, int sample_bytes, int stride_samples,
                                        long long frame_stride_samples, int num_frames, int ctu_row_begin, int ctu_row_end,
-                                       int qp, int margin, uint8_t* d_depth_map, uint8_t* d_depth_max, int32_t* d_hadamard,
+                                       int qp, int margin_split, int margin_stop, uint8_t* d_depth_map, uint8_t* d_depth_max, int32_t* d_hadamard,
                                        int32_t* d_logits, uint32_t* d_flags, void* stream);
 
 /* The 21 split decisions of a CTU as one word (bit 0 = 64x64, bits 1..4 = 32x32 quadrants, bits 5..20 = 16x16

@@ -645,13 +645,14 @@ void fho_depth_from_logits(const int32_t logits[21][2], int vw, int vh, uint8_t 
   depth_from_logits_thr(logits, vw, vh, 0, depth);
 }
 
-/* Soft decisions: depth_min follows only the splits the classifier is sure of (difference > margin), depth_max every
- * split it is not sure to reject (difference > -margin); the hook forces a split above depth_min, forbids one at
- * depth_max and leaves the depths in between to HM's RDO.  margin = 0: both equal fho_depth_from_logits. */
-void fho_depth_range_from_logits(const int32_t logits[21][2], int vw, int vh, int margin, uint8_t depth_min[256], uint8_t depth_max[256])
+/* Soft decisions: depth_min follows only the splits the classifier is sure of (difference > margin_split), depth_max
+ * every split it is not sure to reject (difference > -margin_stop); the hook forces a split above depth_min, forbids one
+ * at depth_max and leaves the depths in between to HM's RDO.  Both margins 0: both maps equal fho_depth_from_logits. */
+void fho_depth_range_from_logits(const int32_t logits[21][2], int vw, int vh, int margin_split, int margin_stop,
+                                 uint8_t depth_min[256], uint8_t depth_max[256])
 {
-  depth_from_logits_thr(logits, vw, vh, margin, depth_min);
-  depth_from_logits_thr(logits, vw, vh, -margin, depth_max);
+  depth_from_logits_thr(logits, vw, vh, margin_split, depth_min);
+  depth_from_logits_thr(logits, vw, vh, -margin_stop, depth_max);
 }
 
 uint32_t fho_flags_from_logits(const int32_t logits[21][2], int vw, int vh)

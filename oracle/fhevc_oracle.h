@@ -131,8 +131,9 @@ void fho_cnn_ctu_debug(const fho_weights* w, const int8_t* ctu, int qp, uint8_t*
 /* logits -> raster 16x16 depth map.  valid_w/valid_h = in-picture part of the CTU; nodes crossing
  * the picture edge are forced to split (TEncCu.cpp:574,894 bBoundary); units outside get 0. */
 void fho_depth_from_logits(const int32_t logits[21][2], int valid_w, int valid_h, uint8_t depth_raster[256]);
-/* soft decisions (hm_patch soft hook): splits surer than +margin -> depth_min, not surer-rejected than -margin -> depth_max */
-void fho_depth_range_from_logits(const int32_t logits[21][2], int valid_w, int valid_h, int margin,
+/* soft decisions (hm_patch soft hook): splits surer than +margin_split -> depth_min, splits not rejected by more than
+ * -margin_stop -> depth_max */
+void fho_depth_range_from_logits(const int32_t logits[21][2], int valid_w, int valid_h, int margin_split, int margin_stop,
                                  uint8_t depth_min[256], uint8_t depth_max[256]);
 /* The same decisions as one 21-bit word per CTU: bit 0 = 64x64 split, bits 1..4 = 32x32 quadrants (raster),
  * bits 5..20 = 16x16 blocks (raster); a bit is set only under split parents and inside the picture (forced

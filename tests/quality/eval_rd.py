@@ -42,7 +42,7 @@ def main():
     ap.add_argument("--crop", default="1920x1080")
     ap.add_argument("--content", default="hetero,texture16")
     ap.add_argument("--floors", action="store_true", help="also evaluate the constant-depth maps")
-    ap.add_argument("--margins", default="", help="comma-separated logit margins of the soft hook to sweep (e.g. 4000,16000)")
+    ap.add_argument("--margins", default="", help="comma-separated soft-hook margins to sweep: m (both sides) or split:stop (e.g. 8000,16000:0)")
     ap.add_argument("--json", default=None)
     args = ap.parse_args()
     from oracle import oracle_py as op
@@ -65,9 +65,9 @@ def main():
         if args.floors:
             for c in range(4):
                 rows[f"const{c}"] = []
-        margins = [int(v) for v in args.margins.split(",") if v]
+        margins = [tuple(int(x) for x in (v.split(":") if ":" in v else (v, v))) for v in args.margins.split(",") if v]
         for mg in margins:
-            rows[f"cnn_margin{mg}"] = []
+            rows[f"cnn_margin{mg[0]}:{mg[1]}"] = []
         agree = []
         for qp in QPS:
             d_anchor, s_anchor = op.rdo_encode(ref, buf, org, stride, Wd, H, 8, qp, chroma=chroma)
@@ -82,9 +82,9 @@ def main():
                 cwn0 = (Wd + 63) // 64
                 for c in range(n):
                     vw, vh = min(64, Wd - (c % cwn0) * 64), min(64, H - (c // cwn0) * 64)
-                    oracle.fho_depth_range_from_logits(np.ascontiguousarray(logits[c * 42:(c + 1) * 42]), vw, vh, mg, dmin[c], dmax[c])
+                    oracle.fho_depth_range_from_logits(np.ascontiguousarray(logits[c * 42:(c + 1) * 42]), vw, vh, mg[0], mg[1], dmin[c], dmax[c])
                 _, s_m = op.rdo_encode(hook, buf, org, stride, Wd, H, 8, qp, forced_depth=dmin, chroma=chroma, forced_depth_max=dmax)
-                rows[f"cnn_margin{mg}"].append((s_m["coded_bits"], s_m["psnr_y"], s_m["seconds"], float((dmin != dmax).mean())))
+                rows[f"cnn_margin{mg[0]}:{mg[1]}"].append((s_m["coded_bits"], s_m["psnr_y"], s_m["seconds"], float((dmin != dmax).mean())))
             _, s_cnn = op.rdo_encode(hook, buf, org, stride, Wd, H, 8, qp, forced_depth=pred, chroma=chroma)
             rows["cnn"].append((s_cnn["coded_bits"], s_cnn["psnr_y"], s_cnn["seconds"]))
             inpic = np.ones((n, 16, 16), bool)  # compare in-picture units only

@@ -149,7 +149,7 @@ def test_soft_decision_ranges(oracle, torch_cuda):
         emin, emax = np.zeros((n, 256), np.uint8), np.zeros((n, 256), np.uint8)
         for c in range(n):
             vw, vh = min(64, W - (c % ctx.ctus_x) * 64), min(64, H - (c // ctx.ctus_x) * 64)
-            oracle.fho_depth_range_from_logits(np.ascontiguousarray(logits_ref[c]), vw, vh, margin, emin[c], emax[c])
+            oracle.fho_depth_range_from_logits(np.ascontiguousarray(logits_ref[c]), vw, vh, margin, margin, emin[c], emax[c])
         gmin, gmax = ctx.predict_frame_range(buf, org, stride, qp=QP, margin=margin)
         assert np.array_equal(gmin, emin) and np.array_equal(gmax, emax), margin
         if margin == 0:
@@ -162,12 +162,19 @@ def test_soft_decision_ranges(oracle, torch_cuda):
     dmin = torch.zeros((n, 256), dtype=torch.uint8, device=dev)
     dmax = torch.zeros((n, 256), dtype=torch.uint8, device=dev)
     flags = torch.zeros(n, dtype=torch.int32, device=dev)
-    ctx._check(ctx.lib.fhevc_predict_frames_device_range(ctx.h, d16.data_ptr() + 2 * org, 2, stride, 0, 1, 0, ctx.ctus_y, QP, 20000,
+    ctx._check(ctx.lib.fhevc_predict_frames_device_range(ctx.h, d16.data_ptr() + 2 * org, 2, stride, 0, 1, 0, ctx.ctus_y, QP, 20000, 5000,
                                                          dmin.data_ptr(), dmax.data_ptr(), None, None, flags.data_ptr(), None))
     expanded = torch.zeros_like(dmin)
     ctx.expand_depth_flags_device(flags.data_ptr(), 1, expanded.data_ptr())
     torch.cuda.synchronize()
     assert torch.equal(expanded, dmin) and bool((dmin <= dmax).all())
+    amin, amax = ctx.predict_frame_range(buf, org, stride, qp=QP, margin=20000, margin_stop=5000)  # asymmetric margins
+    assert np.array_equal(amin, dmin.cpu().numpy()) and np.array_equal(amax, dmax.cpu().numpy())
+    e5min, e5max = np.zeros((n, 256), np.uint8), np.zeros((n, 256), np.uint8)
+    for c in range(n):
+        vw, vh = min(64, W - (c % ctx.ctus_x) * 64), min(64, H - (c // ctx.ctus_x) * 64)
+        oracle.fho_depth_range_from_logits(np.ascontiguousarray(logits_ref[c]), vw, vh, 20000, 5000, e5min[c], e5max[c])
+    assert np.array_equal(amin, e5min) and np.array_equal(amax, e5max)
     with pytest.raises(capi.FastHevcError):
         ctx.predict_frame_range(buf, org, stride, qp=QP, margin=-1)
     ctx.close()

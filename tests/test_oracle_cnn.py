@@ -103,13 +103,16 @@ def test_depth_range_from_logits(oracle):
         vw, vh = [(64, 64), (32, 64), (64, 48), (16, 8), (40, 64)][t % 5]
         plain, a0, b0 = (np.zeros(256, np.uint8) for _ in range(3))
         oracle.fho_depth_from_logits(lg.reshape(-1), vw, vh, plain)
-        oracle.fho_depth_range_from_logits(lg.reshape(-1), vw, vh, 0, a0, b0)
+        oracle.fho_depth_range_from_logits(lg.reshape(-1), vw, vh, 0, 0, a0, b0)
         assert np.array_equal(a0, plain) and np.array_equal(b0, plain)
         prev_a, prev_b = a0, b0
         for m in (5, 25, 1000):
             a, b = np.zeros(256, np.uint8), np.zeros(256, np.uint8)
-            oracle.fho_depth_range_from_logits(lg.reshape(-1), vw, vh, m, a, b)
+            oracle.fho_depth_range_from_logits(lg.reshape(-1), vw, vh, m, m, a, b)
             assert np.all(a <= prev_a) and np.all(prev_b <= b)
+            a1, b1 = np.zeros(256, np.uint8), np.zeros(256, np.uint8)  # the two margins act independently
+            oracle.fho_depth_range_from_logits(lg.reshape(-1), vw, vh, m, 0, a1, b1)
+            assert np.array_equal(a1, a) and np.array_equal(b1, plain)
             prev_a, prev_b = a, b
         forced = np.zeros(256, np.uint8)  # what the picture edge alone forces: all logits say "stop"
         oracle.fho_depth_from_logits(np.tile(np.array([1, 0], np.int32), 21), vw, vh, forced)
