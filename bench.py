@@ -143,32 +143,43 @@ def main():
     # every rank ends a step with the depth maps of the WHOLE GOP (all ranks' frames) in `gathered`; on the wire the
     # maps travel as 4-byte split-flag words per CTU (64x less than 256 B) and are expanded on arrival
     gathered = torch.zeros((world, NF, n_ctus, 256), dtype=torch.uint8, device=dev)
-    flags_all = bands.alloc_flag_buffers(NF, n_ctus, world, dev)          # receive buffer of the all-gather
-    flags_mine = torch.zeros((NF, n_ctus), dtype=torch.int32, device=dev)  # this rank's words (send buffer)
+    # double-buffered so that the all-gather of step i (RCCL's own stream) overlaps the kernels of step i+1
+    flags_all = [bands.alloc_flag_buffers(NF, n_ctus, world, dev) for _ in range(2)]   # receive buffers of the all-gather
+    flags_mine = [torch.zeros((NF, n_ctus), dtype=torch.int32, device=dev) for _ in range(2)]  # this rank's words (send)
     had = torch.zeros((NF, n_ctus), dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
+    inflight = []  # [(work, buffer index)]: at most one collective in flight
 
-    def step():
+    def finish_gather():
+        """wait for the collective in flight and expand its words into the depth maps of the whole GOP"""
+        while inflight:
+            work, b = inflight.pop()
+            work.wait()
+            ctx.expand_depth_flags_device(flags_all[b].data_ptr(), world * NF, gathered.data_ptr(), stream=stream)
+
+    def step(i):
+        b = i & 1
         ctx.predict_frames_device(luma_ptr, args.sample_bytes, stride, frame_stride, NF, gathered[rank].data_ptr(),
-                                  had.data_ptr(), None, stream=stream, d_flags=flags_mine.data_ptr() if world > 1 else None)
+                                  had.data_ptr(), None, stream=stream, d_flags=flags_mine[b].data_ptr() if world > 1 else None)
         if world > 1:
-            dist.all_gather_into_tensor(flags_all.view(-1), flags_mine.view(-1))  # the path's only collective
-            ctx.expand_depth_flags_device(flags_all.data_ptr(), world * NF, gathered.data_ptr(), stream=stream)
+            finish_gather()  # step i-1's gather has had this step's kernels to hide under
+            inflight.append((dist.all_gather_into_tensor(flags_all[b].view(-1), flags_mine[b].view(-1), async_op=True), b))  # the path's only collective
 
     def fence():
+        finish_gather()  # every step's maps are gathered and expanded before the clock stops
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(i)
     fence()
     ctx.enable_kernel_timing(True)
     ctx.kernel_timing(0, reset=True)
     ctx.kernel_timing(1, reset=True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for i in range(args.steps):
+        step(i)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -177,6 +188,20 @@ def main():
         dt = float(t.item())
     cnn_ms, cnn_n = ctx.kernel_timing(0)
     had_ms, had_n = ctx.kernel_timing(1)
+
+    # untimed check of the N > 1 path: what the all-gather + expansion left in `gathered` must be this rank's own maps
+    # in its slot, and the same bytes on every rank
+    gather_ok = None
+    if world > 1:
+        own = torch.empty((NF, n_ctus, 256), dtype=torch.uint8, device=dev)
+        ctx.predict_frames_device(luma_ptr, args.sample_bytes, stride, frame_stride, NF, own.data_ptr(), None, None, stream=stream)
+        torch.cuda.synchronize()
+        chk = torch.tensor([float(torch.equal(own, gathered[rank])), float(gathered.to(torch.int64).sum().item())],
+                           dtype=torch.float64, device=dev)
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        gather_ok = bool(lo[0].item() == 1.0 and lo[1].item() == hi[1].item() and len(torch.unique(gathered)) > 1)
 
     # the path's other stages (SURVEY 8(d) stage 3 and 8(f) N3), measured AFTER the timed region on the same GOP: the
     # 35-mode SATD first pass over 8 of the frames and the AQ pre-analysis over all of them -- reported, never in `value`
@@ -247,6 +272,8 @@ def main():
         }
         if stages:
             line["stages"] = stages
+        if gather_ok is not None:
+            line["gather_verified"] = gather_ok
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(W, H, bd, w)
         print(json.dumps(line), flush=True)
