@@ -17,7 +17,7 @@ pairs = {
 }
 for a, b in pairs.items():
     shutil.copyfile(os.path.join(src, a), os.path.join(dst, b))
-stats = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))
-assert len(stats) == 1, stats
-shutil.copyfile(stats[0], os.path.join(dst, f"{tag}_kernel_stats_bench_default.csv"))
+stats = sorted(glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
+assert stats, "no kernel stats"
+shutil.copyfile(stats[-1], os.path.join(dst, f"{tag}_kernel_stats_bench_default.csv"))  # gpurun merges runs: newest wins
 print("collected", sorted(os.listdir(dst)))
