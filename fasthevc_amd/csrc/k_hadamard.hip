@@ -4,7 +4,10 @@
 //    (TEncCu.cpp:1230-1343): per CTU, sum over whole 8x8 blocks of (sum|WHT(src)| - |DC| + 2) >> 2.
 //    One pass over the planar-Y frame: HBM-bound (each sample read once, 4 B written per CTU).
 //    One lane owns one 8x8 block (8 loads of 16 B, or 8 B for uint8), one wave one CTU: both butterfly passes run
-//    in registers, 8 consecutive lanes read one contiguous 128-byte run of a picture row.
+//    in registers, 8 consecutive lanes read one contiguous 128-byte run of a picture row.  Up to 10 bits the butterflies
+//    run on packed 16-bit VALU (two samples per lane-op, wrapping adds): every coefficient except DC is bounded by
+//    32 * 1023 and DC is left out of the sum anyway, so arithmetic modulo 2^16 is exact; the stage inside a packed pair
+//    is folded into the absolute sum with |a+b| + |a-b| = 2 max(|a|,|b|).  With 32-bit butterflies the kernel is VALU-bound.
 //  * fhevc_satd_kernel: twin of TComRdCost::calcHAD / xGetHADs (TComRdCost.cpp:297-334, 1527-1824) for one
 //    block pair; parity entry point, not a throughput path.
 #include "fhevc_internal.h"
@@ -29,7 +32,57 @@ __device__ __forceinline__ void wht8_inlane(int v[8])
 // For load j (row j of every lane's block) 8 consecutive lanes read one contiguous 128-byte run (int16) of a picture
 // row, so every fetched line is used whole; both transform passes are in-lane: no LDS, no cross-lane traffic until
 // the final 64-lane sum.
-template <typename T>
+typedef __attribute__((ext_vector_type(2))) short i16x2;
+__device__ __forceinline__ unsigned pk_add(unsigned a, unsigned b)
+{
+  return __builtin_bit_cast(unsigned, (i16x2)(__builtin_bit_cast(i16x2, a) + __builtin_bit_cast(i16x2, b)));
+}
+__device__ __forceinline__ unsigned pk_sub(unsigned a, unsigned b)
+{
+  return __builtin_bit_cast(unsigned, (i16x2)(__builtin_bit_cast(i16x2, a) - __builtin_bit_cast(i16x2, b)));
+}
+__device__ __forceinline__ unsigned pk_abs(unsigned a)
+{
+  const i16x2 v = __builtin_bit_cast(i16x2, a);
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(v, (i16x2)(-v)));
+}
+// sum of |WHT8x8| without DC, of a block held as 8 rows x 4 packed pairs (low half = even column), samples < 2^10
+__device__ __forceinline__ int src_had_packed(unsigned (&d)[32])
+{
+#pragma unroll
+  for (int hs = 1; hs < 8; hs <<= 1)  // vertical: rows y, y + hs
+#pragma unroll
+    for (int i = 0; i < 8; i += hs << 1)
+#pragma unroll
+      for (int y = i; y < i + hs; ++y)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const unsigned a = d[y * 4 + j], b = d[(y + hs) * 4 + j];
+          d[y * 4 + j] = pk_add(a, b); d[(y + hs) * 4 + j] = pk_sub(a, b);
+        }
+#pragma unroll
+  for (int hs = 1; hs < 4; hs <<= 1)  // horizontal distance 2 and 4: pairs j, j + hs
+#pragma unroll
+    for (int y = 0; y < 8; ++y)
+#pragma unroll
+      for (int i = 0; i < 4; i += hs << 1)
+#pragma unroll
+        for (int j = i; j < i + hs; ++j) {
+          const unsigned a = d[y * 4 + j], b = d[y * 4 + j + hs];
+          d[y * 4 + j] = pk_add(a, b); d[y * 4 + j + hs] = pk_sub(a, b);
+        }
+  // register 0 holds (a, b) with DC = a + b: only |a - b| counts; both are sums of 32 samples, no wrap
+  const int a0 = (int)(short)(d[0] & 0xFFFF), b0 = (int)(short)(d[0] >> 16);
+  unsigned acc = 0;
+#pragma unroll
+  for (int i = 1; i < 32; ++i) {
+    const unsigned a = pk_abs(d[i]);
+    acc += max(a & 0xFFFFu, a >> 16);
+  }
+  return (int)(2 * acc) + abs(a0 - b0);
+}
+
+template <typename T, bool PACKED>
 __global__ __launch_bounds__(256) void fhevc_src_hadamard_kernel(FhevcFrames F, int32_t* __restrict__ out)
 {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -47,6 +100,31 @@ __global__ __launch_bounds__(256) void fhevc_src_hadamard_kernel(FhevcFrames F, 
     const int cy = F.row_begin + rem / F.ctus_x, cx = rem % F.ctus_x;
     const int vw = min(64, F.width - cx * 64), vh = min(64, F.height - cy * 64);
     const bool ok = (bx * 8 + 8 <= vw) && (by * 8 + 8 <= vh);  // only WHOLE 8x8 blocks count (TEncCu.cpp:1334-1336)
+    int s = 0;
+    if (PACKED) {
+      unsigned d[32];
+      if (ok) {
+        const T* p = reinterpret_cast<const T*>(F.luma) + (long long)f * F.frame_stride +
+                     (long long)(cy * 64 + by * 8) * F.stride + cx * 64 + bx * 8;
+        const bool al = (reinterpret_cast<uintptr_t>(p) & (8 * sizeof(T) - 1)) == 0 && ((F.stride * sizeof(T)) & (8 * sizeof(T) - 1)) == 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const T* rp = p + (long long)j * F.stride;
+          if (al && sizeof(T) == 2) {
+            const uint4 q = *reinterpret_cast<const uint4*>(rp);
+            d[4 * j] = q.x; d[4 * j + 1] = q.y; d[4 * j + 2] = q.z; d[4 * j + 3] = q.w;
+          } else if (al) {
+            const uint2 q = *reinterpret_cast<const uint2*>(rp);  // bytes -> 16-bit pairs (0x0C selects a zero byte)
+            d[4 * j] = __builtin_amdgcn_perm(0u, q.x, 0x0C010C00u); d[4 * j + 1] = __builtin_amdgcn_perm(0u, q.x, 0x0C030C02u);
+            d[4 * j + 2] = __builtin_amdgcn_perm(0u, q.y, 0x0C010C00u); d[4 * j + 3] = __builtin_amdgcn_perm(0u, q.y, 0x0C030C02u);
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) d[4 * j + k] = ((unsigned)rp[2 * k] & 0xFFFFu) | ((unsigned)rp[2 * k + 1] << 16);
+          }
+        }
+        s = src_had_packed(d);
+      }
+    } else {
     int v[64];
     if (ok) {
       const T* p = reinterpret_cast<const T*>(F.luma) + (long long)f * F.frame_stride +
@@ -92,9 +170,9 @@ __global__ __launch_bounds__(256) void fhevc_src_hadamard_kernel(FhevcFrames F, 
             v[8 * j + k] = a + b;
             v[8 * (j + hstep) + k] = a - b;
           }
-    int s = 0;
 #pragma unroll
     for (int i = 1; i < 64; ++i) s += abs(v[i]);  // v[0] is the DC coefficient: left out (TEncCu.cpp:1319)
+    }
     s = ok ? ((s + 2) >> 2) : 0;
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) s += __shfl_xor(s, m);
@@ -152,10 +230,12 @@ hipError_t fhevc_launch_src_hadamard(const FhevcFrames& fr, int32_t* d_out, hipS
   if (total <= 0) return hipSuccess;
   long long groups = (total + 3) / 4;
   const int grid = (int)(((groups < 4096 ? groups : 4096) + 7) & ~7LL);  // multiple of 8: see the XCD remap in the kernel
-  if (fr.sample_bytes == 2)
-    hipLaunchKernelGGL(fhevc_src_hadamard_kernel<int16_t>, dim3(grid), dim3(256), 0, stream, fr, d_out);
+  if (fr.sample_bytes == 2 && fr.bit_depth <= 10)
+    hipLaunchKernelGGL((fhevc_src_hadamard_kernel<int16_t, true>), dim3(grid), dim3(256), 0, stream, fr, d_out);
+  else if (fr.sample_bytes == 2)
+    hipLaunchKernelGGL((fhevc_src_hadamard_kernel<int16_t, false>), dim3(grid), dim3(256), 0, stream, fr, d_out);
   else
-    hipLaunchKernelGGL(fhevc_src_hadamard_kernel<uint8_t>, dim3(grid), dim3(256), 0, stream, fr, d_out);
+    hipLaunchKernelGGL((fhevc_src_hadamard_kernel<uint8_t, true>), dim3(grid), dim3(256), 0, stream, fr, d_out);
   return hipGetLastError();
 }
 

@@ -135,6 +135,30 @@ def test_device_batch_logits_and_bands(oracle, torch_cuda):
     ctx.close()
 
 
+@pytest.mark.parametrize("bd", [8, 10, 12])
+def test_source_hadamard_extremes(oracle, bd):
+    """updateCtuDataISlice twin on patterns that maximise single coefficients: at 8/10 bit the kernel runs wrapping packed
+    16-bit butterflies (every coefficient but DC stays below 2^15, DC is not summed), at 12 bit the 32-bit path."""
+    W, H = 256, 128
+    top = (1 << bd) - 1
+    yy, xx = np.mgrid[0:H, 0:W]
+    rng = np.random.default_rng(bd)
+    patterns = [np.full((H, W), top), ((xx + yy) & 1) * top, (xx & 1) * top, ((yy >> 2) & 1) * top, ((xx >> 1) & 1) * top,
+                (((xx >> 2) ^ (yy >> 1)) & 1) * top, rng.integers(0, top + 1, (H, W)), np.where(rng.random((H, W)) < 0.5, 0, top)]
+    w = weights.random_weights(0)
+    ctx = capi.Context(W, H, bd, w)
+    m = frames.HM_MARGIN
+    for k, pat in enumerate(patterns):
+        buf = np.zeros((H + 2 * m, W + 2 * m), np.int16)
+        buf[m:m + H, m:m + W] = pat.astype(np.int16)
+        org, stride = m * (W + 2 * m) + m, W + 2 * m
+        exp = np.zeros(ctx.num_ctus, np.int32)
+        oracle.fho_frame_src_hadamard(op.ptr(buf.reshape(-1), org), stride, W, H, exp)
+        _, had = ctx.predict_frame(buf, org, stride)
+        assert np.array_equal(had, exp), (bd, k)
+    ctx.close()
+
+
 def test_soft_decision_ranges(oracle, torch_cuda):
     """fhevc_predict_frame_range / _device_range against the oracle's fho_depth_range_from_logits."""
     torch = torch_cuda
