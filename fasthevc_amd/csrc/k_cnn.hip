@@ -351,6 +351,16 @@ __device__ __forceinline__ unsigned long long stamp()
   return t;
 }
 
+// Per-phase re-derivation of the thread coordinates from an opaque copy of threadIdx.x: everything computed from them
+// (LDS addresses, lane classes) then lives only inside its phase instead of in ~20 kernel-long registers, which the
+// conv2 phase (weights 108 + accumulators 64 + fragment ring) had pushed into scratch (reloads stall on vmcnt(0)).
+#define FHEVC_PHASE_IDS                                   \
+  int tid = (int)threadIdx.x;                             \
+  asm volatile("" : "+v"(tid));                           \
+  const int lane = tid & 63, wave = tid >> 6;             \
+  const int r = lane & 31, h = lane >> 5;                 \
+  (void)r; (void)h; (void)wave;
+
 // STAMPS = true is a separate diagnostic instantiation (fhevc_debug_cnn_phase_cycles): wave 0 of every workgroup
 // adds the cycles of each phase (incl. the barrier that ends it) into d_stamps[blockIdx.x * 8 + phase].
 template <bool STAMPS>
@@ -439,6 +449,7 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
 
     // ====== P1: conv1 (1 -> 16): one MFMA per 32 positions x 2 rows, K = 4x3 window, fused maxpool + requant ======
     {
+      FHEVC_PHASE_IDS
       // unit = one pooled row of 32 positions (picture rows 2yp, 2yp+1, all 64 columns); lane (n, h): pooled column n,
       // K slots = the 4x4 input window of the 2x2 pre-pool outputs: lanes h=0 hold window columns 0-1, h=1 columns 2-3,
       // each column as two row-pair dwords -> the fragment is two ds_read_b64, all 16 K slots carry data
@@ -473,6 +484,7 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
 
     // ================= P2: conv2 (16 -> 32), K = 9 taps x 16 ch, fused maxpool + requant =================
     {
+      FHEVC_PHASE_IDS
       if (tid < 42) {  // logits start from the head biases (the previous CTU's logits were consumed before the P1 barrier)
         const int k = tid >> 1, cls = tid & 1;
         const int lvl = k == 0 ? 0 : (k < 5 ? 1 : 2);
@@ -518,6 +530,7 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
     // ================= P3: conv3 (32 -> 64), K = 9 taps x 32 ch, requant to u8 =================
     pre = prefetch_ctu(F, work + (int)gridDim.x < total, next, ld_row, ld_seg);  // next CTU's samples travel under conv3 and the heads
     {
+      FHEVC_PHASE_IDS
       // column rotation of the second row: with an 18-position (288 B) row pitch the 16 lanes of every ds_read_b128
       // group then cover 16 distinct 16-byte slots modulo 256 B
       const int yy = r >> 4, x = yy ? ((r - 2) & 15) : (r & 15);
@@ -548,7 +561,15 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
     FHEVC_STAMP(3)
 
     // ================= P4: FC heads on v_dot4_u32_u8 (weights stored as w+128, resident in LDS) =================
+    {  // conv1's fragments for the next CTU: issued first so that they have landed before the depth phase, whose spill
+       // reloads wait for vmcnt(0)
+      const uint4* fp = frag1p;
+      asm volatile("" : "+v"(fp));  // opaque address: keeps the re-fetch inside the loop
+      wA1a = __builtin_bit_cast(bf16x8, fp[0]);
+      wA1b = __builtin_bit_cast(bf16x8, fp[64]);
+    }
     {
+      FHEVC_PHASE_IDS
       // wave = 32x32 quadrant q; 16-lane DPP row = one 16x16 block of it; lane bits [1:0] = x & 3, [3:2] = y & 3
       const int q = wave, blk = lane >> 4;
       const int y = (q >> 1) * 8 + (blk >> 1) * 4 + ((lane >> 2) & 3);
@@ -600,12 +621,6 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
         atomicAdd(&logitL[1], q64b);
       }
     }
-    {
-      const uint4* fp = frag1p;
-      asm volatile("" : "+v"(fp));  // opaque address: keeps the re-fetch inside the loop
-      wA1a = __builtin_bit_cast(bf16x8, fp[0]);
-      wA1b = __builtin_bit_cast(bf16x8, fp[64]);
-    }
     // the A2/input region (R2) is free since the P3 barrier: stage the next CTU now, its P1 needs no extra barrier
     if (work + (int)gridDim.x < total) stage_ctu(lds, pre, F, next, tid, ld_row, ld_seg, shift_in);
     __syncthreads();
@@ -613,6 +628,7 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
 
     // ================= P5: top-down depth map (forced split at the picture edge), branch-free =================
     {
+      FHEVC_PHASE_IDS
       const int vw = min(64, F.width - cx * 64), vh = min(64, F.height - cy * 64);
       const int ux = tid & 15, uy = tid >> 4;
       const int2 l64 = *reinterpret_cast<const int2*>(logitL);
