@@ -64,12 +64,8 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b)
 {
   return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
 }
-// ReLU + fixed-point requantisation: clamp(floor(acc * 2^-shift), 0, 255); acc*2^-shift is exact in fp32
-__device__ __forceinline__ float requant(float acc, float scale)
-{
-  return __builtin_amdgcn_fmed3f(floorf(acc * scale), 0.0f, 255.0f);
-}
-// same with the bias folded in: (acc + b) * 2^-s == fma(acc, 2^-s, b * 2^-s), every term exact in fp32
+// ReLU + fixed-point requantisation clamp(floor((acc + b) * 2^-s), 0, 255) with the bias folded in:
+// (acc + b) * 2^-s == fma(acc, 2^-s, b * 2^-s), every term exact in fp32
 __device__ __forceinline__ float requant_b(float acc, float scale, float bias_scaled)
 {
   return __builtin_amdgcn_fmed3f(floorf(__builtin_fmaf(acc, scale, bias_scaled)), 0.0f, 255.0f);
@@ -125,13 +121,13 @@ __device__ __forceinline__ int dpp_row_sum(int v)
 // conv1: the two MFMAs of a unit hold, per lane, the four pre-pool outputs of 8 channels for ONE pooled position
 // (rows m of A: channel = m[1:0] + 4*m[3] + 8*m[2], pre-pool row = m[4], pre-pool column = m[5]; lane half h = m[2]
 // holds channels 8h..8h+7 = plane h).  2x2 max-pool = 3 in-lane max per channel, then requant and ONE 16-byte store.
-__device__ __forceinline__ void conv1_store(const f32x16& acc0, const f32x16& acc1, float scale, unsigned char* dst)
+__device__ __forceinline__ void conv1_store(const f32x16& acc0, const f32x16& acc1, unsigned char* dst)
 {
   float v[8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {  // regs k (py 0) and k+8 (py 1) of both MFMAs (px 0, 1)
-    const float m = fmaxf(fmaxf(acc0[k], acc0[k + 8]), fmaxf(acc1[k], acc1[k + 8]));
-    v[k] = requant(m, scale);
+  for (int k = 0; k < 8; ++k) {  // regs k (py 0) and k+8 (py 1) of both MFMAs (px 0, 1); the accumulators are already
+    const float m = fmaxf(fmaxf(acc0[k], acc0[k + 8]), fmaxf(acc1[k], acc1[k + 8]));  // scaled by 2^-s (weights, bias)
+    v[k] = __builtin_amdgcn_fmed3f(floorf(m), 0.0f, 255.0f);
   }
   *reinterpret_cast<uint4*>(dst) = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
 }
@@ -392,9 +388,9 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
 
   float* biasL = reinterpret_cast<float*>(lds + BIAS_OFF);
   int* logitL = reinterpret_cast<int*>(lds + LOGIT_OFF);
-  if (tid < 112) {  // b1 raw (accumulator init); b2, b3 pre-scaled (exact: integer * 2^-s); b3 also carries the floor offset
+  if (tid < 112) {  // all pre-scaled (exact: integer * 2^-s); b1 is the accumulator init of conv1, whose weights carry 2^-s1
     float b = W.bias[tid];
-    if (tid >= 16) b *= (tid < 48 ? W.scale[1] : W.scale[2]);
+    b *= (tid < 16 ? W.scale[0] : (tid < 48 ? W.scale[1] : W.scale[2]));
     if (tid >= 48) b += 0.5f * W.scale[2] - 0.5f;
     biasL[tid] = b;
   }
@@ -476,7 +472,7 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
         const f32x16 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA1a, bq, bias1, 0, 0, 0);
         const f32x16 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA1b, bq, bias1, 0, 0, 0);
         bq = frag1(min(yp + 4, 31));  // next unit's fragment travels during the epilogue (last one is redundant)
-        conv1_store(acc0, acc1, W.scale[0], a1dst + yp * (A1_PITCH * 16));
+        conv1_store(acc0, acc1, a1dst + yp * (A1_PITCH * 16));
       }
     }
     __syncthreads();
