@@ -118,11 +118,11 @@ int build_weight_image(fhevc_ctx* c, const BlobView& b)
   }
   std::vector<uint16_t> frag((size_t)FHEVC_FRAG_TOTAL * 8, 0);
   auto put = [&](int frag_idx, int lane, int j, int v) { frag[((size_t)frag_idx + lane) * 8 + j] = bf16_of_small_int(v); };
-  // conv1 weights carry the layer's 2^-shift: w * 2^-s is still exact in bf16 (a power-of-two scaling of an 8-bit integer)
+  // conv1 and conv2 weights carry their layer's 2^-shift: w * 2^-s is still exact in bf16 (a power-of-two scaling of an 8-bit integer)
   // and every partial sum is a multiple of 2^-s below 2^24 * 2^-s, so the fp32 accumulation stays exact and the MFMA
   // delivers (acc + b) * 2^-s directly: one multiply per output less in the epilogue
-  auto put1 = [&](int frag_idx, int lane, int j, int v) {
-    float f = std::ldexp((float)v, -rd32(b.shift, 0));
+  auto put_scaled = [&](int layer, int frag_idx, int lane, int j, int v) {
+    float f = std::ldexp((float)v, -rd32(b.shift, layer));
     uint32_t u;
     std::memcpy(&u, &f, 4);
     frag[((size_t)frag_idx + lane) * 8 + j] = (uint16_t)(u >> 16);
@@ -138,10 +138,10 @@ int build_weight_image(fhevc_ctx* c, const BlobView& b)
         const int ch = (r & 3) + 4 * ((r >> 3) & 1) + 8 * ((r >> 2) & 1), py = (r >> 4) & 1, px = jm;
         const int wc = 2 * h + ((j >> 1) & 1), wr = 2 * (j >> 2) + (j & 1);
         const int ky = wr - py, kx = wc - px;
-        if (ky >= 0 && ky <= 2 && kx >= 0 && kx <= 2) put1(FHEVC_FRAG_CONV1 + 64 * jm, lane, j, b.w1[ch * 9 + ky * 3 + kx]);
+        if (ky >= 0 && ky <= 2 && kx >= 0 && kx <= 2) put_scaled(0, FHEVC_FRAG_CONV1 + 64 * jm, lane, j, b.w1[ch * 9 + ky * 3 + kx]);
       }
       // conv2: K-step s = tap, k = input channel
-      for (int s = 0; s < 9; ++s) put(FHEVC_FRAG_CONV2 + s * 64, lane, j, b.w2[((r * 16 + k) * 9) + s]);
+      for (int s = 0; s < 9; ++s) put_scaled(1, FHEVC_FRAG_CONV2 + s * 64, lane, j, b.w2[((r * 16 + k) * 9) + s]);
       // conv3: tile t = 32 output channels; K-step s: tap = s>>1, input channel = 16*(s&1) + k
       for (int t = 0; t < 2; ++t)
         for (int s = 0; s < 18; ++s) {

@@ -64,12 +64,6 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b)
 {
   return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
 }
-// ReLU + fixed-point requantisation clamp(floor((acc + b) * 2^-s), 0, 255) with the bias folded in:
-// (acc + b) * 2^-s == fma(acc, 2^-s, b * 2^-s), every term exact in fp32
-__device__ __forceinline__ float requant_b(float acc, float scale, float bias_scaled)
-{
-  return __builtin_amdgcn_fmed3f(floorf(__builtin_fmaf(acc, scale, bias_scaled)), 0.0f, 255.0f);
-}
 __device__ __forceinline__ bf16x8 lds_frag(const unsigned char* p)
 {
   return *reinterpret_cast<const bf16x8*>(p);
@@ -133,18 +127,17 @@ __device__ __forceinline__ void conv1_store(const f32x16& acc0, const f32x16& ac
 }
 // conv2: two output rows -> 2x2 max-pool, requant, store: the even lane of a horizontal pair finishes planes 0-1
 // (regs 0-7), the odd lane planes 2-3 (regs 8-15): 8 requants and two 8-byte stores per lane
-// bb: the pre-scaled biases of the 8 channels this lane stores, read ONCE per phase: an LDS read inside the epilogue
-// makes the compiler drain lgkmcnt to 0 there, i.e. wait for every fragment read the ring has in flight
-__device__ __forceinline__ void conv2_store(const f32x16& acc0, const f32x16& acc1, const float (&bb)[8], float scale,
-                                            unsigned char* lds, int yp, int r, int h)
+// The accumulators start from the pre-scaled bias tile and conv2's weights carry 2^-s, so they already hold
+// (acc + b) * 2^-s (max-pooling commutes with the common bias): pool, floor, clamp, pack.
+__device__ __forceinline__ void conv2_store(const f32x16& acc0, const f32x16& acc1, unsigned char* lds, int yp, int r, int h)
 {
   const bool odd = r & 1;
   float v[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    const float m0 = max_with_xor1(fmaxf(acc0[k], acc1[k]));           // bias after the pool: max(a,b)+c == max(a+c,b+c)
+    const float m0 = max_with_xor1(fmaxf(acc0[k], acc1[k]));
     const float m1 = max_with_xor1(fmaxf(acc0[k + 8], acc1[k + 8]));
-    v[k] = requant_b(odd ? m1 : m0, scale, bb[k]);
+    v[k] = __builtin_amdgcn_fmed3f(floorf(odd ? m1 : m0), 0.0f, 255.0f);
   }
   unsigned char* dst = lds + R2_OFF + (odd ? 2 * A2_PLANE : 0) + ((yp + 1) * A2_PITCH + (r >> 1) + 1) * 16 + h * 8;
   *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
@@ -191,10 +184,10 @@ __device__ __forceinline__ const unsigned char* conv2_frag(const unsigned char* 
 }
 template <bool FIRST, bool LAST>
 __device__ __forceinline__ void conv2_unit(const unsigned char* a1, int yp, int yp_next, const bf16x8 (&wA2)[9], bf16x8 (&ring)[RING],
-                                           f32x16& acc0, f32x16& acc1)
+                                           const f32x16& binit, f32x16& acc0, f32x16& acc1)
 {
-#pragma unroll
-  for (int k = 0; k < 16; ++k) { acc0[k] = 0.0f; acc1[k] = 0.0f; }
+  acc0 = binit;  // C operand of the first MFMA of each accumulator: the bias costs nothing
+  acc1 = binit;
   const unsigned char* base = a1 + (2 * yp) * A1_PITCH * 16;  // halo rows 2yp .. 2yp+3
   const unsigned char* next = a1 + (2 * yp_next) * A1_PITCH * 16;
   if (FIRST) {
@@ -498,27 +491,22 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
       const unsigned char* a1p = lds + R1_OFF + h * A1_PLANE + r * 16;
       // straight-line software pipeline over the wave's 4 units: the MFMA chain of unit i+1 is issued before the
       // VALU epilogue of unit i, so the scheduler can interleave them (separate pipes)
-      float bb2[8];  // pre-scaled bias of the channels this lane stores (even lane: planes 0-1, odd lane: planes 2-3)
-      {
-        const float* bp = biasL + 16 + ((r & 1) ? 16 : 0) + 4 * h;
-        const float4 bA = *reinterpret_cast<const float4*>(bp), bB = *reinterpret_cast<const float4*>(bp + 8);
-        bb2[0] = bA.x; bb2[1] = bA.y; bb2[2] = bA.z; bb2[3] = bA.w; bb2[4] = bB.x; bb2[5] = bB.y; bb2[6] = bB.z; bb2[7] = bB.w;
-      }
+      const f32x16 b2t = bias_tile(biasL + 16, h);  // pre-scaled conv2 biases in the accumulator layout, once per phase
       f32x16 a0, a1, b0, b1;
       bf16x8 ring[RING];
-      conv2_unit<true, false>(a1p, wave, wave + 4, wA2, ring, a0, a1);
-      __builtin_amdgcn_sched_group_barrier(0x100, RING + 2, 0);  // bias + the ring's first fragments go out together
+      conv2_unit<true, false>(a1p, wave, wave + 4, wA2, ring, b2t, a0, a1);
+      __builtin_amdgcn_sched_group_barrier(0x100, RING + 4, 0);  // bias tile + the ring's first fragments go out together
       sched_chain18<0>();
-      conv2_unit<false, false>(a1p, wave + 4, wave + 8, wA2, ring, b0, b1);
-      conv2_store(a0, a1, bb2, W.scale[1], lds, wave, r, h);
+      conv2_unit<false, false>(a1p, wave + 4, wave + 8, wA2, ring, b2t, b0, b1);
+      conv2_store(a0, a1, lds, wave, r, h);
       sched_chain18<5>();
-      conv2_unit<false, false>(a1p, wave + 8, wave + 12, wA2, ring, a0, a1);
-      conv2_store(b0, b1, bb2, W.scale[1], lds, wave + 4, r, h);
+      conv2_unit<false, false>(a1p, wave + 8, wave + 12, wA2, ring, b2t, a0, a1);
+      conv2_store(b0, b1, lds, wave + 4, r, h);
       sched_chain18<5>();
-      conv2_unit<false, true>(a1p, wave + 12, wave + 12, wA2, ring, b0, b1);
-      conv2_store(a0, a1, bb2, W.scale[1], lds, wave + 8, r, h);
+      conv2_unit<false, true>(a1p, wave + 12, wave + 12, wA2, ring, b2t, b0, b1);
+      conv2_store(a0, a1, lds, wave + 8, r, h);
       sched_chain18<5>();
-      conv2_store(b0, b1, bb2, W.scale[1], lds, wave + 12, r, h);
+      conv2_store(b0, b1, lds, wave + 12, r, h);
     }
     __syncthreads();
     FHEVC_STAMP(2)
