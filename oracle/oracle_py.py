@@ -109,8 +109,9 @@ def have_hook():
 
 def load_ref(hook=False):
     """Open oracle/_ref/libhmref.so (or the hook variant, libhmref_hook.so = the same reference objects with
-    hm_patch/ applied) with RTLD_LAZY: one never-called reference symbol stays unresolved, see oracle/Makefile."""
-    path = HOOK_SO if hook else REF_SO
+    hm_patch/ applied; hook="gpu": libhmref_hookgpu.so, whose TEncFastDepth calls the real GPU library) with
+    RTLD_LAZY: one never-called reference symbol stays unresolved, see oracle/Makefile."""
+    path = HOOK_SO.replace("_hook.so", "_hookgpu.so") if hook == "gpu" else (HOOK_SO if hook else REF_SO)
     libdl = C.CDLL(None)
     libdl.dlopen.restype = C.c_void_p
     libdl.dlopen.argtypes = [C.c_char_p, C.c_int]
