@@ -51,9 +51,36 @@ def cpu_baseline(width, height, bit_depth, w, seconds=12.0):
             crops += 1
             if spent > seconds:
                 break
-        return {"value": done / spent, "unit": "CTU depth decisions/s", "cores": 1, "kind": "reference",
-                "sample": f"{crops} crops of 768x512 ({done} CTUs) of the same 1080p hetero frame at QP32 through the reference's own "
-                          f"TEncSlice::compressSlice/TEncCu::xCompressCU full RDO (intra_main settings), {spent:.1f} s of 1 thread"}
+        out = {"value": done / spent, "unit": "CTU depth decisions/s", "cores": 1, "kind": "reference",
+               "sample": f"{crops} crops of 768x512 ({done} CTUs) of the same 1080p hetero frame at QP32 through the reference's own "
+                         f"TEncSlice::compressSlice/TEncCu::xCompressCU full RDO (intra_main settings), {spent:.1f} s of 1 thread"}
+        # the same compressSlice with the hm_patch hook linked to the GPU library (oracle/_ref/libhmref_hookgpu.so): HM's
+        # decision stage end to end, GPU call (H2D + kernels + D2H) included, on the same crops
+        gpu_so = os.path.join(ROOT, "oracle", "_ref", "libhmref_hookgpu.so")
+        blob = os.path.join(ROOT, "fasthevc_amd", "weights", "depthnet_v1.fhw")
+        if os.path.exists(gpu_so) and os.path.exists(blob):
+            knobs = {"FHEVC_ENABLE": "1", "FHEVC_WEIGHTS": blob, "FHEVC_MARGIN_SPLIT": "32000", "FHEVC_MARGIN_STOP": "0"}
+            saved = {k: os.environ.get(k) for k in knobs}
+            os.environ.update(knobs)
+            try:
+                glib = op.bind_rdo(op.load_ref(hook="gpu"))
+                gdone, gspent = 0, 0.0
+                for (ox, oy) in ((0, 0), (768, 0), (1152, 0), (0, 512), (768, 512), (1152, 512), (384, 256), (960, 256))[:crops]:
+                    buf, org, stride = frames.to_pel_plane(luma[oy:oy + ch_, ox:ox + cw_].copy(), bit_depth)
+                    chroma = tuple((c[oy // 2:(oy + ch_) // 2, ox // 2:(ox + cw_) // 2].astype(np.int16) << (bit_depth - 8)) for c in (cu, cv))
+                    _, st = op.rdo_encode(glib, buf, org, stride, cw_, ch_, bit_depth, 32, chroma=chroma)
+                    gdone += st["ctus"]
+                    gspent += st["seconds"]
+                out["with_gpu_hook"] = {"value": gdone / gspent, "unit": "CTUs/s through compressSlice", "speedup": (gdone / gspent) / (done / spent),
+                                        "sample": f"{gdone} CTUs, same crops, hm_patch hook -> fhevc_predict_frame_range (margin_split 32000), "
+                                                  f"{gspent:.1f} s of 1 thread incl. the GPU calls"}
+            finally:
+                for k, v in saved.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
+        return out
     oracle = op.load_oracle()
     ws = op.weights_from_arrays(w)
     buf, org, stride = frames.to_pel_plane(luma, bit_depth)
