@@ -83,6 +83,119 @@ def hetero_yuv420(width, height, seed=4321):
     return y.tobytes() + u.tobytes() + v.tobytes()
 
 
+def fractal_luma(width, height, seed=777, beta=None, shapes=None):
+    """Third synthetic family (neither of SURVEY 8(d)'s generators): 1/f^beta spectral noise, a soft vignette, a few flat
+    rectangles and a thin diagonal line.  beta / shapes default to seeded random draws."""
+    rng = np.random.default_rng(seed)
+    beta = float(rng.uniform(0.9, 1.9)) if beta is None else beta
+    fy, fx = np.fft.fftfreq(height)[:, None], np.fft.rfftfreq(width)[None, :]
+    f = np.sqrt(fx * fx + fy * fy)
+    f[0, 0] = 1.0
+    spec = (rng.normal(size=f.shape) + 1j * rng.normal(size=f.shape)) / f ** beta
+    spec[0, 0] = 0
+    y = np.fft.irfft2(spec, s=(height, width))
+    y = (y - y.mean()) / y.std() * float(rng.uniform(25.0, 55.0)) + float(rng.uniform(100.0, 150.0))
+    yy, xx = np.mgrid[0:height, 0:width]
+    y -= float(rng.uniform(0.0, 40.0)) * (((xx - width / 2) / width) ** 2 + ((yy - height / 2) / height) ** 2)
+    n_shapes = int(rng.integers(0, 5)) if shapes is None else shapes
+    for _ in range(n_shapes):
+        w, h = int(rng.integers(width // 12, width // 3)), int(rng.integers(height // 10, height // 3))
+        x0, y0 = int(rng.integers(0, width - w)), int(rng.integers(0, height - h))
+        y[y0:y0 + h, x0:x0 + w] = float(rng.uniform(30, 225))
+    if rng.random() < 0.6:
+        y[np.abs(yy - (float(rng.uniform(-1.2, 1.2)) * xx + float(rng.uniform(0, height)))) < 1.5] = float(rng.choice([20.0, 235.0]))
+    return np.clip(np.rint(y), 0, 255).astype(np.uint8)
+
+
+def gratings_luma(width, height, seed=777):
+    """Fourth synthetic family: sinusoidal gratings whose frequency and orientation change per region, Gaussian blobs,
+    step edges and text-like strokes (all seeded)."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:height, 0:width].astype(np.float64)
+    y = np.full((height, width), float(rng.uniform(90, 150)))
+    reg = int(rng.choice([128, 192, 256, 384]))
+    fmax = float(rng.choice([0.08, 0.2, 0.35]))
+    for by in range(0, height, reg):
+        for bx in range(0, width, reg):
+            fr, th, amp = rng.uniform(0.01, fmax), rng.uniform(0, np.pi), rng.uniform(0, 60)
+            sl = (slice(by, min(by + reg, height)), slice(bx, min(bx + reg, width)))
+            y[sl] += amp * np.sin(2 * np.pi * fr * (np.cos(th) * xx[sl] + np.sin(th) * yy[sl]))
+    for _ in range(int(rng.integers(0, 16))):
+        cx, cy, sg, a = rng.uniform(0, width), rng.uniform(0, height), rng.uniform(20, 120), rng.uniform(-70, 70)
+        y += a * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * sg * sg))
+    if rng.random() < 0.7:
+        x0 = int(rng.integers(0, width // 2))
+        y[:, x0:x0 + width // 6] += float(rng.uniform(-50, 50))
+    for _ in range(int(rng.integers(0, 200))):
+        x0, y0, ln, horiz = int(rng.integers(0, width - 40)), int(rng.integers(0, height - 40)), int(rng.integers(6, 40)), rng.random() < 0.5
+        if horiz:
+            y[y0:y0 + 2, x0:x0 + ln] = 25.0
+        else:
+            y[y0:y0 + ln, x0:x0 + 2] = 25.0
+    return np.clip(np.rint(y), 0, 255).astype(np.uint8)
+
+
+def polygon_luma(width, height, seed=777):
+    """Fifth synthetic family: flat or shaded half-planes and discs stacked at random, with a little sensor noise."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:height, 0:width].astype(np.float64)
+    y = np.full((height, width), float(rng.uniform(60, 200)))
+    for _ in range(int(rng.integers(6, 40))):
+        v = float(rng.uniform(10, 245))
+        if rng.random() < 0.5:
+            cx, cy, r = rng.uniform(0, width), rng.uniform(0, height), rng.uniform(10, min(width, height) / 3)
+            m = (xx - cx) ** 2 + (yy - cy) ** 2 < r * r
+        else:
+            th, c = rng.uniform(0, 2 * np.pi), rng.uniform(0.15, 0.85)
+            m = (np.cos(th) * (xx / width - c) + np.sin(th) * (yy / height - c) > 0) & (rng.random() < 0.5 or True)
+            m &= (np.abs(xx - rng.uniform(0, width)) < rng.uniform(40, width / 2)) & (np.abs(yy - rng.uniform(0, height)) < rng.uniform(40, height / 2))
+        shade = float(rng.uniform(-0.08, 0.08)) if rng.random() < 0.5 else 0.0
+        y = np.where(m, v + shade * (xx - width / 2), y)
+    y += rng.normal(0, float(rng.uniform(0.0, 3.0)), size=y.shape)
+    return np.clip(np.rint(y), 0, 255).astype(np.uint8)
+
+
+def chirp_luma(width, height, seed=777):
+    """Sixth synthetic family: zone plates (radial chirps), checkerboards of several scales and smooth ramps."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:height, 0:width].astype(np.float64)
+    y = np.full((height, width), float(rng.uniform(100, 150))) + float(rng.uniform(-40, 40)) * (xx / width - 0.5)
+    for _ in range(int(rng.integers(1, 4))):
+        cx, cy = rng.uniform(0, width), rng.uniform(0, height)
+        r2 = (xx - cx) ** 2 + (yy - cy) ** 2
+        y += float(rng.uniform(20, 80)) * np.cos(r2 / (2.0 * float(rng.uniform(300, 3000)))) * np.exp(-r2 / (2 * (float(rng.uniform(0.2, 0.6)) * height) ** 2))
+    for _ in range(int(rng.integers(0, 5))):
+        w, h = int(rng.integers(width // 10, width // 3)), int(rng.integers(height // 8, height // 2))
+        x0, y0 = int(rng.integers(0, width - w)), int(rng.integers(0, height - h))
+        sc = int(rng.choice([2, 4, 8, 16, 32, 64]))
+        chk = ((xx[y0:y0 + h, x0:x0 + w] // sc + yy[y0:y0 + h, x0:x0 + w] // sc) % 2) * 2.0 - 1.0
+        y[y0:y0 + h, x0:x0 + w] = float(rng.uniform(90, 160)) + float(rng.uniform(5, 60)) * chk
+    y += rng.normal(0, float(rng.uniform(0.0, 2.5)), size=y.shape)
+    return np.clip(np.rint(y), 0, 255).astype(np.uint8)
+
+
+def deadleaves_luma(width, height, seed=777, leaves=900):
+    """Dead-leaves picture (occluding discs with a power-law size distribution, each flat, noisy or finely textured):
+    the classic natural-image surrogate.  Used as the HELD-OUT evaluation family: never part of the training labels."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:height, 0:width].astype(np.float64)
+    y = np.full((height, width), 128.0)
+    for _ in range(leaves):
+        r = 6.0 / (rng.uniform(0.02, 1.0) ** 1.0)          # radii 6 .. 300, density ~ r^-2
+        cx, cy = rng.uniform(-50, width + 50), rng.uniform(-50, height + 50)
+        m = (xx - cx) ** 2 + (yy - cy) ** 2 < r * r
+        kind, v = rng.integers(0, 3), rng.uniform(25, 230)
+        if kind == 0:
+            tex = 0.0
+        elif kind == 1:
+            tex = rng.normal(0, rng.uniform(2, 14), size=y.shape)
+        else:
+            th, fr = rng.uniform(0, np.pi), rng.uniform(0.02, 0.3)
+            tex = rng.uniform(4, 25) * np.sin(2 * np.pi * fr * (np.cos(th) * xx + np.sin(th) * yy))
+        y = np.where(m, v + tex, y)
+    return np.clip(np.rint(_box_blur(y, 3)), 0, 255).astype(np.uint8)
+
+
 def to_pel_plane(luma_u8, internal_bit_depth=8, margin=HM_MARGIN):
     """uint8 luma -> int16 `Pel` plane laid out like TComPicYuv (TComPicYuv.cpp:81-119): stride = W + 2*margin,
     origin at (margin, margin), samples left-shifted to the internal bit depth (TVideoIOYuv.cpp:70-84,730).

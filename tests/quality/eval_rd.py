@@ -25,6 +25,21 @@ from fasthevc_amd import frames, weights  # noqa: E402
 QPS = (22, 27, 32, 37)
 
 
+def ood_luma(width, height, seed=777):
+    """Held-out family (no generator of the training labels produces anything like it): a zone plate (radial chirp),
+    checkerboards whose scale changes per band, and a smooth ramp."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:height, 0:width].astype(np.float64)
+    r2 = (xx - width * 0.35) ** 2 + (yy - height * 0.5) ** 2
+    y = 128.0 + 70.0 * np.cos(r2 / (2.0 * 900.0)) * np.exp(-r2 / (2 * (0.45 * height) ** 2))
+    band = (xx > width * 0.62)
+    scale = np.choose(np.minimum((yy / (height / 5)).astype(int), 4), [4, 8, 16, 32, 64])
+    chk = ((xx // scale + yy // scale) % 2) * 2.0 - 1.0
+    y = np.where(band, 128.0 + 55.0 * chk, y)
+    y += 25.0 * (xx / width - 0.5) + rng.normal(0, 1.5, size=y.shape)
+    return np.clip(np.rint(y), 0, 255).astype(np.uint8)
+
+
 def bd_rate(r_anchor, p_anchor, r_test, p_test):
     """Bjontegaard delta rate (%), cubic fit of log-rate over PSNR, integrated over the common PSNR interval."""
     la, lt = np.log(np.asarray(r_anchor, float)), np.log(np.asarray(r_test, float))
@@ -54,9 +69,17 @@ def main():
     cw_, ch_ = (int(v) for v in args.crop.split("x"))
     report = {}
     for name in args.content.split(","):
-        full = frames.hetero_luma(1920, 1080) if name == "hetero" else frames.texture16_luma(1920, 1080)
+        if name in ("ood", "fractal", "gratings", "polygon", "chirp", "deadleaves"):
+            full = {"ood": ood_luma, "fractal": lambda w, h: frames.fractal_luma(w, h, seed=424242),
+                    "chirp": lambda w, h: frames.chirp_luma(w, h, seed=424242),
+                    "deadleaves": lambda w, h: frames.deadleaves_luma(w, h, seed=424242),
+                    "gratings": lambda w, h: frames.gratings_luma(w, h, seed=424242),
+                    "polygon": lambda w, h: frames.polygon_luma(w, h, seed=424242)}[name](1920, 1080)
+            cu = cv = np.full((540, 960), 128, np.uint8)
+        else:
+            full = frames.hetero_luma(1920, 1080) if name == "hetero" else frames.texture16_luma(1920, 1080)
+            cu, cv = frames.chroma_planes(name, 1920, 1080)
         luma = full[:ch_, :cw_].copy()
-        cu, cv = frames.chroma_planes(name, 1920, 1080)
         chroma = (cu[:ch_ // 2, :cw_ // 2].astype(np.int16), cv[:ch_ // 2, :cw_ // 2].astype(np.int16))
         buf, org, stride = frames.to_pel_plane(luma, 8)
         H, Wd = luma.shape

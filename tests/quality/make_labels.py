@@ -28,6 +28,16 @@ def training_picture(seed):
     """Seeded content different from the two pinned evaluation pictures (other seeds, random contrast/brightness)."""
     rng = np.random.default_rng(10_000 + seed)
     kind = seed % 4
+    if seed >= 5000:  # further families, flat mid-grey chroma: 1000.. fractal, 2000.. gratings, 3000.. polygons, 4000.. chirps,
+        return frames.deadleaves_luma(W, H, seed=70_000 + seed, leaves=int(rng.integers(150, 900))), "flatchroma"  # 5000.. dead leaves
+    if seed >= 4000:
+        return frames.chirp_luma(W, H, seed=70_000 + seed), "flatchroma"
+    if seed >= 3000:
+        return frames.polygon_luma(W, H, seed=70_000 + seed), "flatchroma"
+    if seed >= 2000:
+        return frames.gratings_luma(W, H, seed=70_000 + seed), "flatchroma"
+    if seed >= 1000:
+        return frames.fractal_luma(W, H, seed=70_000 + seed), "flatchroma"
     if kind == 3:
         y = frames.texture16_luma(W, H, seed=50_000 + seed, frame=int(rng.integers(0, 50))).astype(np.float64)
     else:
@@ -44,7 +54,7 @@ def work(seed):
     from oracle import oracle_py as op
     lib = op.bind_rdo(op.load_ref())
     luma, kind = training_picture(seed)
-    chroma = tuple(c.astype(np.int16) for c in frames.chroma_planes(kind, W, H))
+    chroma = None if kind == "flatchroma" else tuple(c.astype(np.int16) for c in frames.chroma_planes(kind, W, H))
     buf, org, stride = frames.to_pel_plane(luma, 8)
     cw, ch = W // 64, H // 64
     tiles = luma.reshape(ch, 64, cw, 64).transpose(0, 2, 1, 3).reshape(cw * ch, 64, 64)

@@ -16,6 +16,10 @@ def test_synthetic_frames_are_pinned():
     # md5 of the 4:2:0 files, SURVEY.md section 8(d)
     assert hashlib.md5(frames.texture16_yuv420(416, 240)).hexdigest() == "913977ec4bc414503cefc9e5a8d0bcc3"
     assert hashlib.md5(frames.hetero_yuv420(1920, 1080)).hexdigest() == "d2a7dee5ef67252b527b2f66fcaed0ca"
+    # the further training / evaluation families (tests/quality): pinned so that labels and BD-rate numbers stay reproducible
+    assert hashlib.md5(frames.fractal_luma(416, 240, seed=424242).tobytes()).hexdigest() == "60d4b75bd42ccf9a10193c3b4a792c8b"
+    assert hashlib.md5(frames.gratings_luma(416, 240, seed=424242).tobytes()).hexdigest() == "72c78d42644f4230606f504b0c9d332c"
+    assert hashlib.md5(frames.polygon_luma(416, 240, seed=424242).tobytes()).hexdigest() == "05b8769a68e6b1a5c02877cd0ba0e4c5"
 
 
 def test_pel_plane_layout():
