@@ -13,7 +13,12 @@
 #endif
 
 TEncFastDepth::TEncFastDepth()
-  : m_enabled(false), m_valid(false), m_external(false), m_ctx(NULL), m_width(0), m_height(0), m_bitDepth(0), m_marginSplit(0), m_marginStop(0)
+  : m_enabled(false), m_valid(false), m_external(false), m_ctx(NULL), m_width(0), m_height(0), m_bitDepth(0), m_marginSplit(0), m_marginStop(0), m_pWindow(-1)
+{
+  readKnobs();
+}
+
+void TEncFastDepth::readKnobs()
 {
   const char* en = std::getenv("FHEVC_ENABLE");
   m_enabled = en != NULL && en[0] == '1';
@@ -24,6 +29,8 @@ TEncFastDepth::TEncFastDepth()
   m_marginStop  = mt ? std::atoi(mt) : (mg ? std::atoi(mg) : 0);
   if (m_marginSplit < 0) m_marginSplit = 0;
   if (m_marginStop < 0) m_marginStop = 0;
+  const char* pw = std::getenv("FHEVC_P_WINDOW");
+  m_pWindow = pw ? std::atoi(pw) : -1;
 }
 
 TEncFastDepth::~TEncFastDepth()
@@ -48,6 +55,32 @@ bool TEncFastDepth::predictPicture(TComPic* pcPic, int sliceQp, int sliceType)
 {
   if (m_external) return true;       // validation feed wins
   m_valid = false;
+  if (sliceType != I_SLICE)
+  {
+    // Inter-CU depth reuse (config 4): the classifier is trained on intra decisions, so P/B pictures take their depth range
+    // from the co-located depths of their first reference picture, +- FHEVC_P_WINDOW levels -- but only when that picture
+    // was itself inter coded (intra depths say little about inter depths).  No GPU work: the depths are in the DPB.
+    if (m_pWindow < 0) return false;
+    TComSlice* slice = pcPic->getSlice(pcPic->getCurrSliceIdx());
+    if (slice->getNumRefIdx(REF_PIC_LIST_0) < 1) return false;
+    TComPic* ref = slice->getRefPic(REF_PIC_LIST_0, 0);
+    if (ref == NULL || ref->getSlice(0)->getSliceType() == I_SLICE) return false;
+    const int numCtus = (int)pcPic->getNumberOfCtusInFrame();
+    m_depth.resize((size_t)numCtus * 256);
+    m_depthMax.resize(m_depth.size());
+    for (int c = 0; c < numCtus; c++)
+    {
+      const TComDataCU* ctu = ref->getCtu(c);
+      for (int r = 0; r < 256; r++)
+      {
+        const int d = (int)ctu->getDepth(g_auiRasterToZscan[r]);
+        m_depth[(size_t)c * 256 + r]    = (unsigned char)(d - m_pWindow < 0 ? 0 : d - m_pWindow);
+        m_depthMax[(size_t)c * 256 + r] = (unsigned char)(d + m_pWindow > 3 ? 3 : d + m_pWindow);
+      }
+    }
+    m_valid = true;
+    return true;
+  }
   if (!m_enabled) return false;
 #ifdef FHEVC_HOOK_NO_GPU
   (void)pcPic; (void)sliceQp; (void)sliceType;
@@ -90,10 +123,23 @@ bool TEncFastDepth::predictPicture(TComPic* pcPic, int sliceQp, int sliceType)
 bool TEncFastDepth::forcedRange(const TComDataCU* pcCU, int& dmin, int& dmax) const
 {
   if (!m_valid) return false;
-  const size_t idx = (size_t)pcCU->getCtuRsAddr() * 256 + g_auiZscanToRaster[pcCU->getZorderIdxInCtu()];
-  if (idx >= m_depth.size() || idx >= m_depthMax.size()) return false;
-  dmin = (int)m_depth[idx];
-  dmax = (int)m_depthMax[idx];
+  const size_t base = (size_t)pcCU->getCtuRsAddr() * 256;
+  if (base + 256 > m_depth.size() || base + 256 > m_depthMax.size()) return false;
+  // the CU's area in 4x4 units: a node must split if ANY unit inside asks for a deeper CU, and may split if any unit allows
+  // it (for the maps the library produces -- constant inside every CU -- this equals reading the top-left unit; it keeps
+  // per-unit ranges from other sources, e.g. the temporal window, consistent over the node)
+  const int raster = (int)g_auiZscanToRaster[pcCU->getZorderIdxInCtu()];
+  const int ux = raster & 15, uy = raster >> 4, n = 16 >> (int)pcCU->getDepth(0);
+  int lo = 0, hi = 0;
+  for (int y = uy; y < uy + n && y < 16; y++)
+    for (int x = ux; x < ux + n && x < 16; x++)
+    {
+      const int a = (int)m_depth[base + (size_t)y * 16 + x], b = (int)m_depthMax[base + (size_t)y * 16 + x];
+      if (a > lo) lo = a;
+      if (b > hi) hi = b;
+    }
+  dmin = lo;
+  dmax = hi;
   return dmax >= dmin;
 }
 
@@ -103,6 +149,10 @@ void fhevc_hook_register(TEncFastDepth* p) { g_hookInstance = p; }
 extern "C" void fhevc_hook_set_external_map(const unsigned char* map, int num_ctus)
 {
   if (g_hookInstance != NULL) g_hookInstance->setExternalMap(map, num_ctus);
+}
+extern "C" void fhevc_hook_reload_knobs()   // the harness changes the environment between pictures
+{
+  if (g_hookInstance != NULL) g_hookInstance->readKnobs();
 }
 extern "C" void fhevc_hook_set_external_range(const unsigned char* map_min, const unsigned char* map_max, int num_ctus)
 {

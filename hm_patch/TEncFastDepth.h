@@ -12,6 +12,8 @@
  *   FHEVC_MARGIN=<int>        soft decisions: logit margin inside which a split decision is left to HM's RDO (default 0);
  *   FHEVC_MARGIN_SPLIT / FHEVC_MARGIN_STOP set the two sides separately (not forcing unsure splits is almost free,
  *                             not forbidding unsure ones costs the recursion it allows)
+ *   FHEVC_P_WINDOW=<w>        P/B pictures: restrict the depth search to the co-located depth of the first reference picture
+ *                             +- w levels when that picture was inter coded (default: off); independent of FHEVC_ENABLE
  */
 #ifndef __TENCFASTDEPTH__
 #define __TENCFASTDEPTH__
@@ -27,6 +29,7 @@ class TEncFastDepth
 public:
   TEncFastDepth();
   ~TEncFastDepth();
+  void readKnobs();   ///< (re-)read the environment knobs; the constructor calls it
 
   /// one GPU pass over the original luma plane of pcPic; false -> this picture runs stock RDO
   bool predictPicture(TComPic* pcPic, int sliceQp, int sliceType);
@@ -41,7 +44,7 @@ public:
 private:
   bool       m_enabled, m_valid, m_external;
   fhevc_ctx* m_ctx;
-  int        m_width, m_height, m_bitDepth, m_marginSplit, m_marginStop;
+  int        m_width, m_height, m_bitDepth, m_marginSplit, m_marginStop, m_pWindow;
   std::vector<unsigned char> m_depth;     // numCtus * 256, raster 16x16 per CTU: depth_min
   std::vector<unsigned char> m_depthMax;  // depth_max (== m_depth when the margin is 0)
 };

@@ -57,6 +57,7 @@
 // provided by the hook build (hm_patch/TEncFastDepth.cpp compiled into this library): explicit depth map feed
 extern "C" void fhevc_hook_set_external_map(const unsigned char* map, int num_ctus);
 extern "C" void fhevc_hook_set_external_range(const unsigned char* map_min, const unsigned char* map_max, int num_ctus);
+extern "C" void fhevc_hook_reload_knobs();
 void fhevc_hook_register(TEncFastDepth* p);
 #endif
 
@@ -84,6 +85,9 @@ struct Encoder {
   TEncRateCtrl rc;
   TEncSbac*** rdSbac = nullptr;
   TComPic* pic = nullptr;
+  TComPic* pic0 = nullptr;   // the first picture object (pic may point to either while P pictures ping-pong)
+  TComPic* pic1 = nullptr;   // second picture object (P-slice variant)
+  TComPic* last = nullptr;   // the picture encoded last: reference of the next P picture
 };
 
 std::map<long long, Encoder*> g_encoders;
@@ -239,6 +243,7 @@ Encoder* get_encoder(int w, int h, int bd)
 
   e->pic = new TComPic();
   e->pic->create(e->sps, e->pps, true, true);
+  e->pic0 = e->pic;
   g_encoders[key] = e;
   return e;
 }
@@ -358,6 +363,7 @@ int href_rdo_encode_frame_yuv(const int16_t* luma, int stride, const int16_t* cb
     stats[4] = sse;
     stats[5] = n;
   }
+  e->last = e->pic;  // reference of a following P picture (href_rdo_encode_next_p, P-variant builds)
   return 0;
 }
 
@@ -427,6 +433,74 @@ int href_aq_qp(const int16_t* luma, int stride, int width, int height, int bit_d
   pic.destroy();
   return (int)k;
 }
+
+#ifdef FHEVC_PVAR
+// ---- config 4 (encoder_lowdelay_P_main.cfg): the NEXT picture as a P slice predicted from the reconstruction of the picture
+// encoded last in this geometry (by href_rdo_encode_frame[_yuv] = I slice, or by this function), through the reference's own
+// compressSlice with HM-16.14's inter checks restored (hm_patch/restore_inter.py; as shipped the reference aborts on any
+// non-I slice: SURVEY F6).  Differences to the full encoder, all documented in DESIGN.md: one reference picture, no
+// in-loop filters on it, TMVP off, QP of the P picture given by the caller (TEncSlice::initEncSlice derives QP + QPOffset +
+// model offset from the GOP entry), lambda = 0.57 * 2^((qp-12)/3) as under LambdaFromQpEnable.
+// forced_min/forced_max: optional depth range (hook), NULL = full RDO.  stats as href_rdo_encode_frame, [7] = skipped share.
+int href_rdo_encode_next_p(const int16_t* luma, const int16_t* cb, const int16_t* cr, int stride, int width, int height,
+                           int bit_depth, int qp, int poc, const uint8_t* forced_min, const uint8_t* forced_max,
+                           uint8_t* depth_out, double* stats)
+{
+  if ((width % 8) || (height % 8) || width < 64 || height < 64) return -1;
+  Encoder* e = get_encoder(width, height, bit_depth);
+  if (!e->last) return -3;  // nothing encoded yet in this geometry
+  e->cfg.setUseHADME(true); e->cfg.setFastInterSearchMode(FASTINTERSEARCH_DISABLED);
+  e->cfg.setDisableIntraPUsInInterSlices(false); e->cfg.setRestrictMESampling(false);
+  e->cfg.setClipForBiPredMeEnabled(false); e->cfg.setFastMEAssumingSmootherMVEnabled(false);
+  e->cfg.setSearchRange(64); e->cfg.setMinSearchWindow(8); e->cfg.setBipredSearchRange(4);
+  const int n = (int)e->pic->getNumberOfCtusInFrame();
+  // the last reconstruction becomes the reference picture: borders extended for motion search, motion field compressed
+  TComPic* ref = e->last;
+  ref->getPicYuvRec()->setBorderExtension(false);  // the object is re-used: its borders are from an older picture
+  ref->getPicYuvRec()->extendPicBorder();
+  ref->compressMotion();
+  ref->setReconMark(true);
+  ref->getSlice(0)->setReferenced(true);
+  if (!e->pic1) { e->pic1 = new TComPic(); e->pic1->create(e->sps, e->pps, true, true); }
+  TComPic* other = (ref == e->pic0) ? e->pic1 : e->pic0;  // ping-pong between the two picture objects
+  e->pic = other;                   // load_picture / init_slice work on e->pic
+  load_picture(*e, luma, stride, cb, cr);
+  init_slice(*e, qp);
+  TComSlice* s = e->pic->getSlice(0);
+  s->setPOC(poc); s->setSliceType(P_SLICE); s->setNalUnitType(NAL_UNIT_CODED_SLICE_TRAIL_R);
+  s->setNumRefIdx(REF_PIC_LIST_0, 1); s->setNumRefIdx(REF_PIC_LIST_1, 0);
+  s->setRefPic(ref, REF_PIC_LIST_0, 0);
+  s->setRefPOCList(); s->setList1IdxToList0Idx();
+  s->setEnableTMVPFlag(false); s->setColFromL0Flag(true); s->setColRefIdx(0);
+  s->setMaxNumMergeCand(5); s->setDepth(0);
+  s->setLFCrossSliceBoundaryFlag(true);
+  e->slice.setSearchRange(s);
+  fhevc_hook_register(&e->cu.getFastDepth());
+  fhevc_hook_reload_knobs();
+  if (forced_min && forced_max) fhevc_hook_set_external_range(forced_min, forced_max, n);
+  else fhevc_hook_set_external_map(forced_min, forced_min ? n : 0);
+  const auto t0 = std::chrono::steady_clock::now();
+  e->slice.compressSlice(e->pic, false, false);
+  const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  long skipped = 0;
+  for (int c = 0; c < n; c++) {
+    TComDataCU* ctu = e->pic->getCtu(c);
+    for (int r = 0; r < 256; r++) depth_out[c * 256 + r] = ctu->getDepth(g_auiRasterToZscan[r]);
+    for (int z = 0; z < 256; z++) skipped += ctu->isSkipped(z) ? 1 : 0;
+  }
+  stats[0] = (double)e->slice.m_uiPicTotalBits; stats[1] = (double)e->slice.m_uiPicDist; stats[2] = e->slice.m_dPicRdCost;
+  stats[3] = sec; stats[5] = n; stats[6] = (double)e->pic->getSlice(0)->getSliceBits(); stats[7] = (double)skipped / (n * 256.0);
+  double sse = 0;
+  const Pel* o = e->pic->getPicYuvOrg()->getAddr(COMPONENT_Y);
+  const Pel* r = e->pic->getPicYuvRec()->getAddr(COMPONENT_Y);
+  const int so = e->pic->getPicYuvOrg()->getStride(COMPONENT_Y), sr = e->pic->getPicYuvRec()->getStride(COMPONENT_Y);
+  for (int y = 0; y < height; y++)
+    for (int x = 0; x < width; x++) { const double d = (double)o[y * so + x] - (double)r[y * sr + x]; sse += d * d; }
+  stats[4] = sse;
+  e->last = e->pic;
+  return 0;
+}
+#endif
 
 // debugging aid: histograms of the decisions of the last encoded picture of that geometry
 int href_rdo_debug_hist(int width, int height, int bit_depth, int* modes35, int* part2, int* trdepth4, int* tskip2, int* cbf2)

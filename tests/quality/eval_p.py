@@ -1,0 +1,129 @@
+#!/usr/bin/env python3
+"""TEST/QUALITY INFRASTRUCTURE (uses oracle/_ref/libhmref_p.so).  Config 4 (encoder_lowdelay_P_main.cfg geometry): a 2-frame
+1080p pan clip, POC 0 as an I slice and POC 1 as a P slice through the reference's own compressSlice with HM-16.14's
+inter checks restored (hm_patch/restore_inter.py; the reference as shipped aborts on P slices).
+
+"Inter-CU depth reuse" (BASELINE.json config 4): the depth search of POC 1 is restricted to a window around the
+co-located depth of POC 0 through the soft hook (depth_min / depth_max per 4x4 unit).  Reports the BD-rate of POC 1 and
+the time in compressSlice against the unrestricted search, over QP {22,27,32,37} (P picture at QP + 6 as
+TEncSlice::initEncSlice derives it from the cfg's GOP entry).  Decision stage only: no in-loop filters, TMVP off.
+
+usage: python tests/quality/eval_p.py [--size 1920x1080] [--json out.json]
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from fasthevc_amd import frames  # noqa: E402
+from eval_rd import bd_rate  # noqa: E402
+
+P_SO = os.path.join(ROOT, "oracle", "_ref", "libhmref_p.so")
+
+
+def load_p():
+    from oracle import oracle_py as op
+    libdl = C.CDLL(None)
+    libdl.dlopen.restype = C.c_void_p
+    libdl.dlopen.argtypes = [C.c_char_p, C.c_int]
+    h = libdl.dlopen(P_SO.encode(), os.RTLD_LAZY | os.RTLD_LOCAL)
+    if not h:
+        raise OSError("cannot dlopen " + P_SO + " (make -C oracle pvar)")
+    lib = op.bind_rdo(C.CDLL(P_SO, handle=h))
+    lib.href_rdo_encode_next_p.argtypes = [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_void_p] * 4
+    return lib
+
+
+def pan_clip(W, H, nframes=2, seed=1234):
+    """SURVEY Appendix B's config-4 clip: texture and noise drawn once, noise rolled 3 px per frame, base and edges evaluated
+    at x + 3f, flat chroma."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:H, 0:W]
+    tex = rng.integers(0, 2, size=(H // 16 + 1, W // 16 + 1)).repeat(16, 0).repeat(16, 1)[:H, :W]
+    noise = rng.normal(0, 18, size=(H, W)) * tex
+    out = []
+    for f in range(nframes):
+        base = 128 + 60 * np.sin((xx + 3 * f) / 37.0) * np.cos(yy / 23.0)
+        edges = (((xx + 3 * f) // 48 + yy // 40) % 2) * 30
+        out.append(np.clip(base + np.roll(noise, 3 * f, axis=1) + edges, 0, 255).astype(np.uint8))
+    return out
+
+
+def encode_seq(lib, ys, qp, window=None):
+    """I P P ...: POC 0 at qp, the P pictures at qp + 6.  window = (levels below, levels above) the co-located depth of
+    the PREVIOUS picture (None = unrestricted search; the first P picture is unrestricted when its reference is the I
+    picture: intra depths say little about inter depths).  -> per picture (depth [n,256], stats)."""
+    from oracle import oracle_py as op
+    H, W = ys[0].shape
+    n = ((W + 63) // 64) * ((H + 63) // 64)
+    u = np.full((H // 2, W // 2), 128, np.int16)
+    out = []
+    buf, org, stride = frames.to_pel_plane(ys[0], 8)
+    d, st = op.rdo_encode(lib, buf, org, stride, W, H, 8, qp, chroma=(u, u))
+    out.append((d, {"bits": st["coded_bits"], "psnr_y": st["psnr_y"], "seconds": st["seconds"], "skip_share": 0.0}))
+    for f in range(1, len(ys)):
+        buf, org, stride = frames.to_pel_plane(ys[f], 8)
+        fmin = fmax = None
+        if window is not None and f >= 2:
+            prev = out[-1][0].astype(int)
+            fmin = np.ascontiguousarray(np.clip(prev - window[0], 0, 3).astype(np.uint8))
+            fmax = np.ascontiguousarray(np.clip(prev + window[1], 0, 3).astype(np.uint8))
+        d1 = np.zeros(n * 256, np.uint8)
+        s1 = np.zeros(8)
+        rc = lib.href_rdo_encode_next_p(buf.reshape(-1).ctypes.data + 2 * org, u.ctypes.data, u.ctypes.data, stride, W, H, 8, qp + 6, f,
+                                        None if fmin is None else fmin.ctypes.data, None if fmax is None else fmax.ctypes.data,
+                                        d1.ctypes.data, s1.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(f"href_rdo_encode_next_p failed: {rc}")
+        out.append((d1.reshape(n, 256), {"bits": float(s1[6]), "psnr_y": float(10 * np.log10(255.0 * 255.0 / (s1[4] / (W * H)))),
+                                        "seconds": float(s1[3]), "skip_share": float(s1[7])}))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--size", default="1920x1080")
+    ap.add_argument("--frames", type=int, default=4)
+    ap.add_argument("--json", default=None)
+    args = ap.parse_args()
+    W, H = (int(v) for v in args.size.split("x"))
+    lib = load_p()
+    ys = pan_clip(W, H, args.frames)
+    windows = {"same_depth": (0, 0), "window_pm1": (1, 1), "at_most_plus1": (3, 1), "at_least_minus1": (1, 3)}
+    rows = {"anchor": []}
+    rows.update({k: [] for k in windows})
+    report = {"clip": f"{W}x{H} pan clip, {args.frames} frames (I P P ...), restricted pictures: POC >= 2", "qp": [], "pictures": []}
+    for qp in (22, 27, 32, 37):
+        anchor = encode_seq(lib, ys, qp)
+        tail = lambda seq: (sum(s["bits"] for _, s in seq[2:]), float(np.mean([s["psnr_y"] for _, s in seq[2:]])), sum(s["seconds"] for _, s in seq[2:]))
+        rows["anchor"].append(tail(anchor))
+        report["qp"].append(qp)
+        report["pictures"].append([dict(s, depth_hist=np.bincount(d.reshape(-1), minlength=4).tolist()) for d, s in anchor])
+        same = [float((anchor[f][0] == anchor[f - 1][0]).mean()) for f in range(2, len(ys))]
+        pm1 = [float((np.abs(anchor[f][0].astype(int) - anchor[f - 1][0].astype(int)) <= 1).mean()) for f in range(2, len(ys))]
+        print(f"qp {qp}: " + " | ".join(f"POC{f} {s['bits']:.0f} b {s['psnr_y']:.2f} dB {s['seconds']:.1f} s skip {100 * s['skip_share']:.0f} %" for f, (_, s) in enumerate(anchor))
+              + f" | P->P depth equal {100 * np.mean(same):.0f} %, within 1 {100 * np.mean(pm1):.0f} %", flush=True)
+        for k, win in windows.items():
+            t = tail(encode_seq(lib, ys, qp, win))
+            rows[k].append(t)
+            print(f"   {k}: POC2.. {t[0]:.0f} b {t[1]:.2f} dB {t[2]:.1f} s", flush=True)
+    ra, pa = [r[0] for r in rows["anchor"]], [r[1] for r in rows["anchor"]]
+    report["anchor"] = rows["anchor"]
+    for k in windows:
+        v = rows[k]
+        report[k] = {"points": v, "bd_rate_percent": bd_rate(ra, pa, [r[0] for r in v], [r[1] for r in v]),
+                     "time_ratio": float(np.sum([r[2] for r in rows["anchor"]]) / np.sum([r[2] for r in v]))}
+        print(f"{k}: BD-rate of the restricted P pictures {report[k]['bd_rate_percent']:+.2f} %  decision time {report[k]['time_ratio']:.2f}x faster")
+    if args.json:
+        with open(args.json, "w") as f:
+            json.dump(report, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -80,6 +80,74 @@ def test_hook_with_own_depth_map_reproduces_full_rdo():
     assert s_bad["rdcost"] > 1.05 * s_stock["rdcost"]
 
 
+@need_ref
+def test_soft_hook_ranges():
+    """Soft hook (depth_min/depth_max per unit): the free range [0, 3] is stock full RDO; a range that contains HM's own
+    depth everywhere gives HM's own result while searching less; a range that excludes it cannot beat it."""
+    buf, org, stride = _crop()
+    hook = op.bind_rdo(op.load_ref(hook=True))
+    fx = np.load(FIX)
+    ch = _crop_chroma()
+    own = fx["depth"]
+    lo, hi = np.zeros_like(own), np.full_like(own, 3)
+    d_free, s_free = op.rdo_encode(hook, buf, org, stride, 768, 512, 8, 32, forced_depth=lo, forced_depth_max=hi, chroma=ch)
+    assert np.array_equal(d_free, own) and s_free["bits"] == float(fx["bits"]) and s_free["dist"] == float(fx["dist"])
+    around_lo = np.maximum(own.astype(int) - 1, 0).astype(np.uint8)
+    around_hi = np.minimum(own.astype(int) + 1, 3).astype(np.uint8)
+    d_ar, s_ar = op.rdo_encode(hook, buf, org, stride, 768, 512, 8, 32, forced_depth=around_lo, forced_depth_max=around_hi, chroma=ch)
+    # HM's search is greedy (CABAC states depend on what was evaluated), so a narrower search may settle elsewhere inside the
+    # window, but it stays inside it and at HM's RD cost
+    assert np.all((d_ar >= around_lo) & (d_ar <= around_hi))
+    assert abs(s_ar["rdcost"] / s_free["rdcost"] - 1.0) < 0.005 and float((d_ar == own).mean()) > 0.9
+    assert s_ar["seconds"] < s_free["seconds"]
+    # the one-shot depth_max does not leak into the next call: a single map afterwards is a hard decision again
+    d_hard, _ = op.rdo_encode(hook, buf, org, stride, 768, 512, 8, 32, forced_depth=hi, chroma=ch)
+    assert np.all(d_hard == 3)
+    # a range that forbids depth 0 is obeyed; HM's greedy search is not globally optimal, so the RD cost moves only a little
+    d_excl, s_excl = op.rdo_encode(hook, buf, org, stride, 768, 512, 8, 32, forced_depth=np.maximum(own, 1), forced_depth_max=hi, chroma=ch)
+    assert d_excl.min() >= 1 and abs(s_excl["rdcost"] / s_free["rdcost"] - 1.0) < 0.01
+
+
+P_SO = os.path.join(ROOT, "oracle", "_ref", "libhmref_p.so")
+
+
+@pytest.mark.skipif(not os.path.exists(P_SO), reason="oracle/_ref/libhmref_p.so not built (make -C oracle pvar, build container only)")
+def test_p_slice_variant_and_temporal_depth_window():
+    """Config 4: the reference with HM-16.14's inter checks restored (hm_patch/restore_inter.py).  I slices are unaffected;
+    P pictures encode (as shipped the reference aborts on them); the hook's FHEVC_P_WINDOW knob equals explicit
+    depth ranges built from the previous picture's depths, and is not applied to the first P picture after an I picture."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "quality"))
+    import eval_p
+    lib = eval_p.load_p()
+    W, H, QP = 256, 192, 32
+    ys = eval_p.pan_clip(W, H, 4)
+    saved = os.environ.pop("FHEVC_P_WINDOW", None)
+    try:
+        full = eval_p.encode_seq(lib, ys, QP)
+        # the I picture equals what the unmodified reference library decides
+        buf, org, stride = frames.to_pel_plane(ys[0], 8)
+        u = np.full((H // 2, W // 2), 128, np.int16)
+        d_ref, s_ref = op.rdo_encode(op.bind_rdo(op.load_ref()), buf, org, stride, W, H, 8, QP, chroma=(u, u))
+        assert np.array_equal(full[0][0], d_ref) and full[0][1]["bits"] == s_ref["coded_bits"]
+        # P pictures: far fewer bits than the I picture, inter prediction is used (some skipped area), depths are valid
+        for d, s in full[1:]:
+            assert s["bits"] < 0.4 * full[0][1]["bits"] and d.max() <= 3
+        assert max(s["skip_share"] for _, s in full[1:]) > 0.0
+        explicit = eval_p.encode_seq(lib, ys, QP, window=(1, 1))
+        os.environ["FHEVC_P_WINDOW"] = "1"
+        by_knob = eval_p.encode_seq(lib, ys, QP)
+        for f in range(4):
+            assert np.array_equal(by_knob[f][0], explicit[f][0]) and by_knob[f][1]["bits"] == explicit[f][1]["bits"], f
+        assert np.array_equal(by_knob[1][0], full[1][0])      # POC 1 references the I picture: unrestricted
+        for f in (2, 3):                                      # restricted pictures stay inside the window
+            assert np.all(np.abs(by_knob[f][0].astype(int) - by_knob[f - 1][0].astype(int)) <= 1)
+    finally:
+        os.environ.pop("FHEVC_P_WINDOW", None)
+        if saved is not None:
+            os.environ["FHEVC_P_WINDOW"] = saved
+
+
 def test_trained_weights_follow_the_reference_decisions(oracle):
     """The shipped blob (fasthevc_amd/weights/depthnet_v1.fhw, trained on the reference's full-RDO labels) against the
     committed reference depth map of a picture it never saw (pinned hetero content): most units get HM's depth, nearly all within one level."""
