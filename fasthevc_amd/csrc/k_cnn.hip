@@ -13,13 +13,16 @@
 //     with one ds_read_b128 per K-step: activations live in LDS as 8-channel planes [y][x][8] bf16 so the
 //     16-lane groups of a ds_read_b128 cover 256 contiguous bytes;
 //   * operands are fixed-point integers (|w| <= 127, activations 0..255, |acc| < 2^24) so the fp32
-//     accumulation is exact in any order -> the integer depth map is bit-exact against the CPU oracle;
+//     accumulation is exact in any order -> the integer depth map is bit-exact against the CPU oracle; conv1 and conv2
+//     carry their 2^-shift in the bf16 weights (still exact) and start from the pre-scaled bias as the MFMA's C operand;
 //   * ReLU/requant/max-pool are fused into the MFMA epilogue (in-lane max for the vertical pair,
 //     DPP quad_perm for the horizontal pair), FC heads run on v_dot4_u32_u8 with weights resident in LDS;
 //   * conv1 folds the 2x2 max-pool window into the MFMA's M dimension: A rows = (16 filters) x (2x2 pre-pool
 //     positions) = 64 rows = two MFMAs, K = the 4x4 input window (all 16 slots used, read as row-pair dwords), so a
 //     lane holds all four pre-pool outputs of its pooled position: the pool is three in-lane max, no DPP;
-//   * the next CTU's samples are prefetched into registers while the heads of the current one run.
+//   * the next CTU's samples are prefetched into registers from the start of conv3 and staged into LDS after the heads;
+//   * MFMA chains read their fragments through a register ring that runs across the units of a phase; thread
+//     coordinates are re-derived per phase so that nothing address-like stays live across the conv2 phase (no spills).
 #include "fhevc_internal.h"
 #include <cstdlib>
 
