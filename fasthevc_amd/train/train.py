@@ -159,7 +159,11 @@ def main():
     ap.add_argument("--batch", type=int, default=96)
     ap.add_argument("--threads", type=int, default=8)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--qps", default="", help="comma-separated slice QPs of the label files (default 22,27,32,37; P-picture labels: 28,33,38,43)")
     args = ap.parse_args()
+    if args.qps:
+        global QPS
+        QPS = tuple(int(v) for v in args.qps.split(","))
     torch.set_num_threads(args.threads)
     torch.manual_seed(args.seed)
     (tr_t, tr_d), (va_t, va_d), nfiles = load_data(args.data)

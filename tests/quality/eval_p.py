@@ -55,7 +55,24 @@ def pan_clip(W, H, nframes=2, seed=1234):
     return out
 
 
-def encode_seq(lib, ys, qp, window=None):
+def cnn_ranges(oracle, ws, y, qp, margin_split, margin_stop):
+    """depth range of one picture from a weight blob through the CPU oracle (the GPU path is bit-exact with it)"""
+    from oracle import oracle_py as op
+    H, W = y.shape
+    n = ((W + 63) // 64) * ((H + 63) // 64)
+    cw = (W + 63) // 64
+    buf, org, stride = frames.to_pel_plane(y, 8)
+    pred = np.zeros(n * 256, np.uint8)
+    logits = np.zeros(n * 42, np.int32)
+    oracle.fho_predict_frame(ws, op.ptr(buf.reshape(-1), org), stride, W, H, 8, qp, pred, C.c_void_p(logits.ctypes.data))
+    dmin, dmax = np.zeros((n, 256), np.uint8), np.zeros((n, 256), np.uint8)
+    for c in range(n):
+        vw, vh = min(64, W - (c % cw) * 64), min(64, H - (c // cw) * 64)
+        oracle.fho_depth_range_from_logits(np.ascontiguousarray(logits[c * 42:(c + 1) * 42]), vw, vh, margin_split, margin_stop, dmin[c], dmax[c])
+    return dmin, dmax
+
+
+def encode_seq(lib, ys, qp, window=None, cnn=None):
     """I P P ...: POC 0 at qp, the P pictures at qp + 6.  window = (levels below, levels above) the co-located depth of
     the PREVIOUS picture (None = unrestricted search; the first P picture is unrestricted when its reference is the I
     picture: intra depths say little about inter depths).  -> per picture (depth [n,256], stats)."""
@@ -70,7 +87,10 @@ def encode_seq(lib, ys, qp, window=None):
     for f in range(1, len(ys)):
         buf, org, stride = frames.to_pel_plane(ys[f], 8)
         fmin = fmax = None
-        if window is not None and f >= 2:
+        if cnn is not None and f >= 2:  # classifier for inter pictures: (oracle, weights, margin_split, margin_stop)
+            fmin, fmax = cnn_ranges(cnn[0], cnn[1], ys[f], qp + 6, cnn[2], cnn[3])
+            fmin, fmax = np.ascontiguousarray(fmin), np.ascontiguousarray(fmax)
+        elif window is not None and f >= 2:
             prev = out[-1][0].astype(int)
             fmin = np.ascontiguousarray(np.clip(prev - window[0], 0, 3).astype(np.uint8))
             fmax = np.ascontiguousarray(np.clip(prev + window[1], 0, 3).astype(np.uint8))
@@ -91,13 +111,22 @@ def main():
     ap.add_argument("--size", default="1920x1080")
     ap.add_argument("--frames", type=int, default=4)
     ap.add_argument("--json", default=None)
+    ap.add_argument("--weights-p", default=None, help="FHW1 blob trained on P-picture labels (make_labels_p.py): adds classifier variants")
     args = ap.parse_args()
     W, H = (int(v) for v in args.size.split("x"))
     lib = load_p()
     ys = pan_clip(W, H, args.frames)
     windows = {"same_depth": (0, 0), "window_pm1": (1, 1), "at_most_plus1": (3, 1), "at_least_minus1": (1, 3)}
+    cnn_variants = {}
+    if args.weights_p:
+        from oracle import oracle_py as op
+        from fasthevc_amd import weights
+        oracle, ws = op.load_oracle(), op.weights_from_arrays(weights.load(args.weights_p))
+        cnn_variants = {"cnn_p_hard": (oracle, ws, 0, 0), "cnn_p_split32000": (oracle, ws, 32000, 0), "cnn_p_soft8000": (oracle, ws, 8000, 8000)}
+        windows = {"window_pm1": (1, 1)}
     rows = {"anchor": []}
     rows.update({k: [] for k in windows})
+    rows.update({k: [] for k in cnn_variants})
     report = {"clip": f"{W}x{H} pan clip, {args.frames} frames (I P P ...), restricted pictures: POC >= 2", "qp": [], "pictures": []}
     for qp in (22, 27, 32, 37):
         anchor = encode_seq(lib, ys, qp)
@@ -113,9 +142,13 @@ def main():
             t = tail(encode_seq(lib, ys, qp, win))
             rows[k].append(t)
             print(f"   {k}: POC2.. {t[0]:.0f} b {t[1]:.2f} dB {t[2]:.1f} s", flush=True)
+        for k, cv in cnn_variants.items():
+            t = tail(encode_seq(lib, ys, qp, cnn=cv))
+            rows[k].append(t)
+            print(f"   {k}: POC2.. {t[0]:.0f} b {t[1]:.2f} dB {t[2]:.1f} s", flush=True)
     ra, pa = [r[0] for r in rows["anchor"]], [r[1] for r in rows["anchor"]]
     report["anchor"] = rows["anchor"]
-    for k in windows:
+    for k in list(windows) + list(cnn_variants):
         v = rows[k]
         report[k] = {"points": v, "bd_rate_percent": bd_rate(ra, pa, [r[0] for r in v], [r[1] for r in v]),
                      "time_ratio": float(np.sum([r[2] for r in rows["anchor"]]) / np.sum([r[2] for r in v]))}
