@@ -174,7 +174,14 @@ def main():
     flags_all = [bands.alloc_flag_buffers(NF, n_ctus, world, dev) for _ in range(2)]   # receive buffers of the all-gather
     flags_mine = [torch.zeros((NF, n_ctus), dtype=torch.int32, device=dev) for _ in range(2)]  # this rank's words (send)
     had = torch.zeros((NF, n_ctus), dtype=torch.int32, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
+    # A real (non-null) torch stream for everything that follows: the library treats a NULL stream handle as "the context's
+    # own stream", which torch's collectives (ordered against torch's CURRENT stream) would not see.  With it the kernels,
+    # the all-gather's stream dependencies and the expansion are all expressed on one stream.
+    torch.cuda.synchronize()
+    tstream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
+    assert stream != 0
     inflight = []  # [(work, buffer index)]: at most one collective in flight
 
     def finish_gather():
