@@ -576,11 +576,12 @@ int fhevc_intra_first_pass_device(fhevc_ctx* c, const void* d_luma, int sample_b
 }
 
 // Diagnostic (not part of include/fasthevc.h): run the stamped instantiation of the depth kernel over a
-// device-resident batch and return per-phase cycle sums averaged over workgroups (P0..P5) + CTUs per workgroup.
+// device-resident batch and return per-phase cycle sums averaged over workgroups (slots 0..7: prologue, conv1, conv2, conv3,
+// barrier wait after staging, depth, heads, staging), CTUs per workgroup (8) and the grid (9).
 int fhevc_debug_cnn_phase_cycles(fhevc_ctx* c, const void* d_luma, int sample_bytes, int stride_samples,
-                                 long long frame_stride_samples, int num_frames, uint8_t* d_depth_map, double* out8)
+                                 long long frame_stride_samples, int num_frames, uint8_t* d_depth_map, double* out10)
 {
-  if (!c || !d_luma || !d_depth_map || !out8 || !c->have_weights) return FHEVC_E_INVALID;
+  if (!c || !d_luma || !d_depth_map || !out10 || !c->have_weights) return FHEVC_E_INVALID;
   hipSetDevice(c->device);
   const FhevcFrames fr = frames_of(c, d_luma, sample_bytes, stride_samples, frame_stride_samples, num_frames, 0, c->ctus_y);
   unsigned long long* d_st = nullptr;
@@ -593,10 +594,10 @@ int fhevc_debug_cnn_phase_cycles(fhevc_ctx* c, const void* d_luma, int sample_by
   HIP_TRY(c, hipMemcpyAsync(h.data(), d_st, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   hipFree(d_st);
-  for (int k = 0; k < 8; ++k) out8[k] = 0;
-  for (int b = 0; b < grid; ++b) for (int k = 0; k < 6; ++k) out8[k] += (double)h[(size_t)b * 8 + k] / grid;
-  out8[6] = (double)num_frames * c->num_ctus / grid;
-  out8[7] = grid;
+  for (int k = 0; k < 10; ++k) out10[k] = 0;
+  for (int b = 0; b < grid; ++b) for (int k = 0; k < 8; ++k) out10[k] += (double)h[(size_t)b * 8 + k] / grid;
+  out10[8] = (double)num_frames * c->num_ctus / grid;
+  out10[9] = grid;
   return FHEVC_OK;
 }
 

@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
   const int total = per_frame * F.num_frames;
   const int shift_in = F.bit_depth - 8;
 
-  unsigned long long tsum[7] = { 0, 0, 0, 0, 0, 0, 0 }, tprev = 0;
+  unsigned long long tsum[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tprev = 0;
 #define FHEVC_STAMP(k)                                     \
   if (STAMPS) {                                            \
     const unsigned long long tn = stamp();                 \
@@ -609,7 +609,9 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
       }
     }
     // the A2/input region (R2) is free since the P3 barrier: stage the next CTU now, its P1 needs no extra barrier
+    FHEVC_STAMP(6)  // heads only
     if (work + (int)gridDim.x < total) stage_ctu(lds, pre, F, next, tid, ld_row, ld_seg, shift_in);
+    FHEVC_STAMP(7)  // staging of the next CTU; slot 4 below is then the wait at the barrier
     __syncthreads();
     FHEVC_STAMP(4)
 
@@ -667,7 +669,7 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
     // before the P4 barrier, halo rewritten above by disjoint addresses); the logits are re-initialised in P2.
   }
   if (STAMPS && tid == 0) {
-    for (int k = 0; k < 6; ++k) d_stamps[blockIdx.x * 8 + k] = tsum[k];
+    for (int k = 0; k < 8; ++k) d_stamps[blockIdx.x * 8 + k] = tsum[k];
   }
 #undef FHEVC_STAMP
 }
