@@ -189,15 +189,15 @@ void time_begin(fhevc_ctx* c, hipStream_t s, int which)
   if (!c->timing) return;
   TimedLaunch t;
   if (!c->pool.empty()) { t.start = c->pool.back().first; t.stop = c->pool.back().second; c->pool.pop_back(); }
-  else { hipEventCreate(&t.start); hipEventCreate(&t.stop); }
+  else { (void)hipEventCreate(&t.start); (void)hipEventCreate(&t.stop); }
   t.which = which;
-  hipEventRecord(t.start, s);
+  (void)hipEventRecord(t.start, s);
   c->pending.push_back(t);
 }
 void time_end(fhevc_ctx* c, hipStream_t s)
 {
   if (!c->timing) return;
-  hipEventRecord(c->pending.back().stop, s);
+  (void)hipEventRecord(c->pending.back().stop, s);
 }
 void time_resolve(fhevc_ctx* c)
 {
@@ -278,7 +278,7 @@ int fhevc_create(fhevc_ctx** out, const fhevc_cfg* cfg)
   ok &= hipMalloc(&c->d_satd_out, 4) == hipSuccess;
   for (auto& e : c->ev) ok &= hipEventCreate(&e) == hipSuccess;
   if (!ok) { fhevc_destroy(c); return FHEVC_E_NOMEM; }
-  hipMemset(c->d_luma, 0, (size_t)c->dev_stride * c->ctus_y * 64 * sizeof(int16_t));
+  if (hipMemset(c->d_luma, 0, (size_t)c->dev_stride * c->ctus_y * 64 * sizeof(int16_t)) != hipSuccess) { fhevc_destroy(c); return FHEVC_E_HIP; }
   if (cfg->weights_path) {
     FILE* fp = std::fopen(cfg->weights_path, "rb");
     if (!fp) { fhevc_destroy(c); return FHEVC_E_WEIGHTS; }
@@ -295,14 +295,14 @@ int fhevc_create(fhevc_ctx** out, const fhevc_cfg* cfg)
 void fhevc_destroy(fhevc_ctx* c)
 {
   if (!c) return;
-  hipSetDevice(c->device);
-  if (c->stream) hipStreamSynchronize(c->stream);
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
   time_resolve(c);
-  for (auto& p : c->pool) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
-  for (auto& e : c->ev) if (e) hipEventDestroy(e);
-  hipFree(c->d_frag); hipFree(c->d_bias); hipFree(c->d_whead); hipFree(c->d_bhead);
-  hipFree(c->d_luma); hipFree(c->d_depth); hipFree(c->d_had); hipFree(c->d_nodes); hipFree(c->d_satd); hipFree(c->d_satd_out); hipFree(c->d_act); hipFree(c->d_depth_max);
-  if (c->stream) hipStreamDestroy(c->stream);
+  for (auto& p : c->pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+  for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+  (void)hipFree(c->d_frag); (void)hipFree(c->d_bias); (void)hipFree(c->d_whead); (void)hipFree(c->d_bhead);
+  (void)hipFree(c->d_luma); (void)hipFree(c->d_depth); (void)hipFree(c->d_had); (void)hipFree(c->d_nodes); (void)hipFree(c->d_satd); (void)hipFree(c->d_satd_out); (void)hipFree(c->d_act); (void)hipFree(c->d_depth_max);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
 
@@ -315,7 +315,7 @@ int fhevc_set_weights(fhevc_ctx* c, const void* blob, size_t bytes)
   const struct { const int8_t* p; size_t n; } i8s[6] = { { v.w1, 144 }, { v.w2, 4608 }, { v.w3, 18432 }, { v.wh64, 8192 }, { v.wh32, 8192 }, { v.wh16, 2048 } };
   for (const auto& a : i8s)
     for (size_t i = 0; i < a.n; ++i) if (a.p[i] == -128) return fail(c, FHEVC_E_WEIGHTS, "weight -128 not allowed");
-  hipSetDevice(c->device);
+  (void)hipSetDevice(c->device);
   return build_weight_image(c, v);
 }
 
@@ -402,7 +402,7 @@ int fhevc_predict_frame(fhevc_ctx* c, const int16_t* luma, int stride_samples, i
   (void)slice_type;
   if (!c || !luma || !depth_map || stride_samples < c->cfg.width) return FHEVC_E_INVALID;
   if (!c->have_weights) return fail(c, FHEVC_E_STATE, "weights not set");
-  hipSetDevice(c->device);
+  (void)hipSetDevice(c->device);
   int rc = upload_frame(c, luma, stride_samples);
   if (rc != FHEVC_OK) return rc;
   rc = fhevc_predict_frames_device(c, c->d_luma, 2, c->dev_stride, 0, 1, 0, c->ctus_y, qp, c->d_depth,
@@ -427,7 +427,7 @@ int fhevc_predict_frame_range(fhevc_ctx* c, const int16_t* luma, int stride_samp
   (void)slice_type;
   if (!c || !luma || !depth_min || !depth_max || stride_samples < c->cfg.width) return FHEVC_E_INVALID;
   if (!c->have_weights) return fail(c, FHEVC_E_STATE, "weights not set");
-  hipSetDevice(c->device);
+  (void)hipSetDevice(c->device);
   if (!c->d_depth_max) HIP_TRY(c, hipMalloc(&c->d_depth_max, (size_t)c->num_ctus * 256));
   int rc = upload_frame(c, luma, stride_samples);
   if (rc != FHEVC_OK) return rc;
@@ -448,7 +448,7 @@ int fhevc_satd(fhevc_ctx* c, const int16_t* org, int org_stride, const int16_t* 
   if (!c || !org || !cur || !out) return FHEVC_E_INVALID;
   if (w < 2 || h < 2 || w > 64 || h > 64 || (w & 1) || (h & 1) || bit_depth < 8 || bit_depth > 12) return fail(c, FHEVC_E_INVALID, "bad SATD block");
   if (org_stride < w || cur_stride < w) return fail(c, FHEVC_E_INVALID, "bad SATD stride");
-  hipSetDevice(c->device);
+  (void)hipSetDevice(c->device);
   HIP_TRY(c, hipMemcpy2DAsync(c->d_satd, 64 * 2, org, (size_t)org_stride * 2, (size_t)w * 2, (size_t)h, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemcpy2DAsync(c->d_satd + 64 * 64, 64 * 2, cur, (size_t)cur_stride * 2, (size_t)w * 2, (size_t)h, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, fhevc_launch_satd(c->d_satd, 64, c->d_satd + 64 * 64, 64, w, h, bit_depth, c->d_satd_out, c->stream));
@@ -461,7 +461,7 @@ int fhevc_satd(fhevc_ctx* c, const int16_t* org, int org_stride, const int16_t* 
 int fhevc_intra_first_pass(fhevc_ctx* c, const int16_t* luma, int stride_samples, int qp, fhevc_node_cost* out)
 {
   if (!c || !luma || !out || stride_samples < c->cfg.width || qp < 0 || qp > 51) return FHEVC_E_INVALID;
-  hipSetDevice(c->device);
+  (void)hipSetDevice(c->device);
   int rc = upload_frame(c, luma, stride_samples);
   if (rc != FHEVC_OK) return rc;
   // lambda = 0.57 * 2^((qp-12)/3): TEncSlice::calculateLambda, all-intra path (TEncSlice.cpp:433-527)
@@ -520,7 +520,7 @@ int fhevc_preanalyze_frames_device(fhevc_ctx* c, const void* d_luma, int sample_
     return fail(c, FHEVC_E_INVALID, "bad pre-analysis arguments");
   if ((c->cfg.width & 7) || (c->cfg.height & 7)) return fail(c, FHEVC_E_INVALID, "pre-analysis needs picture sizes that are multiples of 8");
   if (sample_bytes == 1 && c->cfg.bit_depth != 8) return fail(c, FHEVC_E_INVALID, "uint8 samples need bit depth 8");
-  hipSetDevice(c->device);
+  (void)hipSetDevice(c->device);
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
   const FhevcFrames fr = frames_of(c, d_luma, sample_bytes, stride_samples, frame_stride_samples, num_frames, ctu_row_begin, ctu_row_end);
   const long long per_frame = fhevc_aq_parts(c->cfg.width, c->cfg.height, max_aq_depth, nullptr);
@@ -537,7 +537,7 @@ int fhevc_preanalyze(fhevc_ctx* c, const int16_t* luma, int stride_samples, int 
   long long off[5];
   const int total = fhevc_aq_parts(c->cfg.width, c->cfg.height, max_aq_depth, off);
   if (total < 0) return fail(c, FHEVC_E_INVALID, "bad max_aq_depth");
-  hipSetDevice(c->device);
+  (void)hipSetDevice(c->device);
   if (!c->d_act) HIP_TRY(c, hipMalloc(&c->d_act, (size_t)fhevc_aq_parts(c->cfg.width, c->cfg.height, 4, nullptr) * sizeof(double)));
   int rc = upload_frame(c, luma, stride_samples);
   if (rc != FHEVC_OK) return rc;
@@ -564,7 +564,7 @@ int fhevc_intra_first_pass_device(fhevc_ctx* c, const void* d_luma, int sample_b
       ctu_row_begin < 0 || ctu_row_end > c->ctus_y || ctu_row_begin > ctu_row_end)
     return fail(c, FHEVC_E_INVALID, "bad first-pass arguments");
   if (sample_bytes == 1 && c->cfg.bit_depth != 8) return fail(c, FHEVC_E_INVALID, "uint8 samples need bit depth 8");
-  hipSetDevice(c->device);
+  (void)hipSetDevice(c->device);
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
   const double sqrt_lambda = std::sqrt(0.57 * std::pow(2.0, ((double)qp - 12.0) / 3.0));
   const FhevcFrames fr = frames_of(c, d_luma, sample_bytes, stride_samples, frame_stride_samples, num_frames, ctu_row_begin, ctu_row_end);
@@ -582,7 +582,7 @@ int fhevc_debug_cnn_phase_cycles(fhevc_ctx* c, const void* d_luma, int sample_by
                                  long long frame_stride_samples, int num_frames, uint8_t* d_depth_map, double* out10)
 {
   if (!c || !d_luma || !d_depth_map || !out10 || !c->have_weights) return FHEVC_E_INVALID;
-  hipSetDevice(c->device);
+  (void)hipSetDevice(c->device);
   const FhevcFrames fr = frames_of(c, d_luma, sample_bytes, stride_samples, frame_stride_samples, num_frames, 0, c->ctus_y);
   unsigned long long* d_st = nullptr;
   const int max_grid = 2 * c->num_cus;
@@ -593,7 +593,7 @@ int fhevc_debug_cnn_phase_cycles(fhevc_ctx* c, const void* d_luma, int sample_by
   std::vector<unsigned long long> h((size_t)max_grid * 8);
   HIP_TRY(c, hipMemcpyAsync(h.data(), d_st, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  hipFree(d_st);
+  (void)hipFree(d_st);
   for (int k = 0; k < 10; ++k) out10[k] = 0;
   for (int b = 0; b < grid; ++b) for (int k = 0; k < 8; ++k) out10[k] += (double)h[(size_t)b * 8 + k] / grid;
   out10[8] = (double)num_frames * c->num_ctus / grid;

@@ -366,8 +366,6 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 31, h = lane >> 5;
-
   // ---- resident weight fragments (A operands) ----
   // conv1's two fragments are only live from the end of a CTU's heads to its conv1: they are re-fetched (L2-hot) under
   // the heads of the previous CTU, which frees 8 registers in the conv2 phase, the tightest one
