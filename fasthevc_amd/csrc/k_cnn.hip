@@ -167,6 +167,7 @@ __device__ __forceinline__ void conv3_store(const f32x16& acc, const f32x16& b, 
 // waits for it, exposing the LDS latency 18 times per chain; instead the reads run RING steps ahead of their MFMA
 // and sched_group_barrier pins the (MFMA, DS read, a few VALU of the previous unit's epilogue) interleave.
 constexpr int RING = 4;
+static_assert(12 % RING == 0, "conv2 hands its ring slots from unit to unit unchanged");
 template <int VALU_PER_MFMA>
 __device__ __forceinline__ void sched_chain18()
 {
@@ -528,16 +529,16 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
       const int yp0 = wave >> 1;
       const f32x16 b3 = bias_tile(bias3, h);  // once per phase (see conv2_store)
       bf16x8 ring[RING];
-      f32x16 accA = conv3_unit<true, false, 0>(a2, yp0, yp0 + 2, wA3, ring);
+      f32x16 accA = conv3_unit<true, false, 0>(a2, yp0, yp0 + 2, wA3, ring);  // PHASE of unit k = (18 k) % RING
       __builtin_amdgcn_sched_group_barrier(0x100, RING + 4, 0);
       sched_chain18<0>();
-      f32x16 accB = conv3_unit<false, false, 2>(a2, yp0 + 2, yp0 + 4, wA3, ring);
+      f32x16 accB = conv3_unit<false, false, (18 * 1) % RING>(a2, yp0 + 2, yp0 + 4, wA3, ring);
       conv3_store(accA, b3, W.scale[2], a3dst + (yp0 + 0) * 2048, tile3, psw);
       sched_chain18<4>();
-      accA = conv3_unit<false, false, 0>(a2, yp0 + 4, yp0 + 6, wA3, ring);
+      accA = conv3_unit<false, false, (18 * 2) % RING>(a2, yp0 + 4, yp0 + 6, wA3, ring);
       conv3_store(accB, b3, W.scale[2], a3dst + (yp0 + 2) * 2048, tile3, psw);
       sched_chain18<4>();
-      accB = conv3_unit<false, true, 2>(a2, yp0 + 6, yp0 + 6, wA3, ring);
+      accB = conv3_unit<false, true, (18 * 3) % RING>(a2, yp0 + 6, yp0 + 6, wA3, ring);
       conv3_store(accA, b3, W.scale[2], a3dst + (yp0 + 4) * 2048, tile3, psw);
       sched_chain18<4>();
       conv3_store(accB, b3, W.scale[2], a3dst + (yp0 + 6) * 2048, tile3, psw);
