@@ -25,7 +25,7 @@ void TEncFastDepth::readKnobs()
   const char* mg = std::getenv("FHEVC_MARGIN");
   const char* ms = std::getenv("FHEVC_MARGIN_SPLIT");
   const char* mt = std::getenv("FHEVC_MARGIN_STOP");
-  m_marginSplit = ms ? std::atoi(ms) : (mg ? std::atoi(mg) : 0);
+  m_marginSplit = ms ? std::atoi(ms) : (mg ? std::atoi(mg) : 32000);  // default: unsure splits are not forced
   m_marginStop  = mt ? std::atoi(mt) : (mg ? std::atoi(mg) : 0);
   if (m_marginSplit < 0) m_marginSplit = 0;
   if (m_marginStop < 0) m_marginStop = 0;

@@ -9,9 +9,10 @@
  *   FHEVC_ENABLE=1            turn the path on
  *   FHEVC_WEIGHTS=<file>      FHW1 weight blob
  *   FHEVC_DEVICE=<ordinal>    HIP device (default 0)
- *   FHEVC_MARGIN=<int>        soft decisions: logit margin inside which a split decision is left to HM's RDO (default 0);
+ *   FHEVC_MARGIN=<int>        soft decisions: logit margin inside which a split decision is left to HM's RDO;
  *   FHEVC_MARGIN_SPLIT / FHEVC_MARGIN_STOP set the two sides separately (not forcing unsure splits is almost free,
- *                             not forbidding unsure ones costs the recursion it allows)
+ *                             not forbidding unsure ones costs the recursion it allows).  Defaults: split 32000, stop 0;
+ *                             FHEVC_MARGIN=0 gives hard decisions
  *   FHEVC_P_WINDOW=<w>        P/B pictures: restrict the depth search to the co-located depth of the first reference picture
  *                             +- w levels when that picture was inter coded (default: off); independent of FHEVC_ENABLE
  */

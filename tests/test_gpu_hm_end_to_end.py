@@ -46,7 +46,8 @@ def test_reference_encoder_driven_by_the_gpu_library(oracle):
     saved = {k: os.environ.get(k) for k in KNOBS}
     try:
         # TEncFastDepth reads its knobs when the harness constructs the encoder of a geometry: one geometry per setting
-        for (W, H), env, margins in (((768, 512), {"FHEVC_ENABLE": "1", "FHEVC_WEIGHTS": BLOB}, (0, 0)),
+        for (W, H), env, margins in (((768, 512), {"FHEVC_ENABLE": "1", "FHEVC_WEIGHTS": BLOB, "FHEVC_MARGIN": "0"}, (0, 0)),
+                                    ((832, 448), {"FHEVC_ENABLE": "1", "FHEVC_WEIGHTS": BLOB}, (32000, 0)),   # the hook's defaults
                                     ((704, 512), {"FHEVC_ENABLE": "1", "FHEVC_WEIGHTS": BLOB, "FHEVC_MARGIN_SPLIT": "32000"}, (32000, 0)),
                                     ((640, 448), {"FHEVC_ENABLE": "1", "FHEVC_WEIGHTS": BLOB, "FHEVC_MARGIN": "8000"}, (8000, 8000))):
             buf, org, stride, chroma = _picture(W, H)
