@@ -275,7 +275,7 @@ __device__ __forceinline__ Prefetched prefetch_ctu(const FhevcFrames& F, bool li
 // Stage one CTU into LDS (region R2): centred 8-bit samples as bf16, two picture rows per dword, zero halo.
 // halo coordinates: hy = row + 1, hx = col + 1; dword (hy >> 1) * IN_PITCH + hx, half (hy & 1)
 __device__ __forceinline__ void stage_ctu(unsigned char* lds, const Prefetched& pre, const FhevcFrames& F, CtuPos c,
-                                          int tid, int ld_row, int ld_seg, int shift_in)
+                                          int tid, int ld_row, int ld_seg, int shift_in, unsigned in_cells)
 {
   unsigned short* inh = reinterpret_cast<unsigned short*>(lds + R2_OFF);
   const int hy = ld_row + 1;
@@ -312,26 +312,55 @@ __device__ __forceinline__ void stage_ctu(unsigned char* lds, const Prefetched& 
       dst[2 * j] = (unsigned short)(__float_as_uint((float)v) >> 16);
     }
   }
-  // input halo: 66*66 - 64*64 = 260 positions
-  for (int e = tid; e < 260; e += 256) {
-    int y, x;
-    if (e < 66) { y = 0; x = e; }
-    else if (e < 132) { y = 65; x = e - 66; }
-    else { const int k = e - 132; y = 1 + (k >> 1); x = (k & 1) ? 65 : 0; }
-    inh[2 * ((y >> 1) * IN_PITCH + x) + (y & 1)] = 0;
-  }
+  // input halo: 66*66 - 64*64 = 260 two-byte cells
+  *reinterpret_cast<unsigned short*>(lds + (in_cells & 0xFFFF)) = 0;
+  if (tid < 260 - 256) *reinterpret_cast<unsigned short*>(lds + (in_cells >> 16)) = 0;
 }
-// zero the halo of the conv1 output planes (region R1, shared with the conv3 output): 132 positions x 2 planes
-__device__ __forceinline__ void zero_a1_halo(unsigned char* lds, int tid)
+// LDS byte offsets of the halo cells a thread zeroes (computed once per kernel: the index arithmetic with its three-way
+// divergence cost ~700 cycles per CTU when it ran inside the phases).  Cell e of: the conv1 output halo (264 x 16 B),
+// the conv2 output halo (272 x 16 B), the input tile halo (260 x 2 B).
+__device__ __forceinline__ int a1_halo_off(int e)
 {
-  for (int e = tid; e < 264; e += 256) {
-    const int pl = e / 132, k0 = e - pl * 132;
-    int y, x;
-    if (k0 < 34) { y = 0; x = k0; }
-    else if (k0 < 68) { y = 33; x = k0 - 34; }
-    else { const int k = k0 - 68; y = 1 + (k >> 1); x = (k & 1) ? 33 : 0; }
-    *reinterpret_cast<uint4*>(lds + R1_OFF + pl * A1_PLANE + (y * A1_PITCH + x) * 16) = make_uint4(0, 0, 0, 0);
-  }
+  const int pl = e / 132, k0 = e - pl * 132;
+  int y, x;
+  if (k0 < 34) { y = 0; x = k0; }
+  else if (k0 < 68) { y = 33; x = k0 - 34; }
+  else { const int k = k0 - 68; y = 1 + (k >> 1); x = (k & 1) ? 33 : 0; }
+  return R1_OFF + pl * A1_PLANE + (y * A1_PITCH + x) * 16;
+}
+__device__ __forceinline__ int a2_halo_off(int e)
+{
+  const int pl = e / 68, k0 = e - pl * 68;
+  int y, x;
+  if (k0 < 18) { y = 0; x = k0; }
+  else if (k0 < 36) { y = 17; x = k0 - 18; }
+  else { const int k = k0 - 36; y = 1 + (k >> 1); x = (k & 1) ? 17 : 0; }
+  return R2_OFF + pl * A2_PLANE + (y * A2_PITCH + x) * 16;
+}
+__device__ __forceinline__ int in_halo_off(int e)
+{
+  int y, x;
+  if (e < 66) { y = 0; x = e; }
+  else if (e < 132) { y = 65; x = e - 66; }
+  else { const int k = e - 132; y = 1 + (k >> 1); x = (k & 1) ? 65 : 0; }
+  return R2_OFF + 2 * (2 * ((y >> 1) * IN_PITCH + x) + (y & 1));
+}
+// a thread's two cells of each halo, packed as (first | second << 16); all offsets are below 64 KiB
+struct HaloCells { unsigned a1, a2, in; };
+__device__ __forceinline__ HaloCells halo_cells(int tid)
+{
+  HaloCells hc;
+  hc.a1 = (unsigned)a1_halo_off(tid) | ((unsigned)a1_halo_off(min(tid + 256, 263)) << 16);
+  hc.a2 = (unsigned)a2_halo_off(tid) | ((unsigned)a2_halo_off(min(tid + 256, 271)) << 16);
+  hc.in = (unsigned)in_halo_off(tid) | ((unsigned)in_halo_off(min(tid + 256, 259)) << 16);
+  return hc;
+}
+static_assert(R2_OFF + R2_BYTES <= 65536, "halo offsets are packed into 16 bits");
+// zero the halo of the conv1 output planes (region R1, shared with the conv3 output): 132 positions x 2 planes
+__device__ __forceinline__ void zero_a1_halo(unsigned char* lds, int tid, unsigned cells)
+{
+  *reinterpret_cast<uint4*>(lds + (cells & 0xFFFF)) = make_uint4(0, 0, 0, 0);
+  if (tid < 264 - 256) *reinterpret_cast<uint4*>(lds + (cells >> 16)) = make_uint4(0, 0, 0, 0);
 }
 
 // in-kernel stamp (diagnostic build only): s_memtime with its own lgkmcnt wait, fenced against reordering
@@ -367,6 +396,7 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
+  const HaloCells hc = halo_cells(tid);  // three registers for the life of the kernel
   // ---- resident weight fragments (A operands) ----
   // conv1's two fragments are only live from the end of a CTU's heads to its conv1: they are re-fetched (L2-hot) under
   // the heads of the previous CTU, which frees 8 registers in the conv2 phase, the tightest one
@@ -424,8 +454,8 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
   }
   Prefetched pre = prefetch_ctu(F, vblock < total, pos, ld_row, ld_seg);
   if (vblock < total) {  // prologue: first CTU of this workgroup
-    stage_ctu(lds, pre, F, pos, tid, ld_row, ld_seg, shift_in);
-    zero_a1_halo(lds, tid);
+    stage_ctu(lds, pre, F, pos, tid, ld_row, ld_seg, shift_in, hc.in);
+    zero_a1_halo(lds, tid, hc.a1);
   }
   __syncthreads();
   FHEVC_STAMP(0)
@@ -482,14 +512,8 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
         logitL[tid] = W.bhead[2 * lvl + cls] + (cls ? W.bhead[6 + lvl * 52 + F.qp] : 0);  // head bias + QP prior on "split"
       }
       // the input tile is dead: zero the A2 halo (68 positions x 4 planes) while conv2 fills the interior
-      for (int e = tid; e < 272; e += 256) {
-        const int pl = e / 68, k0 = e - pl * 68;
-        int y, x;
-        if (k0 < 18) { y = 0; x = k0; }
-        else if (k0 < 36) { y = 17; x = k0 - 18; }
-        else { const int k = k0 - 36; y = 1 + (k >> 1); x = (k & 1) ? 17 : 0; }
-        *reinterpret_cast<uint4*>(lds + R2_OFF + pl * A2_PLANE + (y * A2_PITCH + x) * 16) = make_uint4(0, 0, 0, 0);
-      }
+      *reinterpret_cast<uint4*>(lds + (hc.a2 & 0xFFFF)) = make_uint4(0, 0, 0, 0);
+      if (tid < 272 - 256) *reinterpret_cast<uint4*>(lds + (hc.a2 >> 16)) = make_uint4(0, 0, 0, 0);
       const unsigned char* a1p = lds + R1_OFF + h * A1_PLANE + r * 16;
       // straight-line software pipeline over the wave's 4 units: the MFMA chain of unit i+1 is issued before the
       // VALU epilogue of unit i, so the scheduler can interleave them (separate pipes)
@@ -609,7 +633,7 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
     }
     // the A2/input region (R2) is free since the P3 barrier: stage the next CTU now, its P1 needs no extra barrier
     FHEVC_STAMP(6)  // heads only
-    if (work + (int)gridDim.x < total) stage_ctu(lds, pre, F, next, tid, ld_row, ld_seg, shift_in);
+    if (work + (int)gridDim.x < total) stage_ctu(lds, pre, F, next, tid, ld_row, ld_seg, shift_in, hc.in);
     FHEVC_STAMP(7)  // staging of the next CTU; slot 4 below is then the wait at the barrier
     __syncthreads();
     FHEVC_STAMP(4)
@@ -660,7 +684,7 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
         const unsigned long long m = __ballot(bit && k < 21);
         if (lane == 0) d_flags[o] = (uint32_t)(m & 0x1FFFFFu);
       }
-      zero_a1_halo(lds, tid);  // R1 held the conv3 output until the P4 barrier; conv1 of the next CTU needs a zero halo
+      zero_a1_halo(lds, tid, hc.a1);  // R1 held the conv3 output until the P4 barrier; conv1 of the next CTU needs a zero halo
     }
     FHEVC_STAMP(5)
     pos = next;
