@@ -46,9 +46,10 @@ constexpr int R2_OFF = R1_OFF + R1_BYTES;         // R2: input CTU bf16 [66][68]
 constexpr int R2_BYTES = 4 * A2_PLANE;            // 20736
 constexpr int IN_PITCH = 68;                      // dwords per input row PAIR (66 used): lo = row 2j, hi = row 2j+1
 constexpr int BIAS_OFF = R2_OFF + R2_BYTES;       // float b1[16] b2[32] b3[64]
-constexpr int LOGIT_OFF = BIAS_OFF + 112 * 4;     // int logits[21][2]
-constexpr int HEADW_OFF = LOGIT_OFF + 48 * 4;     // uint8 head weights (w+128): wh64, wh32, wh16 = 18432 B
-constexpr int LDS_BYTES = HEADW_OFF + 18432;      // 76800 -> two workgroups per CU (153.6 of 160 KiB)
+constexpr int LOGIT_OFF = BIAS_OFF + 112 * 4;     // int logits[21][2] (the 64-level pair is formed by the readers) + at [44..51] the
+                                                  // four waves' partial 64-level sums
+constexpr int HEADW_OFF = LOGIT_OFF + 56 * 4;     // uint8 head weights (w+128): wh64, wh32, wh16 = 18432 B
+constexpr int LDS_BYTES = HEADW_OFF + 18432;      // 76832 -> two workgroups per CU (153.7 of 160 KiB)
 static_assert(33 * IN_PITCH * 4 <= R2_BYTES, "input tile must fit the A2 region");
 static_assert(HEADW_OFF % 16 == 0, "head weights are read with ds_read_b128");
 static_assert(P3_OFF + 4096 <= R1_OFF + R1_BYTES, "pooled map must fit R1");
@@ -397,6 +398,10 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const HaloCells hc = halo_cells(tid);  // three registers for the life of the kernel
+  // head bias + QP prior on "split" (class 1): uniform, lives in scalar registers
+  const int hb64a = W.bhead[0], hb64b = W.bhead[1] + W.bhead[6 + 0 * 52 + F.qp];
+  const int hb32a = W.bhead[2], hb32b = W.bhead[3] + W.bhead[6 + 1 * 52 + F.qp];
+  const int hb16a = W.bhead[4], hb16b = W.bhead[5] + W.bhead[6 + 2 * 52 + F.qp];
   // ---- resident weight fragments (A operands) ----
   // conv1's two fragments are only live from the end of a CTU's heads to its conv1: they are re-fetched (L2-hot) under
   // the heads of the previous CTU, which frees 8 registers in the conv2 phase, the tightest one
@@ -506,11 +511,6 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
     // ================= P2: conv2 (16 -> 32), K = 9 taps x 16 ch, fused maxpool + requant =================
     {
       FHEVC_PHASE_IDS
-      if (tid < 42) {  // logits start from the head biases (the previous CTU's logits were consumed before the P1 barrier)
-        const int k = tid >> 1, cls = tid & 1;
-        const int lvl = k == 0 ? 0 : (k < 5 ? 1 : 2);
-        logitL[tid] = W.bhead[2 * lvl + cls] + (cls ? W.bhead[6 + lvl * 52 + F.qp] : 0);  // head bias + QP prior on "split"
-      }
       // the input tile is dead: zero the A2 halo (68 positions x 4 planes) while conv2 fills the interior
       *reinterpret_cast<uint4*>(lds + (hc.a2 & 0xFFFF)) = make_uint4(0, 0, 0, 0);
       if (tid < 272 - 256) *reinterpret_cast<uint4*>(lds + (hc.a2 >> 16)) = make_uint4(0, 0, 0, 0);
@@ -613,8 +613,7 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
       const int r64a = dpp_row_sum((int)s64a - corr), r64b = dpp_row_sum((int)s64b - corr);
       if ((lane & 15) == 0) {  // one owner per 16x16 block: no atomics
         const int bi = ((q >> 1) * 2 + (blk >> 1)) * 4 + (q & 1) * 2 + (blk & 1);
-        logitL[(5 + bi) * 2 + 0] += r16a;
-        logitL[(5 + bi) * 2 + 1] += r16b;
+        *reinterpret_cast<int2*>(logitL + (5 + bi) * 2) = make_int2(r16a + hb16a, r16b + hb16b);  // plain stores: nothing to read back
       }
       const int q32a = __builtin_amdgcn_readlane(r32a, 0) + __builtin_amdgcn_readlane(r32a, 16) +
                        __builtin_amdgcn_readlane(r32a, 32) + __builtin_amdgcn_readlane(r32a, 48);
@@ -625,10 +624,8 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
       const int q64b = __builtin_amdgcn_readlane(r64b, 0) + __builtin_amdgcn_readlane(r64b, 16) +
                        __builtin_amdgcn_readlane(r64b, 32) + __builtin_amdgcn_readlane(r64b, 48);
       if (lane == 0) {
-        logitL[(1 + q) * 2 + 0] += q32a;  // one wave per quadrant: no atomics
-        logitL[(1 + q) * 2 + 1] += q32b;
-        atomicAdd(&logitL[0], q64a);      // four waves meet in the 64-level logits
-        atomicAdd(&logitL[1], q64b);
+        *reinterpret_cast<int2*>(logitL + (1 + q) * 2) = make_int2(q32a + hb32a, q32b + hb32b);  // one wave per quadrant
+        *reinterpret_cast<int2*>(logitL + 44 + 2 * q) = make_int2(q64a, q64b);  // the readers add the four waves' parts
       }
     }
     // the A2/input region (R2) is free since the P3 barrier: stage the next CTU now, its P1 needs no extra barrier
@@ -643,7 +640,8 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
       FHEVC_PHASE_IDS
       const int vw = min(64, F.width - cx * 64), vh = min(64, F.height - cy * 64);
       const int ux = tid & 15, uy = tid >> 4;
-      const int2 l64 = *reinterpret_cast<const int2*>(logitL);
+      const int4 pa = *reinterpret_cast<const int4*>(logitL + 44), pb = *reinterpret_cast<const int4*>(logitL + 48);
+      const int2 l64 = make_int2(hb64a + pa.x + pa.z + pb.x + pb.z, hb64b + pa.y + pa.w + pb.y + pb.w);
       const int2 l32 = *reinterpret_cast<const int2*>(logitL + 2 * (1 + (uy >> 3) * 2 + (ux >> 3)));
       const int2 l16 = *reinterpret_cast<const int2*>(logitL + 2 * (5 + (uy >> 2) * 4 + (ux >> 2)));
       const bool inside = (ux * 4 < vw) && (uy * 4 < vh);
@@ -664,12 +662,12 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
         const int d = (inside && s64) ? (s32 ? (s16 ? 3 : 2) : 1) : 0;
         d_depth_max[o * 256 + tid] = (uint8_t)d;
       }
-      if (d_logits != nullptr && tid < 42) d_logits[o * 42 + tid] = logitL[tid];
+      if (d_logits != nullptr && tid < 42) d_logits[o * 42 + tid] = tid == 0 ? l64.x : (tid == 1 ? l64.y : logitL[tid]);
       if (d_flags != nullptr && wave == 0) {  // the 21 decisions as one word: lane k < 21 evaluates node k
         const int k = lane;
         const int bi = k - 5, qq = k < 5 ? k - 1 : (bi >> 3) * 2 + ((bi >> 1) & 1);  // own / parent quadrant
         const int qx = (qq & 1) * 32, qy = (qq >> 1) * 32, bxx = (bi & 3) * 16, byy = (bi >> 2) * 16;
-        const int2 a64 = *reinterpret_cast<const int2*>(logitL);
+        const int2 a64 = l64;
         const bool n64 = (vw < 64) || (vh < 64) || (a64.y - a64.x > margin_split);
         bool bit = n64;
         if (k >= 1 && k < 21) {
