@@ -59,13 +59,6 @@ int fail(fhevc_ctx* c, int code, const char* what, hipError_t e = hipSuccess)
     if (e_ != hipSuccess) return fail((c), FHEVC_E_HIP, #call, e_);        \
   } while (0)
 
-inline uint16_t bf16_of_small_int(int v)  // |v| <= 256: exact
-{
-  float f = (float)v;
-  uint32_t u;
-  std::memcpy(&u, &f, 4);
-  return (uint16_t)(u >> 16);
-}
 
 // FHW1 blob layout (fasthevc_amd/weights.py)
 struct BlobView {
@@ -117,8 +110,7 @@ int build_weight_image(fhevc_ctx* c, const BlobView& b)
     c->scale[l] = std::ldexp(1.0f, -s);
   }
   std::vector<uint16_t> frag((size_t)FHEVC_FRAG_TOTAL * 8, 0);
-  auto put = [&](int frag_idx, int lane, int j, int v) { frag[((size_t)frag_idx + lane) * 8 + j] = bf16_of_small_int(v); };
-  // conv1 and conv2 weights carry their layer's 2^-shift: w * 2^-s is still exact in bf16 (a power-of-two scaling of an 8-bit integer)
+  // all conv weights carry their layer's 2^-shift: w * 2^-s is still exact in bf16 (a power-of-two scaling of an 8-bit integer)
   // and every partial sum is a multiple of 2^-s below 2^24 * 2^-s, so the fp32 accumulation stays exact and the MFMA
   // delivers (acc + b) * 2^-s directly: one multiply per output less in the epilogue
   auto put_scaled = [&](int layer, int frag_idx, int lane, int j, int v) {
@@ -146,7 +138,7 @@ int build_weight_image(fhevc_ctx* c, const BlobView& b)
       for (int t = 0; t < 2; ++t)
         for (int s = 0; s < 18; ++s) {
           const int oc = 32 * t + r, ic = 16 * (s & 1) + k, tap = s >> 1;
-          put(FHEVC_FRAG_CONV3 + (t * 18 + s) * 64, lane, j, b.w3[(oc * 32 + ic) * 9 + tap]);
+          put_scaled(2, FHEVC_FRAG_CONV3 + (t * 18 + s) * 64, lane, j, b.w3[(oc * 32 + ic) * 9 + tap]);
         }
     }
   }

@@ -7,8 +7,8 @@
 
 // ---- depth CNN (k_cnn.hip) -------------------------------------------------------------------------------
 // Packed weight image in HBM, built once by fhevc_set_weights (fhevc_api.hip: build_weight_image):
-//   frag  : MFMA A-operand fragments, one uint4 (8 bf16) per lane: conv1 [2][64], conv2 [9][64] (both scaled by their
-//           layer's 2^-shift), conv3 [2][18][64]
+//   frag  : MFMA A-operand fragments, one uint4 (8 bf16) per lane: conv1 [2][64], conv2 [9][64], conv3 [2][18][64], all scaled
+//           by their layer's 2^-shift
 //   bias  : float b1[16], b2[32], b3[64]
 //   whead : uint8 (w + 128): wh64[2][4096], wh32[2][4096], wh16[2][1024]
 //   bhead : int32 bh64[2], bh32[2], bh16[2], qp_bias[3][52]
@@ -34,7 +34,7 @@ struct FhevcCnnWeights {
   const float* bias;
   const uint8_t* whead;
   const int32_t* bhead;      // bh64[2], bh32[2], bh16[2], then qp_bias[3][52]
-  float scale[3];            // 2^-shift per conv layer (conv1/conv2: folded into the fragments; used for the biases, conv3: epilogue)
+  float scale[3];            // 2^-shift per conv layer (folded into the fragments; the kernel pre-scales the biases with it)
 };
 
 // d_depth_max / margins: soft decisions (nullptr / 0, 0 = the plain map only)

@@ -13,8 +13,10 @@
 //     with one ds_read_b128 per K-step: activations live in LDS as 8-channel planes [y][x][8] bf16 so the
 //     16-lane groups of a ds_read_b128 cover 256 contiguous bytes;
 //   * operands are fixed-point integers (|w| <= 127, activations 0..255, |acc| < 2^24) so the fp32
-//     accumulation is exact in any order -> the integer depth map is bit-exact against the CPU oracle; conv1 and conv2
-//     carry their 2^-shift in the bf16 weights (still exact) and start from the pre-scaled bias as the MFMA's C operand;
+//     accumulation is exact in any order -> the integer depth map is bit-exact against the CPU oracle; every conv
+//     carries its 2^-shift in the bf16 weights (still exact) and starts from the pre-scaled bias as the MFMA's C operand;
+//   * the waves run with fp32 rounding toward -inf, which turns v_cvt_pk_u8_f32 into floor + ReLU + clamp + pack
+//     (conv3's whole epilogue); every other fp32 operation of the kernel is exact, so the mode changes nothing else;
 //   * ReLU/requant/max-pool are fused into the MFMA epilogue (in-lane max for the vertical pair,
 //     DPP quad_perm for the horizontal pair), FC heads run on v_dot4_u32_u8 with weights resident in LDS;
 //   * conv1 folds the 2x2 max-pool window into the MFMA's M dimension: A rows = (16 filters) x (2x2 pre-pool
@@ -147,18 +149,19 @@ __device__ __forceinline__ void conv2_store(const f32x16& acc0, const f32x16& ac
   *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
   *reinterpret_cast<uint2*>(dst + A2_PLANE) = make_uint2(pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
 }
-// conv3: requant to u8, 16 channels of this lane half for one position.  v_cvt_pk_u8_f32 rounds to nearest even and
-// saturates to 0..255; the conv3 bias in LDS carries an extra -0.5 + 2^-(s+1), which turns that rounding into
-// floor() for every multiple of 2^-s (exact while shift <= 14): fma + cvt = floor + ReLU + clamp + pack
+// conv3: requant to u8, 16 channels of this lane half for one position.  The kernel runs with MODE.fp_round = toward
+// -inf (set once at its top), under which v_cvt_pk_u8_f32 rounds DOWN and saturates to 0..255 (verified on hardware:
+// tools/probes/probe_cvt_mode): one instruction = floor + ReLU + clamp + pack.  conv3's weights carry 2^-s and the
+// accumulators start from the pre-scaled bias tile, so they already hold (acc + b) * 2^-s exactly.
 // dst = start of the position's 64-byte row + 4*h; channel 32*tile + 8*g + 4*h + k lives in logical 16-B chunk
 // 2*tile + (g >> 1), at byte 8*(g & 1) + 4*h + k; psw = chunk swizzle of this position
-__device__ __forceinline__ void conv3_store(const f32x16& acc, const f32x16& b, float scale, unsigned char* dst, int tile, int psw)
+__device__ __forceinline__ void conv3_store(const f32x16& acc, unsigned char* dst, int tile, int psw)
 {
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     unsigned d = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) d = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(acc[4 * g + k], scale, b[4 * g + k]), k, d);
+    for (int k = 0; k < 4; ++k) d = __builtin_amdgcn_cvt_pk_u8_f32(acc[4 * g + k], k, d);
     *reinterpret_cast<unsigned*>(dst + (((2 * tile + (g >> 1)) ^ psw) << 4) + 8 * (g & 1)) = d;
   }
 }
@@ -216,11 +219,10 @@ __device__ __forceinline__ const unsigned char* conv3_frag(const unsigned char* 
   return base + 2 * (s & 1) * A2_PLANE + (((s >> 1) / 3) * A2_PITCH + ((s >> 1) % 3)) * 16;
 }
 template <bool FIRST, bool LAST, int PHASE>
-__device__ __forceinline__ f32x16 conv3_unit(const unsigned char* a2, int yp, int yp_next, const bf16x8 (&wA3)[18], bf16x8 (&ring)[RING])
+__device__ __forceinline__ f32x16 conv3_unit(const unsigned char* a2, int yp, int yp_next, const bf16x8 (&wA3)[18], bf16x8 (&ring)[RING],
+                                             const f32x16& binit)
 {
-  f32x16 acc;
-#pragma unroll
-  for (int k = 0; k < 16; ++k) acc[k] = 0.0f;
+  f32x16 acc = binit;  // C operand of the first MFMA: the bias costs nothing
   const unsigned char* base = a2 + (2 * yp) * A2_PITCH * 16;
   const unsigned char* next = a2 + (2 * yp_next) * A2_PITCH * 16;
   if (FIRST) {
@@ -395,6 +397,9 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
                                                                   uint8_t* __restrict__ d_depth_max, int margin_split, int margin_stop)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  // fp32 rounding mode of this wave: toward -inf (MODE.fp_round, hwreg id 1, bits 1:0 <- 2).  Every fp32 operation of
+  // the kernel is exact (integers scaled by powers of two), so only v_cvt_pk_u8_f32 notices: it becomes floor + clamp
+  __builtin_amdgcn_s_setreg((1 << 11) | 1, 2);
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const HaloCells hc = halo_cells(tid);  // three registers for the life of the kernel
@@ -421,7 +426,6 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
   if (tid < 112) {  // all pre-scaled (exact: integer * 2^-s); b1 is the accumulator init of conv1, whose weights carry 2^-s1
     float b = W.bias[tid];
     b *= (tid < 16 ? W.scale[0] : (tid < 48 ? W.scale[1] : W.scale[2]));
-    if (tid >= 48) b += 0.5f * W.scale[2] - 0.5f;
     biasL[tid] = b;
   }
   // head weights stay in LDS for the life of the workgroup; the four 16-B chunks of a 64-B row are XOR-swizzled by
@@ -553,19 +557,21 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
       const int yp0 = wave >> 1;
       const f32x16 b3 = bias_tile(bias3, h);  // once per phase (see conv2_store)
       bf16x8 ring[RING];
-      f32x16 accA = conv3_unit<true, false, 0>(a2, yp0, yp0 + 2, wA3, ring);  // PHASE of unit k = (18 k) % RING
+      f32x16 accA = conv3_unit<true, false, 0>(a2, yp0, yp0 + 2, wA3, ring, b3);  // PHASE of unit k = (18 k) % RING
       __builtin_amdgcn_sched_group_barrier(0x100, RING + 4, 0);
       sched_chain18<0>();
-      f32x16 accB = conv3_unit<false, false, (18 * 1) % RING>(a2, yp0 + 2, yp0 + 4, wA3, ring);
-      conv3_store(accA, b3, W.scale[2], a3dst + (yp0 + 0) * 2048, tile3, psw);
-      sched_chain18<4>();
-      accA = conv3_unit<false, false, (18 * 2) % RING>(a2, yp0 + 4, yp0 + 6, wA3, ring);
-      conv3_store(accB, b3, W.scale[2], a3dst + (yp0 + 2) * 2048, tile3, psw);
-      sched_chain18<4>();
-      accB = conv3_unit<false, true, (18 * 3) % RING>(a2, yp0 + 6, yp0 + 6, wA3, ring);
-      conv3_store(accA, b3, W.scale[2], a3dst + (yp0 + 4) * 2048, tile3, psw);
-      sched_chain18<4>();
-      conv3_store(accB, b3, W.scale[2], a3dst + (yp0 + 6) * 2048, tile3, psw);
+      f32x16 accB = conv3_unit<false, false, (18 * 1) % RING>(a2, yp0 + 2, yp0 + 4, wA3, ring, b3);
+      conv3_store(accA, a3dst + (yp0 + 0) * 2048, tile3, psw);
+      sched_chain18<0>();
+      accA = conv3_unit<false, false, (18 * 2) % RING>(a2, yp0 + 4, yp0 + 6, wA3, ring, b3);
+      conv3_store(accB, a3dst + (yp0 + 2) * 2048, tile3, psw);
+      sched_chain18<0>();
+      accB = conv3_unit<false, true, (18 * 3) % RING>(a2, yp0 + 6, yp0 + 6, wA3, ring, b3);
+      conv3_store(accA, a3dst + (yp0 + 4) * 2048, tile3, psw);
+      sched_chain18<0>();
+      conv3_store(accB, a3dst + (yp0 + 6) * 2048, tile3, psw);
+      asm volatile("" ::"v"(b3));  // the bias tile stays in its registers to the end of the phase: otherwise the last unit's
+                                   // accumulator takes them over and its chain is hoisted into the previous one
     }
     __syncthreads();
     FHEVC_STAMP(3)
