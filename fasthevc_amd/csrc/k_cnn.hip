@@ -46,7 +46,7 @@ constexpr int A2_PLANE = 18 * 18 * 16 + 96;       // 5280: planes start 32 B apa
                                                   // stores of conv2 (even lane -> plane g, odd lane -> plane g+2) never share a bank
 constexpr int R2_OFF = R1_OFF + R1_BYTES;         // R2: input CTU bf16 [66][68]; later A2 (4 planes)
 constexpr int R2_BYTES = 4 * A2_PLANE;            // 20736
-constexpr int IN_PITCH = 66;                      // dwords per input row PAIR: lo = halo row 2d, hi = 2d+1; 66 = 2 mod 32 spreads the staging stores (8 dword rows x 8 lanes 8 dwords apart) over all banks
+constexpr int IN_PITCH = 68;                      // dwords per input row PAIR (66 used): lo = row 2j, hi = row 2j+1
 constexpr int BIAS_OFF = R2_OFF + R2_BYTES;       // float b1[16] b2[32] b3[64]
 constexpr int LOGIT_OFF = BIAS_OFF + 112 * 4;     // int logits[21][2] (the 64-level pair is formed by the readers) + at [44..51] the
                                                   // four waves' partial 64-level sums
@@ -239,14 +239,9 @@ __device__ __forceinline__ f32x16 conv3_unit(const unsigned char* a2, int yp, in
   return acc;
 }
 
-// One thread's 16 samples of a CTU fetched ahead of use: two picture rows x 8 columns (columns 8*ld_seg ..).  The LDS
-// image keeps two picture rows per dword (halo rows hy = row + 1: dword row hy >> 1, half hy & 1), so thread group
-// ld_j < 31 owns picture rows 2*ld_j + 1 (low halves) and 2*ld_j + 2 (high halves) = dword row ld_j + 1 and stores whole
-// dwords; group 31 owns the two leftover rows 0 (high halves of dword row 0) and 63 (low halves of dword row 32), whose
-// other halves are the top and bottom halo.  fast = 0: picture edge or unaligned plane, guarded scalar loads instead.
+// One thread's 16 samples of a CTU (picture row ld_row, columns 16*ld_seg..) fetched ahead of use.  fast = 0:
+// picture edge or unaligned plane, P0 falls back to guarded scalar loads.
 struct Prefetched { uint4 a, b; int fast; };
-__device__ __forceinline__ int stage_row_a(int ld_j) { return ld_j < 31 ? 2 * ld_j + 1 : 0; }
-__device__ __forceinline__ int stage_row_b(int ld_j) { return ld_j < 31 ? 2 * ld_j + 2 : 63; }
 // CTU coordinates of a work item: frame, CTU row inside the band, CTU column.  A workgroup walks its items with a
 // mixed-radix increment (advance) instead of dividing the work index: integer division costs ~40 VALU instructions.
 struct CtuPos { int f, ry, cx; };
@@ -257,112 +252,76 @@ __device__ __forceinline__ CtuPos advance(CtuPos c, const CtuPos& step, int band
   if (c.ry >= band_rows) { c.ry -= band_rows; c.f++; }
   return c;
 }
-__device__ __forceinline__ Prefetched prefetch_ctu(const FhevcFrames& F, bool live, CtuPos c, int ld_j, int ld_seg)
+__device__ __forceinline__ Prefetched prefetch_ctu(const FhevcFrames& F, bool live, CtuPos c, int ld_row, int ld_seg)
 {
   Prefetched p;
   p.a = make_uint4(0, 0, 0, 0); p.b = make_uint4(0, 0, 0, 0); p.fast = 0;
   if (!live) return p;
-  const int pya = (F.row_begin + c.ry) * 64 + stage_row_a(ld_j), pyb = (F.row_begin + c.ry) * 64 + stage_row_b(ld_j);
-  const int px0 = c.cx * 64 + ld_seg * 8;
-  if (max(pya, pyb) >= F.height || px0 + 8 > F.width) return p;
-  const long long fb = (long long)c.f * F.frame_stride + px0;
-  const long long ba = fb + (long long)pya * F.stride, bb = fb + (long long)pyb * F.stride;
+  const int pf = c.f, pcy = F.row_begin + c.ry, pcx = c.cx;
+  const int py = pcy * 64 + ld_row, px0 = pcx * 64 + ld_seg * 16;
+  if (py >= F.height || px0 + 16 > F.width) return p;
+  const long long base = (long long)pf * F.frame_stride + (long long)py * F.stride + px0;
   if (F.sample_bytes == 2) {
-    const int16_t* sa = reinterpret_cast<const int16_t*>(F.luma) + ba;
-    const int16_t* sb = reinterpret_cast<const int16_t*>(F.luma) + bb;
-    if ((reinterpret_cast<uintptr_t>(sa) | reinterpret_cast<uintptr_t>(sb)) & 15) return p;
-    p.a = *reinterpret_cast<const uint4*>(sa);
-    p.b = *reinterpret_cast<const uint4*>(sb);
+    const int16_t* src = reinterpret_cast<const int16_t*>(F.luma) + base;
+    if (reinterpret_cast<uintptr_t>(src) & 15) return p;
+    p.a = *reinterpret_cast<const uint4*>(src);
+    p.b = *reinterpret_cast<const uint4*>(src + 8);
   } else {
-    const uint8_t* sa = reinterpret_cast<const uint8_t*>(F.luma) + ba;
-    const uint8_t* sb = reinterpret_cast<const uint8_t*>(F.luma) + bb;
-    if ((reinterpret_cast<uintptr_t>(sa) | reinterpret_cast<uintptr_t>(sb)) & 7) return p;
-    const uint2 ua = *reinterpret_cast<const uint2*>(sa), ub = *reinterpret_cast<const uint2*>(sb);
-    p.a.x = ua.x; p.a.y = ua.y; p.b.x = ub.x; p.b.y = ub.y;
+    const uint8_t* src = reinterpret_cast<const uint8_t*>(F.luma) + base;
+    if (reinterpret_cast<uintptr_t>(src) & 15) return p;
+    p.a = *reinterpret_cast<const uint4*>(src);
   }
   p.fast = 1;
   return p;
 }
 
-typedef __attribute__((ext_vector_type(2))) short s16x2;
-// two int16 samples of one dword -> two centred 8-bit samples (load_centered on both halves), packed 16-bit VALU
-__device__ __forceinline__ unsigned centre_pair(unsigned w, int shift, unsigned rnd2)
-{
-  const s16x2 zero = { 0, 0 }, top = { 255, 255 }, mid = { 128, 128 };
-  s16x2 t = __builtin_elementwise_max(__builtin_bit_cast(s16x2, w), zero);
-  if (shift > 0) {
-    u16x2 u = __builtin_bit_cast(u16x2, t) + __builtin_bit_cast(u16x2, rnd2);
-    u16x2 sh = { (unsigned short)shift, (unsigned short)shift };
-    t = __builtin_bit_cast(s16x2, (u16x2)(u >> sh));
-  }
-  t = __builtin_elementwise_min(t, top) - mid;
-  return __builtin_bit_cast(unsigned, t);
-}
-
 // Stage one CTU into LDS (region R2): centred 8-bit samples as bf16, two picture rows per dword, zero halo.
 // halo coordinates: hy = row + 1, hx = col + 1; dword (hy >> 1) * IN_PITCH + hx, half (hy & 1)
 __device__ __forceinline__ void stage_ctu(unsigned char* lds, const Prefetched& pre, const FhevcFrames& F, CtuPos c,
-                                          int tid, int ld_j, int ld_seg, int shift_in, unsigned in_cell)
+                                          int tid, int ld_row, int ld_seg, int shift_in, unsigned in_cells)
 {
-  float fa[8], fb[8];  // centred samples of the two rows; only their upper 16 bits (= bf16, exact) are stored
+  unsigned short* inh = reinterpret_cast<unsigned short*>(lds + R2_OFF);
+  const int hy = ld_row + 1;
+  unsigned short* dst = inh + 2 * ((hy >> 1) * IN_PITCH + ld_seg * 16 + 1) + (hy & 1);
   if (pre.fast) {
     if (F.sample_bytes == 2) {
-      const unsigned rnd2 = shift_in > 0 ? (0x00010001u << (shift_in - 1)) : 0u;
-      const unsigned wa[4] = { pre.a.x, pre.a.y, pre.a.z, pre.a.w }, wb[4] = { pre.b.x, pre.b.y, pre.b.z, pre.b.w };
+      const unsigned wds[8] = { pre.a.x, pre.a.y, pre.a.z, pre.a.w, pre.b.x, pre.b.y, pre.b.z, pre.b.w };
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const unsigned ta = centre_pair(wa[k], shift_in, rnd2), tb = centre_pair(wb[k], shift_in, rnd2);
-        fa[2 * k] = (float)(short)(ta & 0xFFFF); fa[2 * k + 1] = (float)((int)ta >> 16);
-        fb[2 * k] = (float)(short)(tb & 0xFFFF); fb[2 * k + 1] = (float)((int)tb >> 16);
+      for (int j = 0; j < 8; ++j) {
+        short s0 = (short)(wds[j] & 0xFFFF), s1 = (short)(wds[j] >> 16);
+        dst[4 * j] = (unsigned short)(__float_as_uint((float)load_centered(&s0, shift_in)) >> 16);
+        dst[4 * j + 2] = (unsigned short)(__float_as_uint((float)load_centered(&s1, shift_in)) >> 16);
       }
     } else {
-      const unsigned wa[2] = { pre.a.x, pre.a.y }, wb[2] = { pre.b.x, pre.b.y };
+      const unsigned wds[4] = { pre.a.x, pre.a.y, pre.a.z, pre.a.w };
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        fa[k] = (float)((wa[k >> 2] >> (8 * (k & 3))) & 0xFF) - 128.0f;
-        fb[k] = (float)((wb[k >> 2] >> (8 * (k & 3))) & 0xFF) - 128.0f;
+      for (int j = 0; j < 16; ++j) {
+        const int v = (int)((wds[j >> 2] >> (8 * (j & 3))) & 0xFF) - 128;
+        dst[2 * j] = (unsigned short)(__float_as_uint((float)v) >> 16);
       }
     }
   } else {  // picture edge or unaligned plane: guarded scalar loads
-    const int cy = F.row_begin + c.ry;
-    const int pya = cy * 64 + stage_row_a(ld_j), pyb = cy * 64 + stage_row_b(ld_j), px0 = c.cx * 64 + ld_seg * 8;
-    const long long fbase = (long long)c.f * F.frame_stride + px0;
-    const long long ba = fbase + (long long)pya * F.stride, bb = fbase + (long long)pyb * F.stride;
-#pragma unroll 2
-    for (int k = 0; k < 8; ++k) {
-      int va = 0, vb = 0;
-      if (px0 + k < F.width) {
-        if (F.sample_bytes == 2) {
-          if (pya < F.height) va = load_centered(reinterpret_cast<const int16_t*>(F.luma) + ba + k, shift_in);
-          if (pyb < F.height) vb = load_centered(reinterpret_cast<const int16_t*>(F.luma) + bb + k, shift_in);
-        } else {
-          if (pya < F.height) va = (int)reinterpret_cast<const uint8_t*>(F.luma)[ba + k] - 128;
-          if (pyb < F.height) vb = (int)reinterpret_cast<const uint8_t*>(F.luma)[bb + k] - 128;
-        }
+    const int f = c.f, cy = F.row_begin + c.ry, cx = c.cx;
+    const int py = cy * 64 + ld_row, px0 = cx * 64 + ld_seg * 16;
+    const long long base = (long long)f * F.frame_stride + (long long)py * F.stride + px0;
+    const bool row_ok = py < F.height;
+#pragma unroll 4
+    for (int j = 0; j < 16; ++j) {
+      int v = 0;
+      if (row_ok && px0 + j < F.width) {
+        if (F.sample_bytes == 2) v = load_centered(reinterpret_cast<const int16_t*>(F.luma) + base + j, shift_in);
+        else v = (int)reinterpret_cast<const uint8_t*>(F.luma)[base + j] - 128;
       }
-      fa[k] = (float)va; fb[k] = (float)vb;
+      dst[2 * j] = (unsigned short)(__float_as_uint((float)v) >> 16);
     }
   }
-  unsigned* in32 = reinterpret_cast<unsigned*>(lds + R2_OFF);
-  if (ld_j < 31) {
-    unsigned* dst = in32 + (ld_j + 1) * IN_PITCH + ld_seg * 8 + 1;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) dst[k] = pack_bf16(fa[k], fb[k]);
-  } else {  // row 0 above the top halo row's zeros, row 63 below which the bottom halo row's zeros
-    unsigned* d0 = in32 + ld_seg * 8 + 1;
-    unsigned* d32 = in32 + 32 * IN_PITCH + ld_seg * 8 + 1;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      d0[k] = __float_as_uint(fa[k]) & 0xFFFF0000u;
-      d32[k] = __float_as_uint(fb[k]) >> 16;
-    }
-  }
-  // left and right halo columns (hx = 0, 65) of the 33 dword rows; the top and bottom halo rows came with rows 0 and 63
-  if (tid < 66) *reinterpret_cast<unsigned*>(lds + in_cell) = 0;
+  // input halo: 66*66 - 64*64 = 260 two-byte cells
+  *reinterpret_cast<unsigned short*>(lds + (in_cells & 0xFFFF)) = 0;
+  if (tid < 260 - 256) *reinterpret_cast<unsigned short*>(lds + (in_cells >> 16)) = 0;
 }
 // LDS byte offsets of the halo cells a thread zeroes (computed once per kernel: the index arithmetic with its three-way
 // divergence cost ~700 cycles per CTU when it ran inside the phases).  Cell e of: the conv1 output halo (264 x 16 B),
-// the conv2 output halo (272 x 16 B), the input tile's left/right halo columns (66 x 4 B).
+// the conv2 output halo (272 x 16 B), the input tile halo (260 x 2 B).
 __device__ __forceinline__ int a1_halo_off(int e)
 {
   const int pl = e / 132, k0 = e - pl * 132;
@@ -381,9 +340,13 @@ __device__ __forceinline__ int a2_halo_off(int e)
   else { const int k = k0 - 36; y = 1 + (k >> 1); x = (k & 1) ? 17 : 0; }
   return R2_OFF + pl * A2_PLANE + (y * A2_PITCH + x) * 16;
 }
-__device__ __forceinline__ int in_halo_off(int e)  // dword rows 0..32, columns hx = 0 and 65 (66 cells of 4 B)
+__device__ __forceinline__ int in_halo_off(int e)
 {
-  return R2_OFF + 4 * ((e >> 1) * IN_PITCH + ((e & 1) ? 65 : 0));
+  int y, x;
+  if (e < 66) { y = 0; x = e; }
+  else if (e < 132) { y = 65; x = e - 66; }
+  else { const int k = e - 132; y = 1 + (k >> 1); x = (k & 1) ? 65 : 0; }
+  return R2_OFF + 2 * (2 * ((y >> 1) * IN_PITCH + x) + (y & 1));
 }
 // a thread's two cells of each halo, packed as (first | second << 16); all offsets are below 64 KiB
 struct HaloCells { unsigned a1, a2, in; };
@@ -392,7 +355,7 @@ __device__ __forceinline__ HaloCells halo_cells(int tid)
   HaloCells hc;
   hc.a1 = (unsigned)a1_halo_off(tid) | ((unsigned)a1_halo_off(min(tid + 256, 263)) << 16);
   hc.a2 = (unsigned)a2_halo_off(tid) | ((unsigned)a2_halo_off(min(tid + 256, 271)) << 16);
-  hc.in = (unsigned)in_halo_off(min(tid, 65));
+  hc.in = (unsigned)in_halo_off(tid) | ((unsigned)in_halo_off(min(tid + 256, 259)) << 16);
   return hc;
 }
 static_assert(R2_OFF + R2_BYTES <= 65536, "halo offsets are packed into 16 bits");
@@ -487,8 +450,8 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
   }
   if (STAMPS) tprev = stamp();
 
-  // this thread's 16 samples of a CTU: row pair group tid >> 3 (see Prefetched), columns 8 * (tid & 7) ..
-  const int ld_row = tid >> 3, ld_seg = tid & 7;
+  // this thread's 16 samples of a CTU: picture row (tid >> 2), columns 16 * (tid & 3) ..
+  const int ld_row = tid >> 2, ld_seg = tid & 3;
   // XCD-aware order (speed only): blockIdx % 8 share an L2, give each XCD a contiguous run of CTUs per sweep so that the
   // 128-byte lines shared by horizontally adjacent CTUs (HM's unaligned margins) are fetched into one L2, not two
   const int vblock = (gridDim.x & 7) ? (int)blockIdx.x : (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));
