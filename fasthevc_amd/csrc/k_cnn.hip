@@ -36,6 +36,9 @@ namespace {
 
 // ---- LDS map (bytes) ---------------------------------------------------------------------------------------
 constexpr int A1_PITCH = 34;                      // conv1 output 32x32 + 1 halo each side, positions per row
+constexpr int A1_ROW = A1_PITCH * 16;             // bytes per row of a plane; inside a row the columns are split by parity:
+constexpr int A1_PAR = 17 * 16;                   // column x lives at (x & 1) * A1_PAR + (x >> 1) * 16, so that the stride-2
+                                                  // column runs conv2 reads (one pooled column per lane) are contiguous
 constexpr int A1_PLANE = 34 * 34 * 16;            // one 8-channel plane: 16 B per position
 constexpr int R1_OFF = 0;                         // R1: A1 (2 planes); later A3 u8 [256][64] + pooled [64][64]
 constexpr int R1_BYTES = 2 * A1_PLANE;            // 36992
@@ -131,23 +134,33 @@ __device__ __forceinline__ void conv1_store(const f32x16& acc0, const f32x16& ac
   }
   *reinterpret_cast<uint4*>(dst) = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
 }
-// conv2: two output rows -> 2x2 max-pool, requant, store: the even lane of a horizontal pair finishes planes 0-1
-// (regs 0-7), the odd lane planes 2-3 (regs 8-15): 8 requants and two 8-byte stores per lane
-// The accumulators start from the pre-scaled bias tile and conv2's weights carry 2^-s, so they already hold
-// (acc + b) * 2^-s (max-pooling commutes with the common bias): pool, floor, clamp, pack.
-__device__ __forceinline__ void conv2_store(const f32x16& acc0, const f32x16& acc1, unsigned char* lds, int yp, int r, int h)
+// conv2: a lane owns ONE pooled position; its four pre-pool outputs sit in four accumulators (dy, dx), so the 2x2
+// max-pool is in-lane.  The accumulators start from the pre-scaled bias tile and conv2's weights carry 2^-s, so they
+// already hold (acc + b) * 2^-s (max-pooling commutes with the common bias): pool, floor, clamp, pack.
+// First half (dy = 0 done): the horizontal maximum, in place
+__device__ __forceinline__ void conv2_pool_h(f32x16& acc0, const f32x16& acc1)
 {
-  const bool odd = r & 1;
-  float v[8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const float m0 = max_with_xor1(fmaxf(acc0[k], acc1[k]));
-    const float m1 = max_with_xor1(fmaxf(acc0[k + 8], acc1[k + 8]));
-    v[k] = __builtin_amdgcn_fmed3f(floorf(odd ? m1 : m0), 0.0f, 255.0f);
+  for (int k = 0; k < 16; ++k) acc0[k] = fmaxf(acc0[k], acc1[k]);
+}
+// Second half (dy = 1 done): the vertical maximum into the same registers (this frees the two accumulators for the next
+// half-chain before it starts: the phase is register-tight) ...
+__device__ __forceinline__ void conv2_pool_v(f32x16& top, const f32x16& acc0, const f32x16& acc1)
+{
+#pragma unroll
+  for (int k = 0; k < 16; ++k) top[k] = fmaxf(fmaxf(top[k], acc0[k]), acc1[k]);
+}
+// ... then requant and four 8-byte stores under the next half-chain (reg i -> channel (i & 3) + 8 * (i >> 2) + 4h: plane i >> 2,
+// bytes 8h + 2 * (i & 3)); dst = this lane's position in plane 0 + 8h
+__device__ __forceinline__ void conv2_requant_store(const f32x16& m, unsigned char* dst)
+{
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = __builtin_amdgcn_fmed3f(floorf(m[4 * g + k]), 0.0f, 255.0f);
+    *reinterpret_cast<uint2*>(dst + g * A2_PLANE) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
   }
-  unsigned char* dst = lds + R2_OFF + (odd ? 2 * A2_PLANE : 0) + ((yp + 1) * A2_PITCH + (r >> 1) + 1) * 16 + h * 8;
-  *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
-  *reinterpret_cast<uint2*>(dst + A2_PLANE) = make_uint2(pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
 }
 // conv3: requant to u8, 16 channels of this lane half for one position.  The kernel runs with MODE.fp_round = toward
 // -inf (set once at its top), under which v_cvt_pk_u8_f32 rounds DOWN and saturates to 0..255 (verified on hardware:
@@ -182,32 +195,31 @@ __device__ __forceinline__ void sched_chain18()
     if (VALU_PER_MFMA > 0) __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_MFMA, 0);  // VALU filler
   }
 }
-// conv2 MFMA chain of one unit = output rows 2yp, 2yp+1 (32 positions each), K = 9 taps x 16 channels:
-// 12 fragments (4 input rows x 3 kx), 18 MFMAs (rows 1, 2 feed both accumulators).  The fragment ring runs ACROSS
-// units: the last RING reads of a unit fetch the first fragments of the next one, so only the first unit of a phase
-// exposes the LDS latency (a per-unit preload costs ~4 exposed reads = ~500 cycles per unit).
+// conv2 MFMA half-chain = pre-pool outputs (dy, dx = 0) and (dy, dx = 1) of 32 pooled positions (two pooled rows x 16
+// columns), K = 9 taps x 16 channels.  Output column 2 pc + dx and tap kx read input column 2 pc + c, c = dx + kx in 0..3:
+// 12 fragments (3 input rows x 4 columns c), 18 MFMAs (c = 1, 2 feed both accumulators).  base = the lane's pooled column
+// in input row (first pre-pool row + dy).  The fragment ring runs ACROSS half-chains: the last RING reads fetch the
+// first fragments of the next one, so only the first of a phase exposes the LDS latency.
 __device__ __forceinline__ const unsigned char* conv2_frag(const unsigned char* base, int f)
 {
-  return base + ((f / 3) * A1_PITCH + (f % 3)) * 16;
+  return base + (f / 4) * A1_ROW + ((f % 4) & 1) * A1_PAR + ((f % 4) >> 1) * 16;
 }
 template <bool FIRST, bool LAST>
-__device__ __forceinline__ void conv2_unit(const unsigned char* a1, int yp, int yp_next, const bf16x8 (&wA2)[9], bf16x8 (&ring)[RING],
+__device__ __forceinline__ void conv2_half(const unsigned char* base, const unsigned char* next, const bf16x8 (&wA2)[9], bf16x8 (&ring)[RING],
                                            const f32x16& binit, f32x16& acc0, f32x16& acc1)
 {
   acc0 = binit;  // C operand of the first MFMA of each accumulator: the bias costs nothing
   acc1 = binit;
-  const unsigned char* base = a1 + (2 * yp) * A1_PITCH * 16;  // halo rows 2yp .. 2yp+3
-  const unsigned char* next = a1 + (2 * yp_next) * A1_PITCH * 16;
   if (FIRST) {
 #pragma unroll
     for (int f = 0; f < RING; ++f) ring[f] = lds_frag(conv2_frag(base, f));
   }
 #pragma unroll
-  for (int f = 0; f < 12; ++f) {  // 12 % RING == 0: ring slots line up from unit to unit
-    const int ir = f / 3, kx = f % 3;
+  for (int f = 0; f < 12; ++f) {  // 12 % RING == 0: ring slots line up from half-chain to half-chain
+    const int ky = f / 4, c = f % 4;
     const bf16x8 b = ring[f % RING];
-    if (ir < 3) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA2[ir * 3 + kx], b, acc0, 0, 0, 0);
-    if (ir > 0) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA2[(ir - 1) * 3 + kx], b, acc1, 0, 0, 0);
+    if (c < 3) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA2[ky * 3 + c], b, acc0, 0, 0, 0);
+    if (c > 0) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA2[ky * 3 + c - 1], b, acc1, 0, 0, 0);
     if (f + RING < 12) ring[f % RING] = lds_frag(conv2_frag(base, f + RING));
     else if (!LAST) ring[f % RING] = lds_frag(conv2_frag(next, f + RING - 12));
   }
@@ -329,7 +341,7 @@ __device__ __forceinline__ int a1_halo_off(int e)
   if (k0 < 34) { y = 0; x = k0; }
   else if (k0 < 68) { y = 33; x = k0 - 34; }
   else { const int k = k0 - 68; y = 1 + (k >> 1); x = (k & 1) ? 33 : 0; }
-  return R1_OFF + pl * A1_PLANE + (y * A1_PITCH + x) * 16;
+  return R1_OFF + pl * A1_PLANE + y * A1_ROW + (x & 1) * A1_PAR + (x >> 1) * 16;
 }
 __device__ __forceinline__ int a2_halo_off(int e)
 {
@@ -498,7 +510,7 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
         const uint2 hi = *reinterpret_cast<const uint2*>(inb + (yp + 1) * (IN_PITCH * 4));
         return __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
       };
-      unsigned char* a1dst = lds + R1_OFF + h * A1_PLANE + (A1_PITCH + r + 1) * 16;  // pooled row 0, column r (halo +1)
+      unsigned char* a1dst = lds + R1_OFF + h * A1_PLANE + A1_ROW + ((r + 1) & 1) * A1_PAR + ((r + 1) >> 1) * 16;  // pooled row 0, column r (halo +1)
       bf16x8 bq = frag1(wave);
 #pragma unroll 2
       for (int i = 0; i < 8; ++i) {
@@ -506,7 +518,7 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
         const f32x16 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA1a, bq, bias1, 0, 0, 0);
         const f32x16 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA1b, bq, bias1, 0, 0, 0);
         bq = frag1(min(yp + 4, 31));  // next unit's fragment travels during the epilogue (last one is redundant)
-        conv1_store(acc0, acc1, a1dst + yp * (A1_PITCH * 16));
+        conv1_store(acc0, acc1, a1dst + yp * A1_ROW);
       }
     }
     __syncthreads();
@@ -518,25 +530,39 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
       // the input tile is dead: zero the A2 halo (68 positions x 4 planes) while conv2 fills the interior
       *reinterpret_cast<uint4*>(lds + (hc.a2 & 0xFFFF)) = make_uint4(0, 0, 0, 0);
       if (tid < 272 - 256) *reinterpret_cast<uint4*>(lds + (hc.a2 >> 16)) = make_uint4(0, 0, 0, 0);
-      const unsigned char* a1p = lds + R1_OFF + h * A1_PLANE + r * 16;
-      // straight-line software pipeline over the wave's 4 units: the MFMA chain of unit i+1 is issued before the
-      // VALU epilogue of unit i, so the scheduler can interleave them (separate pipes)
+      // lane -> pooled position: the 32 columns of a B operand are two pooled rows (pr) x 16 pooled columns (pc), assigned so
+      // that each 16-lane group of a ds_read_b128 ({0-3, 12-15, 20-27} and {4-11, 16-19, 28-31}) is one row's 16 columns =
+      // 256 contiguous bytes (conflict-free whatever the row pitch)
+      // = lanes 4q..4q+3 with an even number of bits set in q: pr = parity of q, pc = 4 * (q >> 1) + (r & 3)
+      const int q = r >> 2;
+      const int pr = (q ^ (q >> 1) ^ (q >> 2)) & 1, pc = ((r >> 3) << 2) | (r & 3);
+      // unit u = pooled rows 2u, 2u+1 = pre-pool rows 4u .. 4u+3 (input halo rows 4u .. 4u+5); this lane: input row 4u + 2pr + dy + ky
+      const unsigned char* a1p = lds + R1_OFF + h * A1_PLANE + (2 * pr) * A1_ROW + pc * 16;
+      unsigned char* a2dst = lds + R2_OFF + ((pr + 1) * A2_PITCH + pc + 1) * 16 + 8 * h;  // pooled row pr of unit 0, plane 0
+      const int u0 = wave, u1 = wave + 4;
+      const unsigned char* h00 = a1p + (4 * u0) * A1_ROW;  // half-chains: (u0, dy 0), (u0, dy 1), (u1, dy 0), (u1, dy 1)
+      const unsigned char* h10 = a1p + (4 * u1) * A1_ROW;
       const f32x16 b2t = bias_tile(biasL + 16, h);  // pre-scaled conv2 biases in the accumulator layout, once per phase
-      f32x16 a0, a1, b0, b1;
+      f32x16 t0, t1, a0, a1;
       bf16x8 ring[RING];
-      conv2_unit<true, false>(a1p, wave, wave + 4, wA2, ring, b2t, a0, a1);
+      conv2_half<true, false>(h00, h00 + A1_ROW, wA2, ring, b2t, t0, t1);
       __builtin_amdgcn_sched_group_barrier(0x100, RING + 4, 0);  // bias tile + the ring's first fragments go out together
       sched_chain18<0>();
-      conv2_unit<false, false>(a1p, wave + 4, wave + 8, wA2, ring, b2t, b0, b1);
-      conv2_store(a0, a1, lds, wave, r, h);
-      sched_chain18<5>();
-      conv2_unit<false, false>(a1p, wave + 8, wave + 12, wA2, ring, b2t, a0, a1);
-      conv2_store(b0, b1, lds, wave + 4, r, h);
-      sched_chain18<5>();
-      conv2_unit<false, true>(a1p, wave + 12, wave + 12, wA2, ring, b2t, b0, b1);
-      conv2_store(a0, a1, lds, wave + 8, r, h);
-      sched_chain18<5>();
-      conv2_store(b0, b1, lds, wave + 12, r, h);
+      conv2_half<false, false>(h00 + A1_ROW, h10, wA2, ring, b2t, a0, a1);
+      conv2_pool_h(t0, t1);
+      sched_chain18<1>();
+      __builtin_amdgcn_sched_barrier(0);
+      conv2_pool_v(t0, a0, a1);
+      __builtin_amdgcn_sched_barrier(0);
+      conv2_half<false, false>(h10, h10 + A1_ROW, wA2, ring, b2t, t1, a0);  // (the registers of t1, a0, a1 are free again)
+      conv2_requant_store(t0, a2dst + (2 * u0) * A2_PITCH * 16);
+      sched_chain18<3>();
+      conv2_half<false, true>(h10 + A1_ROW, h10 + A1_ROW, wA2, ring, b2t, a1, t0);
+      conv2_pool_h(t1, a0);
+      sched_chain18<1>();
+      __builtin_amdgcn_sched_barrier(0);
+      conv2_pool_v(t1, a1, t0);
+      conv2_requant_store(t1, a2dst + (2 * u1) * A2_PITCH * 16);
     }
     __syncthreads();
     FHEVC_STAMP(2)
@@ -597,7 +623,7 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
       const unsigned char* w64 = lds + HEADW_OFF + HEAD64_OFF + ((y >> 1) * 8 + (x >> 1)) * 64;  // 2x2 sum pool
       const int sw16 = y & 3, sw32 = y & 3, sw64 = (y >> 1) & 3;  // (row >> 2) & 3, (row >> 3) & 3 of the weight rows (both classes)
       unsigned sa = 0, s16a = 0, s16b = 0, s32a = 0, s32b = 0, s64a = 0, s64b = 0;
-#pragma unroll 2
+#pragma unroll
       for (int qq = 0; qq < 4; ++qq) {  // 16 channels per step keeps this phase's register footprint small
         const uint4 a = *reinterpret_cast<const uint4*>(arow + ((qq ^ psw) << 4));
         const int o16 = (qq ^ sw16) << 4, o32 = (qq ^ sw32) << 4, o64 = (qq ^ sw64) << 4;
