@@ -35,13 +35,14 @@ typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
 namespace {
 
 // ---- LDS map (bytes) ---------------------------------------------------------------------------------------
-constexpr int A1_PITCH = 34;                      // conv1 output 32x32 + 1 halo each side, positions per row
-constexpr int A1_ROW = A1_PITCH * 16;             // bytes per row of a plane; inside a row the columns are split by parity:
-constexpr int A1_PAR = 17 * 16;                   // column x lives at (x & 1) * A1_PAR + (x >> 1) * 16, so that the stride-2
-                                                  // column runs conv2 reads (one pooled column per lane) are contiguous
-constexpr int A1_PLANE = 34 * 34 * 16;            // one 8-channel plane: 16 B per position
+// conv1 output: 32x32 + 1 halo each side = 34 x 34 positions per 8-channel plane
+constexpr int A1_ROW = 36 * 16;                   // bytes per row of a plane; inside a row the columns are split by parity: odd x
+constexpr int A1_EVEN = 19 * 16;                  // at slot x >> 1, even x at slot 19 + (x >> 1), so that the stride-2 column runs
+                                                  // conv2 reads (one pooled column per lane) are contiguous; 19 = 3 mod 8 keeps the
+                                                  // two 64-byte halves of conv1's 8-lane store groups on disjoint banks
+constexpr int A1_PLANE = 34 * A1_ROW;             // one 8-channel plane: 16 B per position
 constexpr int R1_OFF = 0;                         // R1: A1 (2 planes); later A3 u8 [256][64] + pooled [64][64]
-constexpr int R1_BYTES = 2 * A1_PLANE;            // 36992
+constexpr int R1_BYTES = 2 * A1_PLANE;            // 39168
 constexpr int A3_OFF = R1_OFF;
 constexpr int P3_OFF = R1_OFF + 16384;            // maxpool2x2(a3): [8*8][64] u8
 constexpr int A2_PITCH = 18;                      // conv2 output 16x16 + halo
@@ -54,7 +55,7 @@ constexpr int BIAS_OFF = R2_OFF + R2_BYTES;       // float b1[16] b2[32] b3[64]
 constexpr int LOGIT_OFF = BIAS_OFF + 112 * 4;     // int logits[21][2] (the 64-level pair is formed by the readers) + at [44..51] the
                                                   // four waves' partial 64-level sums
 constexpr int HEADW_OFF = LOGIT_OFF + 56 * 4;     // uint8 head weights (w+128): wh64, wh32, wh16 = 18432 B
-constexpr int LDS_BYTES = HEADW_OFF + 18432;      // 76832 -> two workgroups per CU (153.7 of 160 KiB)
+constexpr int LDS_BYTES = HEADW_OFF + 18432;      // 79008 -> two workgroups per CU (154.3 of 160 KiB)
 static_assert(33 * IN_PITCH * 4 <= R2_BYTES, "input tile must fit the A2 region");
 static_assert(HEADW_OFF % 16 == 0, "head weights are read with ds_read_b128");
 static_assert(P3_OFF + 4096 <= R1_OFF + R1_BYTES, "pooled map must fit R1");
@@ -202,7 +203,7 @@ __device__ __forceinline__ void sched_chain18()
 // first fragments of the next one, so only the first of a phase exposes the LDS latency.
 __device__ __forceinline__ const unsigned char* conv2_frag(const unsigned char* base, int f)
 {
-  return base + (f / 4) * A1_ROW + ((f % 4) & 1) * A1_PAR + ((f % 4) >> 1) * 16;
+  return base + (f / 4) * A1_ROW + (((f % 4) & 1) ? 0 : A1_EVEN) + ((f % 4) >> 1) * 16;
 }
 template <bool FIRST, bool LAST>
 __device__ __forceinline__ void conv2_half(const unsigned char* base, const unsigned char* next, const bf16x8 (&wA2)[9], bf16x8 (&ring)[RING],
@@ -341,7 +342,7 @@ __device__ __forceinline__ int a1_halo_off(int e)
   if (k0 < 34) { y = 0; x = k0; }
   else if (k0 < 68) { y = 33; x = k0 - 34; }
   else { const int k = k0 - 68; y = 1 + (k >> 1); x = (k & 1) ? 33 : 0; }
-  return R1_OFF + pl * A1_PLANE + y * A1_ROW + (x & 1) * A1_PAR + (x >> 1) * 16;
+  return R1_OFF + pl * A1_PLANE + y * A1_ROW + ((x & 1) ? 0 : A1_EVEN) + (x >> 1) * 16;
 }
 __device__ __forceinline__ int a2_halo_off(int e)
 {
@@ -510,7 +511,7 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
         const uint2 hi = *reinterpret_cast<const uint2*>(inb + (yp + 1) * (IN_PITCH * 4));
         return __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
       };
-      unsigned char* a1dst = lds + R1_OFF + h * A1_PLANE + A1_ROW + ((r + 1) & 1) * A1_PAR + ((r + 1) >> 1) * 16;  // pooled row 0, column r (halo +1)
+      unsigned char* a1dst = lds + R1_OFF + h * A1_PLANE + A1_ROW + (((r + 1) & 1) ? 0 : A1_EVEN) + ((r + 1) >> 1) * 16;  // pooled row 0, column r (halo +1)
       bf16x8 bq = frag1(wave);
 #pragma unroll 2
       for (int i = 0; i < 8; ++i) {
