@@ -288,6 +288,19 @@ __device__ __forceinline__ Prefetched prefetch_ctu(const FhevcFrames& F, bool li
   return p;
 }
 
+typedef __attribute__((ext_vector_type(2))) short s16x2;
+// two int16 samples of one dword -> two centred 8-bit samples (load_centered on both halves): max(v, 0) first, so that the
+// rounding shift may be a logical one ((0 + rnd) >> s = 0 like every negative sample), then min(255) and -128
+__device__ __forceinline__ unsigned centre_pair(unsigned w, int shift, unsigned rnd2)
+{
+  const s16x2 zero = { 0, 0 }, top = { 255, 255 }, mid = { 128, 128 };
+  s16x2 t = __builtin_elementwise_max(__builtin_bit_cast(s16x2, w), zero);
+  const u16x2 sh = { (unsigned short)shift, (unsigned short)shift };
+  t = __builtin_bit_cast(s16x2, (u16x2)((__builtin_bit_cast(u16x2, t) + __builtin_bit_cast(u16x2, rnd2)) >> sh));
+  t = __builtin_elementwise_min(t, top) - mid;
+  return __builtin_bit_cast(unsigned, t);
+}
+
 // Stage one CTU into LDS (region R2): centred 8-bit samples as bf16, two picture rows per dword, zero halo.
 // halo coordinates: hy = row + 1, hx = col + 1; dword (hy >> 1) * IN_PITCH + hx, half (hy & 1)
 __device__ __forceinline__ void stage_ctu(unsigned char* lds, const Prefetched& pre, const FhevcFrames& F, CtuPos c,
@@ -299,11 +312,12 @@ __device__ __forceinline__ void stage_ctu(unsigned char* lds, const Prefetched& 
   if (pre.fast) {
     if (F.sample_bytes == 2) {
       const unsigned wds[8] = { pre.a.x, pre.a.y, pre.a.z, pre.a.w, pre.b.x, pre.b.y, pre.b.z, pre.b.w };
+      const unsigned rnd2 = shift_in > 0 ? (0x00010001u << (shift_in - 1)) : 0u;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        short s0 = (short)(wds[j] & 0xFFFF), s1 = (short)(wds[j] >> 16);
-        dst[4 * j] = (unsigned short)(__float_as_uint((float)load_centered(&s0, shift_in)) >> 16);
-        dst[4 * j + 2] = (unsigned short)(__float_as_uint((float)load_centered(&s1, shift_in)) >> 16);
+      for (int j = 0; j < 8; ++j) {  // load_centered on both halves of a dword with packed 16-bit VALU
+        const unsigned t = centre_pair(wds[j], shift_in, rnd2);
+        dst[4 * j] = (unsigned short)(__float_as_uint((float)(short)(t & 0xFFFF)) >> 16);
+        dst[4 * j + 2] = (unsigned short)(__float_as_uint((float)((int)t >> 16)) >> 16);
       }
     } else {
       const unsigned wds[4] = { pre.a.x, pre.a.y, pre.a.z, pre.a.w };
