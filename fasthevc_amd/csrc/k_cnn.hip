@@ -520,20 +520,23 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
 #pragma unroll
         for (int i = 0; i < 8; ++i) bias1[8 + i] = bias1[i];
       }
-      auto frag1 = [=](int yp) {
-        const uint2 lo = *reinterpret_cast<const uint2*>(inb + yp * (IN_PITCH * 4));
-        const uint2 hi = *reinterpret_cast<const uint2*>(inb + (yp + 1) * (IN_PITCH * 4));
+      auto frag1 = [](const unsigned char* p) {
+        const uint2 lo = *reinterpret_cast<const uint2*>(p);
+        const uint2 hi = *reinterpret_cast<const uint2*>(p + IN_PITCH * 4);
         return __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
       };
-      unsigned char* a1dst = lds + R1_OFF + h * A1_PLANE + A1_ROW + (((r + 1) & 1) ? 0 : A1_EVEN) + ((r + 1) >> 1) * 16;  // pooled row 0, column r (halo +1)
-      bf16x8 bq = frag1(wave);
+      // this wave's units: pooled rows wave, wave + 4, ...: both addresses advance by constants (no per-unit index arithmetic)
+      const unsigned char* fp = inb + wave * (IN_PITCH * 4);
+      unsigned char* dp = lds + R1_OFF + h * A1_PLANE + (wave + 1) * A1_ROW + (((r + 1) & 1) ? 0 : A1_EVEN) + ((r + 1) >> 1) * 16;  // column r (halo +1)
+      bf16x8 bq = frag1(fp);
 #pragma unroll 2
       for (int i = 0; i < 8; ++i) {
-        const int yp = wave + 4 * i;
         const f32x16 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA1a, bq, bias1, 0, 0, 0);
         const f32x16 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA1b, bq, bias1, 0, 0, 0);
-        bq = frag1(min(yp + 4, 31));  // next unit's fragment travels during the epilogue (last one is redundant)
-        conv1_store(acc0, acc1, a1dst + yp * A1_ROW);
+        fp += 4 * IN_PITCH * 4;
+        bq = frag1(fp);  // next unit's fragment travels during the epilogue (the last one is redundant: it reads past the tile, inside R2)
+        conv1_store(acc0, acc1, dp);
+        dp += 4 * A1_ROW;
       }
     }
     __syncthreads();
