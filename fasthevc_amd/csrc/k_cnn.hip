@@ -268,7 +268,7 @@ __device__ __forceinline__ CtuPos advance(CtuPos c, const CtuPos& step, int band
 __device__ __forceinline__ Prefetched prefetch_ctu(const FhevcFrames& F, bool live, CtuPos c, int ld_row, int ld_seg)
 {
   Prefetched p;
-  p.a = make_uint4(0, 0, 0, 0); p.b = make_uint4(0, 0, 0, 0); p.fast = 0;
+  p.fast = 0;  // a, b stay undefined unless fast (stage_ctu reads them only then): no zero-fill instructions on the way
   if (!live) return p;
   const int pf = c.f, pcy = F.row_begin + c.ry, pcx = c.cx;
   const int py = pcy * 64 + ld_row, px0 = pcx * 64 + ld_seg * 16;
