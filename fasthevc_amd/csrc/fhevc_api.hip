@@ -143,10 +143,15 @@ int build_weight_image(fhevc_ctx* c, const BlobView& b)
     }
   }
   std::vector<float> bias(112);
-  for (int i = 0; i < 16; ++i) bias[i] = (float)rd32(b.b1, i);
+  for (int i = 0; i < 16; ++i) {  // the kernel feeds conv1 the samples x, not x - 128: sum w (x - 128) + b = sum w x + (b - 128 sum w)
+    int sw = 0;
+    for (int t = 0; t < 9; ++t) sw += b.w1[i * 9 + t];
+    if (std::abs(rd32(b.b1, i)) > 4194304) return fail(c, FHEVC_E_WEIGHTS, "|bias| > 2^22");
+    bias[i] = (float)(rd32(b.b1, i) - 128 * sw);  // |.| < 2^22 + 128 * 9 * 127 < 2^23: exact, and conv1's sums stay below 2^24
+  }
   for (int i = 0; i < 32; ++i) bias[16 + i] = (float)rd32(b.b2, i);
   for (int i = 0; i < 64; ++i) bias[48 + i] = (float)rd32(b.b3, i);
-  for (float v : bias) if (std::fabs(v) > 4194304.0f) return fail(c, FHEVC_E_WEIGHTS, "|bias| > 2^22");
+  for (int i = 16; i < 112; ++i) if (std::fabs(bias[i]) > 4194304.0f) return fail(c, FHEVC_E_WEIGHTS, "|bias| > 2^22");
   std::vector<uint8_t> whead(4 * 4096 + 2 * 1024);
   for (int i = 0; i < 8192; ++i) whead[i] = (uint8_t)((int)b.wh64[i] + 128);
   for (int i = 0; i < 8192; ++i) whead[8192 + i] = (uint8_t)((int)b.wh32[i] + 128);

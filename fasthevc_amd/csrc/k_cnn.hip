@@ -103,13 +103,15 @@ __device__ __forceinline__ f32x16 bias_tile(const float* b32, int h)
   return acc;
 }
 
+// one sample as the network sees it: rounded to 8 bits, clamped to 0..255.  The oracle centres it (x - 128); here the LDS
+// image keeps x itself and conv1's bias carries -128 * (sum of the filter's weights) (fhevc_api.hip), which is the same
+// integer arithmetic: the halo and everything outside the picture hold 128
 template <typename T>
-__device__ __forceinline__ int load_centered(const T* p, int shift)
+__device__ __forceinline__ int load_sample8(const T* p, int shift)
 {
   int v = (int)*p;
   if (shift > 0) v = min(255, (v + (1 << (shift - 1))) >> shift);
-  v = min(255, max(0, v));
-  return v - 128;
+  return min(255, max(0, v));
 }
 
 // ---- fused epilogues (forceinline: everything stays in registers) ------------------------------------------
@@ -289,19 +291,19 @@ __device__ __forceinline__ Prefetched prefetch_ctu(const FhevcFrames& F, bool li
 }
 
 typedef __attribute__((ext_vector_type(2))) short s16x2;
-// two int16 samples of one dword -> two centred 8-bit samples (load_centered on both halves): max(v, 0) first, so that the
-// rounding shift may be a logical one ((0 + rnd) >> s = 0 like every negative sample), then min(255) and -128
-__device__ __forceinline__ unsigned centre_pair(unsigned w, int shift, unsigned rnd2)
+// two int16 samples of one dword -> two 8-bit samples (load_sample8 on both halves): max(v, 0) first, so that the
+// rounding shift may be a logical one ((0 + rnd) >> s = 0 like every negative sample), then min(255)
+__device__ __forceinline__ unsigned sample8_pair(unsigned w, int shift, unsigned rnd2)
 {
-  const s16x2 zero = { 0, 0 }, top = { 255, 255 }, mid = { 128, 128 };
+  const s16x2 zero = { 0, 0 }, top = { 255, 255 };
   s16x2 t = __builtin_elementwise_max(__builtin_bit_cast(s16x2, w), zero);
   const u16x2 sh = { (unsigned short)shift, (unsigned short)shift };
   t = __builtin_bit_cast(s16x2, (u16x2)((__builtin_bit_cast(u16x2, t) + __builtin_bit_cast(u16x2, rnd2)) >> sh));
-  t = __builtin_elementwise_min(t, top) - mid;
+  t = __builtin_elementwise_min(t, top);
   return __builtin_bit_cast(unsigned, t);
 }
 
-// Stage one CTU into LDS (region R2): centred 8-bit samples as bf16, two picture rows per dword, zero halo.
+// Stage one CTU into LDS (region R2): 8-bit samples as bf16, two picture rows per dword, halo = 128 (the centre).
 // halo coordinates: hy = row + 1, hx = col + 1; dword (hy >> 1) * IN_PITCH + hx, half (hy & 1)
 __device__ __forceinline__ void stage_ctu(unsigned char* lds, const Prefetched& pre, const FhevcFrames& F, CtuPos c,
                                           int tid, int ld_row, int ld_seg, int shift_in, unsigned in_cells)
@@ -314,16 +316,16 @@ __device__ __forceinline__ void stage_ctu(unsigned char* lds, const Prefetched& 
       const unsigned wds[8] = { pre.a.x, pre.a.y, pre.a.z, pre.a.w, pre.b.x, pre.b.y, pre.b.z, pre.b.w };
       const unsigned rnd2 = shift_in > 0 ? (0x00010001u << (shift_in - 1)) : 0u;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {  // load_centered on both halves of a dword with packed 16-bit VALU
-        const unsigned t = centre_pair(wds[j], shift_in, rnd2);
-        dst[4 * j] = (unsigned short)(__float_as_uint((float)(short)(t & 0xFFFF)) >> 16);
-        dst[4 * j + 2] = (unsigned short)(__float_as_uint((float)((int)t >> 16)) >> 16);
+      for (int j = 0; j < 8; ++j) {  // load_sample8 on both halves of a dword with packed 16-bit VALU, v_cvt_f32_ubyte0/2
+        const unsigned t = sample8_pair(wds[j], shift_in, rnd2);
+        dst[4 * j] = (unsigned short)(__float_as_uint((float)(t & 0xFF)) >> 16);
+        dst[4 * j + 2] = (unsigned short)(__float_as_uint((float)((t >> 16) & 0xFF)) >> 16);
       }
     } else {
       const unsigned wds[4] = { pre.a.x, pre.a.y, pre.a.z, pre.a.w };
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        const int v = (int)((wds[j >> 2] >> (8 * (j & 3))) & 0xFF) - 128;
+        const unsigned v = (wds[j >> 2] >> (8 * (j & 3))) & 0xFF;
         dst[2 * j] = (unsigned short)(__float_as_uint((float)v) >> 16);
       }
     }
@@ -334,17 +336,17 @@ __device__ __forceinline__ void stage_ctu(unsigned char* lds, const Prefetched& 
     const bool row_ok = py < F.height;
 #pragma unroll 4
     for (int j = 0; j < 16; ++j) {
-      int v = 0;
+      int v = 128;
       if (row_ok && px0 + j < F.width) {
-        if (F.sample_bytes == 2) v = load_centered(reinterpret_cast<const int16_t*>(F.luma) + base + j, shift_in);
-        else v = (int)reinterpret_cast<const uint8_t*>(F.luma)[base + j] - 128;
+        if (F.sample_bytes == 2) v = load_sample8(reinterpret_cast<const int16_t*>(F.luma) + base + j, shift_in);
+        else v = (int)reinterpret_cast<const uint8_t*>(F.luma)[base + j];
       }
       dst[2 * j] = (unsigned short)(__float_as_uint((float)v) >> 16);
     }
   }
-  // input halo: 66*66 - 64*64 = 260 two-byte cells
-  *reinterpret_cast<unsigned short*>(lds + (in_cells & 0xFFFF)) = 0;
-  if (tid < 260 - 256) *reinterpret_cast<unsigned short*>(lds + (in_cells >> 16)) = 0;
+  // input halo: 66*66 - 64*64 = 260 two-byte cells of bf16(128)
+  *reinterpret_cast<unsigned short*>(lds + (in_cells & 0xFFFF)) = 0x4300;
+  if (tid < 260 - 256) *reinterpret_cast<unsigned short*>(lds + (in_cells >> 16)) = 0x4300;
 }
 // LDS byte offsets of the halo cells a thread zeroes (computed once per kernel: the index arithmetic with its three-way
 // divergence cost ~700 cycles per CTU when it ran inside the phases).  Cell e of: the conv1 output halo (264 x 16 B),
@@ -694,12 +696,15 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
       const int2 l64 = make_int2(hb64a + pa.x + pa.z + pb.x + pb.z, hb64b + pa.y + pa.w + pb.y + pb.w);
       const int2 l32 = *reinterpret_cast<const int2*>(logitL + 2 * (1 + (uy >> 3) * 2 + (ux >> 3)));
       const int2 l16 = *reinterpret_cast<const int2*>(logitL + 2 * (5 + (uy >> 2) * 4 + (ux >> 2)));
-      const bool inside = (ux * 4 < vw) && (uy * 4 < vh);
       // soft decisions: d_depth follows the splits surer than +margin_split, d_depth_max those not rejected by more
       // than -margin_stop (both 0: the plain map in both); CUs crossing the picture edge are split either way
-      const bool e64 = (vw < 64) || (vh < 64);
-      const bool e32 = ((ux >> 3) * 32 + 32 > vw) || ((uy >> 3) * 32 + 32 > vh);
-      const bool e16 = ((ux >> 2) * 16 + 16 > vw) || ((uy >> 2) * 16 + 16 > vh);
+      const bool e64 = (vw < 64) || (vh < 64);  // uniform: the per-unit edge tests run for CTUs on the picture edge only
+      bool inside = true, e32 = false, e16 = false;
+      if (e64) {
+        inside = (ux * 4 < vw) && (uy * 4 < vh);
+        e32 = ((ux >> 3) * 32 + 32 > vw) || ((uy >> 3) * 32 + 32 > vh);
+        e16 = ((ux >> 2) * 16 + 16 > vw) || ((uy >> 2) * 16 + 16 > vh);
+      }
       const int d64 = l64.y - l64.x, d32 = l32.y - l32.x, d16 = l16.y - l16.x;
       const long long o = (long long)(f * band_rows + (cy - F.row_begin)) * F.ctus_x + cx;
       {
