@@ -152,11 +152,21 @@ int build_weight_image(fhevc_ctx* c, const BlobView& b)
   for (int i = 0; i < 32; ++i) bias[16 + i] = (float)rd32(b.b2, i);
   for (int i = 0; i < 64; ++i) bias[48 + i] = (float)rd32(b.b3, i);
   for (int i = 16; i < 112; ++i) if (std::fabs(bias[i]) > 4194304.0f) return fail(c, FHEVC_E_WEIGHTS, "|bias| > 2^22");
+  // FC heads on v_dot4_i32_i8: conv3's output is kept as a - 128 (signed bytes), so sum w a = sum w (a - 128) + 128 sum w and
+  // the second term moves into the head biases (the 64-level weights act on the 2x2 sum pool: four positions each)
   std::vector<uint8_t> whead(4 * 4096 + 2 * 1024);
-  for (int i = 0; i < 8192; ++i) whead[i] = (uint8_t)((int)b.wh64[i] + 128);
-  for (int i = 0; i < 8192; ++i) whead[8192 + i] = (uint8_t)((int)b.wh32[i] + 128);
-  for (int i = 0; i < 2048; ++i) whead[16384 + i] = (uint8_t)((int)b.wh16[i] + 128);
+  for (int i = 0; i < 8192; ++i) whead[i] = (uint8_t)b.wh64[i];
+  for (int i = 0; i < 8192; ++i) whead[8192 + i] = (uint8_t)b.wh32[i];
+  for (int i = 0; i < 2048; ++i) whead[16384 + i] = (uint8_t)b.wh16[i];
   int32_t bhead[6 + 3 * 52] = { rd32(b.bh64, 0), rd32(b.bh64, 1), rd32(b.bh32, 0), rd32(b.bh32, 1), rd32(b.bh16, 0), rd32(b.bh16, 1) };
+  for (int cls = 0; cls < 2; ++cls) {
+    int s64 = 0, s32 = 0, s16 = 0;
+    for (int i = 0; i < 4096; ++i) { s64 += b.wh64[cls * 4096 + i]; s32 += b.wh32[cls * 4096 + i]; }
+    for (int i = 0; i < 1024; ++i) s16 += b.wh16[cls * 1024 + i];
+    bhead[0 + cls] += 128 * 4 * s64;
+    bhead[2 + cls] += 128 * s32;
+    bhead[4 + cls] += 128 * s16;
+  }
   for (int i = 0; i < 3 * 52; ++i) bhead[6 + i] = rd32(b.qp_bias, i);
 
   if (!c->d_frag) {

@@ -10,7 +10,7 @@
 //   frag  : MFMA A-operand fragments, one uint4 (8 bf16) per lane: conv1 [2][64], conv2 [9][64], conv3 [2][18][64], all scaled
 //           by their layer's 2^-shift
 //   bias  : float b1[16], b2[32], b3[64]
-//   whead : uint8 (w + 128): wh64[2][4096], wh32[2][4096], wh16[2][1024]
+//   whead : int8: wh64[2][4096], wh32[2][4096], wh16[2][1024]
 //   bhead : int32 bh64[2], bh32[2], bh16[2], qp_bias[3][52]
 #define FHEVC_FRAG_CONV1 0
 #define FHEVC_FRAG_CONV2 128

@@ -54,13 +54,13 @@ constexpr int IN_PITCH = 68;                      // dwords per input row PAIR (
 constexpr int BIAS_OFF = R2_OFF + R2_BYTES;       // float b1[16] b2[32] b3[64]
 constexpr int LOGIT_OFF = BIAS_OFF + 112 * 4;     // int logits[21][2] (the 64-level pair is formed by the readers) + at [44..51] the
                                                   // four waves' partial 64-level sums
-constexpr int HEADW_OFF = LOGIT_OFF + 56 * 4;     // uint8 head weights (w+128): wh64, wh32, wh16 = 18432 B
+constexpr int HEADW_OFF = LOGIT_OFF + 56 * 4;     // int8 head weights: wh64, wh32, wh16 = 18432 B
 constexpr int LDS_BYTES = HEADW_OFF + 18432;      // 79008 -> two workgroups per CU (154.3 of 160 KiB)
 static_assert(33 * IN_PITCH * 4 <= R2_BYTES, "input tile must fit the A2 region");
 static_assert(HEADW_OFF % 16 == 0, "head weights are read with ds_read_b128");
 static_assert(P3_OFF + 4096 <= R1_OFF + R1_BYTES, "pooled map must fit R1");
 
-constexpr int HEAD64_OFF = 0, HEAD32_OFF = 2 * 4096, HEAD16_OFF = 4 * 4096;  // into whead (uint8, w+128)
+constexpr int HEAD64_OFF = 0, HEAD32_OFF = 2 * 4096, HEAD16_OFF = 4 * 4096;  // into whead (int8)
 
 // max(v, value of the horizontally adjacent lane): with old = 0 and bound_ctrl the DPP move folds into ONE
 // v_max_f32_dpp quad_perm:[1,0,3,2] (the (v, v, bound_ctrl = 0) form costs v_mov + v_mov_dpp + v_max)
@@ -86,9 +86,9 @@ __device__ __forceinline__ unsigned bytemax(unsigned a, unsigned b)
   unsigned hi = __builtin_bit_cast(unsigned, __builtin_elementwise_max(ah, bh));
   return lo | (hi << 8);
 }
-__device__ __forceinline__ unsigned udot4(unsigned a, unsigned b, unsigned c)
+__device__ __forceinline__ int sdot4(unsigned a, unsigned b, int c)  // v_dot4_i32_i8: four signed 8-bit products
 {
-  return __builtin_amdgcn_udot4(a, b, c, false);
+  return __builtin_amdgcn_sdot4((int)a, (int)b, c, false);
 }
 // init the 16 accumulator rows of a 32-channel tile from the bias table in LDS: reg i -> channel
 // (i&3) + 8*(i>>2) + 4*h (C/D layout of v_mfma_f32_32x32x16_bf16)
@@ -178,7 +178,8 @@ __device__ __forceinline__ void conv3_store(const f32x16& acc, unsigned char* ds
     unsigned d = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) d = __builtin_amdgcn_cvt_pk_u8_f32(acc[4 * g + k], k, d);
-    *reinterpret_cast<unsigned*>(dst + (((2 * tile + (g >> 1)) ^ psw) << 4) + 8 * (g & 1)) = d;
+    // stored as a - 128 (signed bytes) for the heads' v_dot4_i32_i8; their biases carry + 128 * sum of weights (fhevc_api.hip)
+    *reinterpret_cast<unsigned*>(dst + (((2 * tile + (g >> 1)) ^ psw) << 4) + 8 * (g & 1)) = d ^ 0x80808080u;
   }
 }
 
@@ -622,7 +623,7 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
     __syncthreads();
     FHEVC_STAMP(3)
 
-    // ================= P4: FC heads on v_dot4_u32_u8 (weights stored as w+128, resident in LDS) =================
+    // ================= P4: FC heads on v_dot4_i32_i8 (int8 weights resident in LDS, activations a - 128) =================
     {  // conv1's fragments for the next CTU: issued first so that they have landed before the depth phase, whose spill
        // reloads wait for vmcnt(0)
       const uint4* fp = frag1p;
@@ -642,7 +643,7 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
       const unsigned char* w32 = lds + HEADW_OFF + HEAD32_OFF + ((y & 7) * 8 + (x & 7)) * 64;
       const unsigned char* w64 = lds + HEADW_OFF + HEAD64_OFF + ((y >> 1) * 8 + (x >> 1)) * 64;  // 2x2 sum pool
       const int sw16 = y & 3, sw32 = y & 3, sw64 = (y >> 1) & 3;  // (row >> 2) & 3, (row >> 3) & 3 of the weight rows (both classes)
-      unsigned sa = 0, s16a = 0, s16b = 0, s32a = 0, s32b = 0, s64a = 0, s64b = 0;
+      int s16a = 0, s16b = 0, s32a = 0, s32b = 0, s64a = 0, s64b = 0;
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) {  // 16 channels per step keeps this phase's register footprint small
         const uint4 a = *reinterpret_cast<const uint4*>(arow + ((qq ^ psw) << 4));
@@ -650,19 +651,17 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
         const uint4 b0 = *reinterpret_cast<const uint4*>(w16 + o16), b1 = *reinterpret_cast<const uint4*>(w16 + 1024 + o16);
         const uint4 c0 = *reinterpret_cast<const uint4*>(w32 + o32), c1 = *reinterpret_cast<const uint4*>(w32 + 4096 + o32);
         const uint4 d0 = *reinterpret_cast<const uint4*>(w64 + o64), d1 = *reinterpret_cast<const uint4*>(w64 + 4096 + o64);
-        sa = udot4(a.x, 0x01010101u, sa); sa = udot4(a.y, 0x01010101u, sa); sa = udot4(a.z, 0x01010101u, sa); sa = udot4(a.w, 0x01010101u, sa);
-        s16a = udot4(a.x, b0.x, s16a); s16a = udot4(a.y, b0.y, s16a); s16a = udot4(a.z, b0.z, s16a); s16a = udot4(a.w, b0.w, s16a);
-        s16b = udot4(a.x, b1.x, s16b); s16b = udot4(a.y, b1.y, s16b); s16b = udot4(a.z, b1.z, s16b); s16b = udot4(a.w, b1.w, s16b);
-        s32a = udot4(a.x, c0.x, s32a); s32a = udot4(a.y, c0.y, s32a); s32a = udot4(a.z, c0.z, s32a); s32a = udot4(a.w, c0.w, s32a);
-        s32b = udot4(a.x, c1.x, s32b); s32b = udot4(a.y, c1.y, s32b); s32b = udot4(a.z, c1.z, s32b); s32b = udot4(a.w, c1.w, s32b);
-        s64a = udot4(a.x, d0.x, s64a); s64a = udot4(a.y, d0.y, s64a); s64a = udot4(a.z, d0.z, s64a); s64a = udot4(a.w, d0.w, s64a);
-        s64b = udot4(a.x, d1.x, s64b); s64b = udot4(a.y, d1.y, s64b); s64b = udot4(a.z, d1.z, s64b); s64b = udot4(a.w, d1.w, s64b);
+        s16a = sdot4(a.x, b0.x, s16a); s16a = sdot4(a.y, b0.y, s16a); s16a = sdot4(a.z, b0.z, s16a); s16a = sdot4(a.w, b0.w, s16a);
+        s16b = sdot4(a.x, b1.x, s16b); s16b = sdot4(a.y, b1.y, s16b); s16b = sdot4(a.z, b1.z, s16b); s16b = sdot4(a.w, b1.w, s16b);
+        s32a = sdot4(a.x, c0.x, s32a); s32a = sdot4(a.y, c0.y, s32a); s32a = sdot4(a.z, c0.z, s32a); s32a = sdot4(a.w, c0.w, s32a);
+        s32b = sdot4(a.x, c1.x, s32b); s32b = sdot4(a.y, c1.y, s32b); s32b = sdot4(a.z, c1.z, s32b); s32b = sdot4(a.w, c1.w, s32b);
+        s64a = sdot4(a.x, d0.x, s64a); s64a = sdot4(a.y, d0.y, s64a); s64a = sdot4(a.z, d0.z, s64a); s64a = sdot4(a.w, d0.w, s64a);
+        s64b = sdot4(a.x, d1.x, s64b); s64b = sdot4(a.y, d1.y, s64b); s64b = sdot4(a.z, d1.z, s64b); s64b = sdot4(a.w, d1.w, s64b);
       }
       // reductions: DPP inside the 16-lane row (= one 16x16 block), v_readlane across the four rows of the wave
-      const int corr = 128 * (int)sa;
-      const int r16a = dpp_row_sum((int)s16a - corr), r16b = dpp_row_sum((int)s16b - corr);
-      const int r32a = dpp_row_sum((int)s32a - corr), r32b = dpp_row_sum((int)s32b - corr);
-      const int r64a = dpp_row_sum((int)s64a - corr), r64b = dpp_row_sum((int)s64b - corr);
+      const int r16a = dpp_row_sum(s16a), r16b = dpp_row_sum(s16b);
+      const int r32a = dpp_row_sum(s32a), r32b = dpp_row_sum(s32b);
+      const int r64a = dpp_row_sum(s64a), r64b = dpp_row_sum(s64b);
       if ((lane & 15) == 0) {  // one owner per 16x16 block: no atomics
         const int bi = ((q >> 1) * 2 + (blk >> 1)) * 4 + (q & 1) * 2 + (blk & 1);
         *reinterpret_cast<int2*>(logitL + (5 + bi) * 2) = make_int2(r16a + hb16a, r16b + hb16b);  // plain stores: nothing to read back
