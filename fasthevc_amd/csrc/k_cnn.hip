@@ -749,22 +749,29 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
 #undef FHEVC_STAMP
 }
 
-// split-flag words -> depth maps (whole pictures, CTU raster order): one thread per 4x4 unit, 256 B per CTU written
+// split-flag words -> depth maps (whole pictures, CTU raster order): one thread per row of 16 units = one 16-byte store,
+// 16 threads per CTU, 16 CTUs per workgroup and sweep (HBM-write-bound: 256 B per CTU)
 __global__ __launch_bounds__(256) void fhevc_expand_flags_kernel(FhevcFrames F, const uint32_t* __restrict__ flags,
                                                                   uint8_t* __restrict__ depth)
 {
-  const int per_frame = F.ctus_x * F.ctus_y, total = per_frame * F.num_frames;
-  const int tid = threadIdx.x, ux = tid & 15, uy = tid >> 4;
-  for (int c = blockIdx.x; c < total; c += gridDim.x) {
-    const int rem = c % per_frame, cy = rem / F.ctus_x, cx = rem % F.ctus_x;
+  const int per_frame = F.ctus_x * F.ctus_y;
+  const long long total = (long long)per_frame * F.num_frames;
+  const int tid = threadIdx.x, uy = tid & 15, sub = tid >> 4;
+  for (long long c = (long long)blockIdx.x * 16 + sub; c < total; c += (long long)gridDim.x * 16) {
+    const int rem = (int)(c % per_frame), cy = rem / F.ctus_x, cx = rem - cy * F.ctus_x;
     const int vw = min(64, F.width - cx * 64), vh = min(64, F.height - cy * 64);
     const uint32_t w = flags[c];
-    int d = 0;
-    if (ux * 4 < vw && uy * 4 < vh && (w & 1u)) {
-      const int q = (uy >> 3) * 2 + (ux >> 3), bi = (uy >> 2) * 4 + (ux >> 2);
-      d = ((w >> (1 + q)) & 1u) ? (((w >> (5 + bi)) & 1u) ? 3 : 2) : 1;
+    uint32_t out[4] = { 0, 0, 0, 0 };
+    if (uy * 4 < vh && (w & 1u)) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {  // the four units of a 16x16 block share their depth; the picture edge may cut the group
+        const int q = (uy >> 3) * 2 + (j >> 1), bi = (uy >> 2) * 4 + j;
+        const uint32_t d = ((w >> (1 + q)) & 1u) ? (((w >> (5 + bi)) & 1u) ? 3u : 2u) : 1u;
+        const int nvalid = min(4, max(0, (vw >> 2) - 4 * j));
+        out[j] = (d * 0x01010101u) & (nvalid >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nvalid)) - 1u));
+      }
     }
-    depth[(long long)c * 256 + tid] = (uint8_t)d;
+    *reinterpret_cast<uint4*>(depth + c * 256 + uy * 16) = make_uint4(out[0], out[1], out[2], out[3]);
   }
 }
 
@@ -774,7 +781,8 @@ hipError_t fhevc_launch_expand_flags(const FhevcFrames& fr, const uint32_t* d_fl
 {
   const long long total = (long long)fr.ctus_x * fr.ctus_y * fr.num_frames;
   if (total <= 0) return hipSuccess;
-  const int grid = (int)(total < 8192 ? total : 8192);
+  const long long groups = (total + 15) / 16;
+  const int grid = (int)(groups < 8192 ? groups : 8192);
   hipLaunchKernelGGL(fhevc_expand_flags_kernel, dim3(grid), dim3(256), 0, stream, fr, d_flags, d_depth);
   return hipGetLastError();
 }
