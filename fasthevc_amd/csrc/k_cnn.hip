@@ -498,6 +498,21 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
   }
   __syncthreads();
   FHEVC_STAMP(0)
+  // conv1's first LDS reads (bias half-tile, first fragment) are issued one phase early, before the depth phase of the
+  // previous CTU: that phase and conv1's start are both latency-bound, their LDS round trips now overlap
+  float4 early_b0, early_b1;
+  bf16x8 early_bq;
+#define FHEVC_CONV1_EARLY_READS                                                                          \
+  {                                                                                                      \
+    FHEVC_PHASE_IDS                                                                                      \
+    early_b0 = *reinterpret_cast<const float4*>(biasL + 8 * h);                                          \
+    early_b1 = *reinterpret_cast<const float4*>(biasL + 8 * h + 4);                                      \
+    const unsigned char* p = lds + R2_OFF + (2 * r + 2 * h) * 4 + wave * (IN_PITCH * 4);                 \
+    const uint2 lo = *reinterpret_cast<const uint2*>(p);                                                 \
+    const uint2 hi = *reinterpret_cast<const uint2*>(p + IN_PITCH * 4);                                  \
+    early_bq = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));                           \
+  }
+  FHEVC_CONV1_EARLY_READS
 
   // Per CTU: P1 conv1 | P2 conv2 | P3 conv3 (next CTU's samples are requested) | P4 heads + next CTU staged into LDS |
   // P5 depth map + conv1 halo re-zeroed -- four barriers; P5 runs into the next P1 without one (disjoint LDS).
@@ -516,8 +531,7 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
       const unsigned char* inb = lds + R2_OFF + (2 * r + 2 * h) * 4;
       f32x16 bias1;  // reg i -> channel (i&3) + 4*((i>>2)&1) + 8h, the same for both pre-pool rows and both MFMAs
       {
-        const float4 b0 = *reinterpret_cast<const float4*>(biasL + 8 * h);
-        const float4 b1 = *reinterpret_cast<const float4*>(biasL + 8 * h + 4);
+        const float4 b0 = early_b0, b1 = early_b1;  // read from LDS before the previous CTU's depth phase (or by the prologue)
         bias1[0] = b0.x; bias1[1] = b0.y; bias1[2] = b0.z; bias1[3] = b0.w;
         bias1[4] = b1.x; bias1[5] = b1.y; bias1[6] = b1.z; bias1[7] = b1.w;
 #pragma unroll
@@ -531,7 +545,7 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
       // this wave's units: pooled rows wave, wave + 4, ...: both addresses advance by constants (no per-unit index arithmetic)
       const unsigned char* fp = inb + wave * (IN_PITCH * 4);
       unsigned char* dp = lds + R1_OFF + h * A1_PLANE + (wave + 1) * A1_ROW + (((r + 1) & 1) ? 0 : A1_EVEN) + ((r + 1) >> 1) * 16;  // column r (halo +1)
-      bf16x8 bq = frag1(fp);
+      bf16x8 bq = early_bq;  // = frag1(fp), in flight since before the previous CTU's depth phase
 #pragma unroll 2
       for (int i = 0; i < 8; ++i) {
         const f32x16 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA1a, bq, bias1, 0, 0, 0);
@@ -685,6 +699,7 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
     FHEVC_STAMP(7)  // staging of the next CTU; slot 4 below is then the wait at the barrier
     __syncthreads();
     FHEVC_STAMP(4)
+    FHEVC_CONV1_EARLY_READS  // the next CTU's tile is staged (harmless reads if there is none)
 
     // ================= P5: top-down depth map (forced split at the picture edge), branch-free =================
     {
@@ -747,6 +762,7 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
     for (int k = 0; k < 8; ++k) d_stamps[blockIdx.x * 8 + k] = tsum[k];
   }
 #undef FHEVC_STAMP
+#undef FHEVC_CONV1_EARLY_READS
 }
 
 // split-flag words -> depth maps (whole pictures, CTU raster order): one thread per row of 16 units = one 16-byte store,
