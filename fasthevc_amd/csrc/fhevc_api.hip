@@ -134,13 +134,18 @@ int build_weight_image(fhevc_ctx* c, const BlobView& b)
       }
       // conv2: K-step s = tap, k = input channel
       for (int s = 0; s < 9; ++s) put_scaled(1, FHEVC_FRAG_CONV2 + s * 64, lane, j, b.w2[((r * 16 + k) * 9) + s]);
-      // conv3: tile t = 32 output channels; K-step s: tap = s>>1, input channel = 16*(s&1) + k
+    }
+  }
+  // conv3 runs on v_mfma_f32_16x16x32_bf16: lane (m = lane & 15, kg = lane >> 4) holds A[m][8 kg + j]; tile t = the wave's 32
+  // output channels, fragment s = 9 mt + tap: M tile mt (16 channels), K = the tap's 32 input channels
+  for (int lane = 0; lane < 64; ++lane) {
+    const int m = lane & 15, kg = lane >> 4;
+    for (int j = 0; j < 8; ++j)
       for (int t = 0; t < 2; ++t)
         for (int s = 0; s < 18; ++s) {
-          const int oc = 32 * t + r, ic = 16 * (s & 1) + k, tap = s >> 1;
+          const int oc = 32 * t + 16 * (s / 9) + m, ic = 8 * kg + j, tap = s % 9;
           put_scaled(2, FHEVC_FRAG_CONV3 + (t * 18 + s) * 64, lane, j, b.w3[(oc * 32 + ic) * 9 + tap]);
         }
-    }
   }
   std::vector<float> bias(112);
   for (int i = 0; i < 16; ++i) {  // the kernel feeds conv1 the samples x, not x - 128: sum w (x - 128) + b = sum w x + (b - 128 sum w)

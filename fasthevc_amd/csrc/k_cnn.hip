@@ -46,8 +46,9 @@ constexpr int R1_BYTES = 2 * A1_PLANE;            // 39168
 constexpr int A3_OFF = R1_OFF;
 constexpr int P3_OFF = R1_OFF + 16384;            // maxpool2x2(a3): [8*8][64] u8
 constexpr int A2_PITCH = 18;                      // conv2 output 16x16 + halo
-constexpr int A2_PLANE = 18 * 18 * 16 + 96;       // 5280: planes start 32 B apart modulo 128 B, so the paired 8-byte
-                                                  // stores of conv2 (even lane -> plane g, odd lane -> plane g+2) never share a bank
+constexpr int A2_PLANE = 18 * 18 * 16 + 192;      // 5376 = 21 * 256: conv3's B operand takes lane group kg of a ds_read_b128 from plane kg,
+                                                  // and {positions 0-3, 12-15 of plane 0} + {4-11 of plane 1} only tile a 256-byte bank row
+                                                  // when the planes are a multiple of 256 B apart
 constexpr int R2_OFF = R1_OFF + R1_BYTES;         // R2: input CTU bf16 [66][68]; later A2 (4 planes)
 constexpr int R2_BYTES = 4 * A2_PLANE;            // 20736
 constexpr int IN_PITCH = 68;                      // dwords per input row PAIR (66 used): lo = row 2j, hi = row 2j+1
@@ -165,22 +166,27 @@ __device__ __forceinline__ void conv2_requant_store(const f32x16& m, unsigned ch
     *reinterpret_cast<uint2*>(dst + g * A2_PLANE) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
   }
 }
-// conv3: requant to u8, 16 channels of this lane half for one position.  The kernel runs with MODE.fp_round = toward
-// -inf (set once at its top), under which v_cvt_pk_u8_f32 rounds DOWN and saturates to 0..255 (verified on hardware:
-// tools/probes/probe_cvt_mode): one instruction = floor + ReLU + clamp + pack.  conv3's weights carry 2^-s and the
-// accumulators start from the pre-scaled bias tile, so they already hold (acc + b) * 2^-s exactly.
-// dst = start of the position's 64-byte row + 4*h; channel 32*tile + 8*g + 4*h + k lives in logical 16-B chunk
-// 2*tile + (g >> 1), at byte 8*(g & 1) + 4*h + k; psw = chunk swizzle of this position
-__device__ __forceinline__ void conv3_store(const f32x16& acc, unsigned char* dst, int tile, int psw)
+// conv3 on v_mfma_f32_16x16x32_bf16 (the shape that holds the higher clock under the power limit): a K step is ONE tap x all 32
+// input channels (lane group kg = lane >> 4 reads activation plane kg), N = the 16 positions of one output row, M = 16 output
+// channels; a wave owns two M tiles (its 32 channels) and 8 rows.  D layout: lane (x = lane & 15, rg = lane >> 4), reg i ->
+// channel 16 mt + 4 rg + i at position x.
+// Requant: the kernel runs with MODE.fp_round = toward -inf (set once at its top), under which v_cvt_pk_u8_f32 rounds DOWN and
+// saturates to 0..255 (verified on hardware: tools/probes/probe_cvt_mode): one instruction = floor + ReLU + clamp + pack.  The
+// weights carry 2^-s and the accumulators start from the pre-scaled bias, so they already hold (acc + b) * 2^-s exactly.
+// dst = the position's 64-byte row + 4 rg; channel 32 tile + 16 mt + 4 rg + i lives in logical 16-B chunk 2 tile + mt, byte
+// 4 rg + i; psw = chunk swizzle of this position
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+__device__ __forceinline__ void conv3_store(const f32x4& acc0, const f32x4& acc1, unsigned char* dst, int tile, int psw)
 {
+  unsigned d0 = 0, d1 = 0;
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    unsigned d = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) d = __builtin_amdgcn_cvt_pk_u8_f32(acc[4 * g + k], k, d);
-    // stored as a - 128 (signed bytes) for the heads' v_dot4_i32_i8; their biases carry + 128 * sum of weights (fhevc_api.hip)
-    *reinterpret_cast<unsigned*>(dst + (((2 * tile + (g >> 1)) ^ psw) << 4) + 8 * (g & 1)) = d ^ 0x80808080u;
+  for (int k = 0; k < 4; ++k) {
+    d0 = __builtin_amdgcn_cvt_pk_u8_f32(acc0[k], k, d0);
+    d1 = __builtin_amdgcn_cvt_pk_u8_f32(acc1[k], k, d1);
   }
+  // stored as a - 128 (signed bytes) for the heads' v_dot4_i32_i8; their biases carry + 128 * sum of weights (fhevc_api.hip)
+  *reinterpret_cast<unsigned*>(dst + (((2 * tile + 0) ^ psw) << 4)) = d0 ^ 0x80808080u;
+  *reinterpret_cast<unsigned*>(dst + (((2 * tile + 1) ^ psw) << 4)) = d1 ^ 0x80808080u;
 }
 
 // ---- MFMA chains with a register ring of B fragments ---------------------------------------------------------
@@ -228,33 +234,41 @@ __device__ __forceinline__ void conv2_half(const unsigned char* base, const unsi
     else if (!LAST) ring[f % RING] = lds_frag(conv2_frag(next, f + RING - 12));
   }
 }
-// conv3 MFMA chain of one unit = 32 output channels x 32 positions (rows 2yp, 2yp+1), K = 9 taps x 32 channels;
-// the ring runs across units as in conv2 (18 % RING == 2: PHASE = ring slot of this unit's fragment 0)
-__device__ __forceinline__ const unsigned char* conv3_frag(const unsigned char* base, int s)
+// conv3 MFMA chain of one output row: 9 fragments (taps), 18 MFMAs (two M tiles per fragment).  Rows k = 0..7 of a wave are
+// y = y0 + 4 * (k >> 1) + (k & 1); fragment g = 9 k + tap of the phase lives at a compile-time offset from the lane's base
+// pointer, and the 4-deep ring runs across the rows.
+__device__ __forceinline__ constexpr int conv3_frag_off(int g)
 {
-  return base + 2 * (s & 1) * A2_PLANE + (((s >> 1) / 3) * A2_PITCH + ((s >> 1) % 3)) * 16;
+  const int k = g / 9, t = g % 9;
+  return ((4 * (k >> 1) + (k & 1) + t / 3) * A2_PITCH + t % 3) * 16;
 }
-template <bool FIRST, bool LAST, int PHASE>
-__device__ __forceinline__ f32x16 conv3_unit(const unsigned char* a2, int yp, int yp_next, const bf16x8 (&wA3)[18], bf16x8 (&ring)[RING],
-                                             const f32x16& binit)
+template <int K>
+__device__ __forceinline__ void conv3_row(const unsigned char* base, const bf16x8 (&wA3)[18], bf16x8 (&ring)[RING],
+                                          const f32x4& b0, const f32x4& b1, f32x4& acc0, f32x4& acc1)
 {
-  f32x16 acc = binit;  // C operand of the first MFMA: the bias costs nothing
-  const unsigned char* base = a2 + (2 * yp) * A2_PITCH * 16;
-  const unsigned char* next = a2 + (2 * yp_next) * A2_PITCH * 16;
-  if (FIRST) {
+  acc0 = b0;  // C operand of the first MFMA of each accumulator: the bias costs nothing
+  acc1 = b1;
+  if (K == 0) {
 #pragma unroll
-    for (int s = 0; s < RING; ++s) ring[(s + PHASE) % RING] = lds_frag(conv3_frag(base, s));
+    for (int g = 0; g < RING; ++g) ring[g] = lds_frag(base + conv3_frag_off(g));
   }
 #pragma unroll
-  for (int s = 0; s < 18; ++s) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA3[s], ring[(s + PHASE) % RING], acc, 0, 0, 0);
-    const int n = s + RING;
-    if (n < 18) ring[(s + PHASE) % RING] = lds_frag(conv3_frag(base, n));
-    else if (!LAST) ring[(s + PHASE) % RING] = lds_frag(conv3_frag(next, n - 18));
+  for (int t = 0; t < 9; ++t) {
+    const int g = 9 * K + t;
+    const bf16x8 b = ring[g % RING];
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wA3[t], b, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wA3[9 + t], b, acc1, 0, 0, 0);
+    if (g + RING < 72) ring[g % RING] = lds_frag(base + conv3_frag_off(g + RING));
   }
-  return acc;
 }
-
+__device__ __forceinline__ void sched_row18()
+{
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // 2 MFMAs (the two M tiles of a fragment)
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+  }
+}
 // One thread's 16 samples of a CTU (picture row ld_row, columns 16*ld_seg..) fetched ahead of use.  fast = 0:
 // picture edge or unaligned plane, P0 falls back to guarded scalar loads.
 struct Prefetched { uint4 a, b; int fast; };
@@ -606,33 +620,44 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
     pre = prefetch_ctu(F, work + (int)gridDim.x < total, next, ld_row, ld_seg);  // next CTU's samples travel under conv3 and the heads
     {
       FHEVC_PHASE_IDS
-      // column rotation of the second row: with an 18-position (288 B) row pitch the 16 lanes of every ds_read_b128
-      // group then cover 16 distinct 16-byte slots modulo 256 B
-      const int yy = r >> 4, x = yy ? ((r - 2) & 15) : (r & 15);
-      const float* bias3 = biasL + 48 + 32 * tile3;
-      const unsigned char* a2 = lds + R2_OFF + h * A2_PLANE + (yy * A2_PITCH + x) * 16;
+      const int x = lane & 15, kg = lane >> 4;  // B column = position x of the row, K group = activation plane kg; D rows 4 kg ..
+      const int y0 = 2 * (wave >> 1);           // this wave's rows: y0 + {0, 1, 4, 5, 8, 9, 12, 13} (+ {2, 3, ...} for the next wave pair)
+      const unsigned char* a2 = lds + R2_OFF + kg * A2_PLANE + (y0 * A2_PITCH + x) * 16;
       // a3 row of a position p = 64 B = four 16-B chunks; chunk c is stored at c ^ ((p >> 2) & 3) so that the 16
       // lanes of a ds_read_b128 group in the heads (consecutive positions, same logical chunk) hit 16 distinct slots
-      const int psw = (x >> 2) & 3;  // ((yy * 16 + x) >> 2) & 3, rows are 16 positions
-      unsigned char* a3dst = lds + A3_OFF + (yy * 16 + x) * 64 + 4 * h;
-      const int yp0 = wave >> 1;
-      const f32x16 b3 = bias_tile(bias3, h);  // once per phase (see conv2_store)
+      const int psw = (x >> 2) & 3;
+      unsigned char* a3dst = lds + A3_OFF + (y0 * 16 + x) * 64 + 4 * kg;
+      const f32x4 b30 = *reinterpret_cast<const f32x4*>(biasL + 48 + 32 * tile3 + 4 * kg);       // M tile 0: channels 32 t + 4 kg + i
+      const f32x4 b31 = *reinterpret_cast<const f32x4*>(biasL + 48 + 32 * tile3 + 16 + 4 * kg);  // M tile 1
       bf16x8 ring[RING];
-      f32x16 accA = conv3_unit<true, false, 0>(a2, yp0, yp0 + 2, wA3, ring, b3);  // PHASE of unit k = (18 k) % RING
-      __builtin_amdgcn_sched_group_barrier(0x100, RING + 4, 0);
-      sched_chain18<0>();
-      f32x16 accB = conv3_unit<false, false, (18 * 1) % RING>(a2, yp0 + 2, yp0 + 4, wA3, ring, b3);
-      conv3_store(accA, a3dst + (yp0 + 0) * 2048, tile3, psw);
-      sched_chain18<0>();
-      accA = conv3_unit<false, false, (18 * 2) % RING>(a2, yp0 + 4, yp0 + 6, wA3, ring, b3);
-      conv3_store(accB, a3dst + (yp0 + 2) * 2048, tile3, psw);
-      sched_chain18<0>();
-      accB = conv3_unit<false, true, (18 * 3) % RING>(a2, yp0 + 6, yp0 + 6, wA3, ring, b3);
-      conv3_store(accA, a3dst + (yp0 + 4) * 2048, tile3, psw);
-      sched_chain18<0>();
-      conv3_store(accB, a3dst + (yp0 + 6) * 2048, tile3, psw);
-      asm volatile("" ::"v"(b3));  // the bias tile stays in its registers to the end of the phase: otherwise the last unit's
-                                   // accumulator takes them over and its chain is hoisted into the previous one
+      f32x4 p0, p1, q0, q1;
+#define FHEVC_ROW_OFF(k) ((4 * ((k) >> 1) + ((k) & 1)) * 1024)
+      conv3_row<0>(a2, wA3, ring, b30, b31, p0, p1);
+      __builtin_amdgcn_sched_group_barrier(0x100, RING + 2, 0);
+      sched_row18();
+      conv3_row<1>(a2, wA3, ring, b30, b31, q0, q1);
+      conv3_store(p0, p1, a3dst + FHEVC_ROW_OFF(0), tile3, psw);
+      sched_row18();
+      conv3_row<2>(a2, wA3, ring, b30, b31, p0, p1);
+      conv3_store(q0, q1, a3dst + FHEVC_ROW_OFF(1), tile3, psw);
+      sched_row18();
+      conv3_row<3>(a2, wA3, ring, b30, b31, q0, q1);
+      conv3_store(p0, p1, a3dst + FHEVC_ROW_OFF(2), tile3, psw);
+      sched_row18();
+      conv3_row<4>(a2, wA3, ring, b30, b31, p0, p1);
+      conv3_store(q0, q1, a3dst + FHEVC_ROW_OFF(3), tile3, psw);
+      sched_row18();
+      conv3_row<5>(a2, wA3, ring, b30, b31, q0, q1);
+      conv3_store(p0, p1, a3dst + FHEVC_ROW_OFF(4), tile3, psw);
+      sched_row18();
+      conv3_row<6>(a2, wA3, ring, b30, b31, p0, p1);
+      conv3_store(q0, q1, a3dst + FHEVC_ROW_OFF(5), tile3, psw);
+      sched_row18();
+      conv3_row<7>(a2, wA3, ring, b30, b31, q0, q1);
+      conv3_store(p0, p1, a3dst + FHEVC_ROW_OFF(6), tile3, psw);
+      sched_row18();
+      conv3_store(q0, q1, a3dst + FHEVC_ROW_OFF(7), tile3, psw);
+#undef FHEVC_ROW_OFF
     }
     __syncthreads();
     FHEVC_STAMP(3)
