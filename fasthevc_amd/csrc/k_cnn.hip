@@ -50,13 +50,13 @@ constexpr int A2_PLANE = 18 * 18 * 16 + 192;      // 5376 = 21 * 256: conv3's B 
                                                   // and {positions 0-3, 12-15 of plane 0} + {4-11 of plane 1} only tile a 256-byte bank row
                                                   // when the planes are a multiple of 256 B apart
 constexpr int R2_OFF = R1_OFF + R1_BYTES;         // R2: input CTU bf16 [66][68]; later A2 (4 planes)
-constexpr int R2_BYTES = 4 * A2_PLANE;            // 20736
+constexpr int R2_BYTES = 4 * A2_PLANE;            // 21504
 constexpr int IN_PITCH = 68;                      // dwords per input row PAIR (66 used): lo = row 2j, hi = row 2j+1
 constexpr int BIAS_OFF = R2_OFF + R2_BYTES;       // float b1[16] b2[32] b3[64]
 constexpr int LOGIT_OFF = BIAS_OFF + 112 * 4;     // int logits[21][2] (the 64-level pair is formed by the readers) + at [44..51] the
                                                   // four waves' partial 64-level sums
 constexpr int HEADW_OFF = LOGIT_OFF + 56 * 4;     // int8 head weights: wh64, wh32, wh16 = 18432 B
-constexpr int LDS_BYTES = HEADW_OFF + 18432;      // 79008 -> two workgroups per CU (154.3 of 160 KiB)
+constexpr int LDS_BYTES = HEADW_OFF + 18432;      // 79776 -> two workgroups per CU (155.8 of 160 KiB)
 static_assert(33 * IN_PITCH * 4 <= R2_BYTES, "input tile must fit the A2 region");
 static_assert(HEADW_OFF % 16 == 0, "head weights are read with ds_read_b128");
 static_assert(P3_OFF + 4096 <= R1_OFF + R1_BYTES, "pooled map must fit R1");
