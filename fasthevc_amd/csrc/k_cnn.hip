@@ -57,6 +57,8 @@ constexpr int LOGIT_OFF = BIAS_OFF + 112 * 4;     // int logits[21][2] (the 64-l
                                                   // four waves' partial 64-level sums
 constexpr int HEADW_OFF = LOGIT_OFF + 56 * 4;     // int8 head weights: wh64, wh32, wh16 = 18432 B
 constexpr int LDS_BYTES = HEADW_OFF + 18432;      // 79776 -> two workgroups per CU (155.8 of 160 KiB)
+static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+static_assert(A2_PLANE % 256 == 0, "conv3 reads lane group kg of a ds_read_b128 from plane kg");
 static_assert(33 * IN_PITCH * 4 <= R2_BYTES, "input tile must fit the A2 region");
 static_assert(HEADW_OFF % 16 == 0, "head weights are read with ds_read_b128");
 static_assert(P3_OFF + 4096 <= R1_OFF + R1_BYTES, "pooled map must fit R1");
