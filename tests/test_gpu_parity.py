@@ -135,6 +135,31 @@ def test_device_batch_logits_and_bands(oracle, torch_cuda):
     ctx.close()
 
 
+@pytest.mark.parametrize("W,H", [(200, 136), (72, 72), (64, 8), (8, 200)])
+def test_split_flag_words_on_ragged_pictures(oracle, torch_cuda, W, H):
+    """Pictures whose last CTU column/row is cut inside a 16x16 block (width, height = 8 mod 16): the depth maps equal the
+    oracle's and the 4-byte split-flag words expand back to them (the expansion masks the units outside the picture)."""
+    torch = torch_cuda
+    w = weights.random_weights(5)
+    NF = 2
+    lumas = [frames.texture16_luma(W, H, seed=300 + f) for f in range(NF)]
+    refs = [_oracle_frame(oracle, w, y, 8, 27) for y in lumas]
+    ctx = capi.Context(W, H, 8, w, max_frames=NF)
+    dev = torch.device("cuda:0")
+    n = ctx.num_ctus
+    d8 = torch.from_numpy(np.stack(lumas)).to(dev)
+    depth = torch.full((NF, n, 256), 7, dtype=torch.uint8, device=dev)
+    flags = torch.zeros((NF, n), dtype=torch.int32, device=dev)
+    ctx.predict_frames_device(d8.data_ptr(), 1, W, W * H, NF, depth.data_ptr(), None, None, qp=27, d_flags=flags.data_ptr())
+    expanded = torch.full((NF, n, 256), 9, dtype=torch.uint8, device=dev)
+    ctx.expand_depth_flags_device(flags.data_ptr(), NF, expanded.data_ptr())
+    torch.cuda.synchronize()
+    for f in range(NF):
+        assert np.array_equal(depth[f].cpu().numpy(), refs[f][3]), (W, H, f)
+    assert torch.equal(expanded, depth)
+    ctx.close()
+
+
 @pytest.mark.parametrize("bd", [8, 10, 12])
 def test_source_hadamard_extremes(oracle, bd):
     """updateCtuDataISlice twin on patterns that maximise single coefficients: at 8/10 bit the kernel runs wrapping packed
