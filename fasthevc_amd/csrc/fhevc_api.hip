@@ -113,11 +113,20 @@ int build_weight_image(fhevc_ctx* c, const BlobView& b)
   // all conv weights carry their layer's 2^-shift: w * 2^-s is still exact in bf16 (a power-of-two scaling of an 8-bit integer)
   // and every partial sum is a multiple of 2^-s below 2^24 * 2^-s, so the fp32 accumulation stays exact and the MFMA
   // delivers (acc + b) * 2^-s directly: one multiply per output less in the epilogue
+  // conv1 takes bf16 operands (its input tile is bf16), conv2 and conv3 f16 ones (their inputs are written as f16 by the
+  // epilogues before them): |w| * 2^-s >= 2^-14 is a normal f16 number and 7 significant bits fit its 11
   auto put_scaled = [&](int layer, int frag_idx, int lane, int j, int v) {
     float f = std::ldexp((float)v, -rd32(b.shift, layer));
-    uint32_t u;
-    std::memcpy(&u, &f, 4);
-    frag[((size_t)frag_idx + lane) * 8 + j] = (uint16_t)(u >> 16);
+    uint16_t bits;
+    if (layer == 0) {
+      uint32_t u;
+      std::memcpy(&u, &f, 4);
+      bits = (uint16_t)(u >> 16);
+    } else {
+      const _Float16 h = (_Float16)f;
+      std::memcpy(&bits, &h, 2);
+    }
+    frag[((size_t)frag_idx + lane) * 8 + j] = bits;
   };
   for (int lane = 0; lane < 64; ++lane) {
     const int r = lane & 31, h = lane >> 5;

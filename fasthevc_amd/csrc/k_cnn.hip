@@ -28,7 +28,8 @@
 #include "fhevc_internal.h"
 #include <cstdlib>
 
-typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(8))) short bf16x8;   // 8 x 16-bit operand slots of an MFMA fragment (bf16 for conv1, f16 for conv2/conv3)
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
 
@@ -71,6 +72,29 @@ __device__ __forceinline__ float max_with_xor1(float v)
 {
   const int o = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true);
   return fmaxf(v, __builtin_bit_cast(float, o));
+}
+// Activations between the convs travel as f16 (integers 0..255, exact): under the kernel's round-down mode v_cvt_pk_u8_f32 is
+// floor + ReLU + clamp + pack of four values into a dword, and v_cvt_f16_u16 with SDWA byte select / word destination turns
+// two of its bytes into one packed f16 pair: 2 instructions per output where floor + med3 + half a v_perm needed 2.5
+template <int HI>
+__device__ __forceinline__ unsigned f16_pair_of_bytes(unsigned d)  // HI = 0: bytes 0, 1; HI = 1: bytes 2, 3
+{
+  unsigned r;
+  if (HI == 0) {
+    asm("v_cvt_f16_u16_sdwa %0, %1 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0" : "=v"(r) : "v"(d));
+    asm("v_cvt_f16_u16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1" : "+v"(r) : "v"(d));
+  } else {
+    asm("v_cvt_f16_u16_sdwa %0, %1 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:BYTE_2" : "=v"(r) : "v"(d));
+    asm("v_cvt_f16_u16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3" : "+v"(r) : "v"(d));
+  }
+  return r;
+}
+__device__ __forceinline__ unsigned u8x4_floor_clamp(float a, float b, float c, float d)
+{
+  unsigned r = __builtin_amdgcn_cvt_pk_u8_f32(a, 0, 0);
+  r = __builtin_amdgcn_cvt_pk_u8_f32(b, 1, r);
+  r = __builtin_amdgcn_cvt_pk_u8_f32(c, 2, r);
+  return __builtin_amdgcn_cvt_pk_u8_f32(d, 3, r);
 }
 // two fp32 holding integers 0..255 -> two bf16 (exact: the low 16 mantissa bits are zero)
 __device__ __forceinline__ unsigned pack_bf16(float a, float b)
@@ -132,13 +156,12 @@ __device__ __forceinline__ int dpp_row_sum(int v)
 // holds channels 8h..8h+7 = plane h).  2x2 max-pool = 3 in-lane max per channel, then requant and ONE 16-byte store.
 __device__ __forceinline__ void conv1_store(const f32x16& acc0, const f32x16& acc1, unsigned char* dst)
 {
-  float v[8];
+  float m[8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {  // regs k (py 0) and k+8 (py 1) of both MFMAs (px 0, 1); the accumulators are already
-    const float m = fmaxf(fmaxf(acc0[k], acc0[k + 8]), fmaxf(acc1[k], acc1[k + 8]));  // scaled by 2^-s (weights, bias)
-    v[k] = __builtin_amdgcn_fmed3f(floorf(m), 0.0f, 255.0f);
-  }
-  *reinterpret_cast<uint4*>(dst) = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
+  for (int k = 0; k < 8; ++k)  // regs k (py 0) and k+8 (py 1) of both MFMAs (px 0, 1); the accumulators are already scaled by 2^-s (weights, bias)
+    m[k] = fmaxf(fmaxf(acc0[k], acc0[k + 8]), fmaxf(acc1[k], acc1[k + 8]));
+  const unsigned d0 = u8x4_floor_clamp(m[0], m[1], m[2], m[3]), d1 = u8x4_floor_clamp(m[4], m[5], m[6], m[7]);
+  *reinterpret_cast<uint4*>(dst) = make_uint4(f16_pair_of_bytes<0>(d0), f16_pair_of_bytes<1>(d0), f16_pair_of_bytes<0>(d1), f16_pair_of_bytes<1>(d1));
 }
 // conv2: a lane owns ONE pooled position; its four pre-pool outputs sit in four accumulators (dy, dx), so the 2x2
 // max-pool is in-lane.  The accumulators start from the pre-scaled bias tile and conv2's weights carry 2^-s, so they
@@ -162,10 +185,8 @@ __device__ __forceinline__ void conv2_requant_store(const f32x16& m, unsigned ch
 {
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
-    float v[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = __builtin_amdgcn_fmed3f(floorf(m[4 * g + k]), 0.0f, 255.0f);
-    *reinterpret_cast<uint2*>(dst + g * A2_PLANE) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
+    const unsigned d = u8x4_floor_clamp(m[4 * g], m[4 * g + 1], m[4 * g + 2], m[4 * g + 3]);
+    *reinterpret_cast<uint2*>(dst + g * A2_PLANE) = make_uint2(f16_pair_of_bytes<0>(d), f16_pair_of_bytes<1>(d));
   }
 }
 // conv3 on v_mfma_f32_16x16x32_bf16 (the shape that holds the higher clock under the power limit): a K step is ONE tap x all 32
@@ -230,8 +251,8 @@ __device__ __forceinline__ void conv2_half(const unsigned char* base, const unsi
   for (int f = 0; f < 12; ++f) {  // 12 % RING == 0: ring slots line up from half-chain to half-chain
     const int ky = f / 4, c = f % 4;
     const bf16x8 b = ring[f % RING];
-    if (c < 3) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA2[ky * 3 + c], b, acc0, 0, 0, 0);
-    if (c > 0) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA2[ky * 3 + c - 1], b, acc1, 0, 0, 0);
+    if (c < 3) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wA2[ky * 3 + c]), __builtin_bit_cast(f16x8, b), acc0, 0, 0, 0);
+    if (c > 0) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wA2[ky * 3 + c - 1]), __builtin_bit_cast(f16x8, b), acc1, 0, 0, 0);
     if (f + RING < 12) ring[f % RING] = lds_frag(conv2_frag(base, f + RING));
     else if (!LAST) ring[f % RING] = lds_frag(conv2_frag(next, f + RING - 12));
   }
@@ -258,8 +279,8 @@ __device__ __forceinline__ void conv3_row(const unsigned char* base, const bf16x
   for (int t = 0; t < 9; ++t) {
     const int g = 9 * K + t;
     const bf16x8 b = ring[g % RING];
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wA3[t], b, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wA3[9 + t], b, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wA3[t]), __builtin_bit_cast(f16x8, b), acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wA3[9 + t]), __builtin_bit_cast(f16x8, b), acc1, 0, 0, 0);
     if (g + RING < 72) ring[g % RING] = lds_frag(base + conv3_frag_off(g + RING));
   }
 }
