@@ -20,7 +20,7 @@ sys.path.insert(0, ROOT)
 # algorithmic work per CTU: MACs of the three conv layers + the three FC heads
 MAC_PER_CTU = 4096 * 9 * 16 + 1024 * 144 * 32 + 256 * 288 * 64 + (4096 + 4 * 4096 + 16 * 1024) * 2
 FLOP_PER_CTU = 2 * MAC_PER_CTU
-PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, MI355X_MICROARCH.md
+PEAK_BF16_TFLOPS = 2500.0   # dense 16-bit (bf16 = f16) MFMA, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 PEAK_INT32_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12  # 256 CUs x 4 SIMD x 16 lanes x 2.4 GHz: one 32-bit integer op per lane-cycle (39.3)
 
@@ -296,7 +296,7 @@ def main():
             "metric": "CTU depth decisions/sec at 1080p all-intra", "value": value, "unit": "CTU/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16 operands / f32 accumulate (fixed-point valued, exact)", "data": "synthetic",
+            "dtype": "bf16 (conv1) and f16 (conv2, conv3) operands / f32 accumulate (fixed-point valued, exact)", "data": "synthetic",
             "config": {"workload": f"BQTerrace geometry {W}x{H} all-intra QP32, GOP of {NF} synthetic 'hetero' frames per GPU "
                                    f"({'int16 Pel planes, HM stride/margins' if sample_b == 2 else 'uint8 planes'}) resident in HBM, "
                                    f"source Hadamard + CTU-batched CNN depth predictor, {wdesc}",
