@@ -8,20 +8,20 @@
 //
 // How:
 //   * persistent workgroups (256 threads = 4 waves), grid = 2 per CU, grid-stride over CTUs;
-//   * every conv layer is an im2col GEMM on v_mfma_f32_32x32x16_bf16 with A = weights (rows = output channels,
-//     resident in VGPRs for the whole kernel) and B = im2col (columns = 32 spatial positions) read from LDS
-//     with one ds_read_b128 per K-step: activations live in LDS as 8-channel planes [y][x][8] bf16 so the
-//     16-lane groups of a ds_read_b128 cover 256 contiguous bytes;
+//   * every conv layer is an im2col GEMM on 16-bit MFMA -- conv1 v_mfma_f32_32x32x16_bf16, conv2 v_mfma_f32_32x32x16_f16,
+//     conv3 v_mfma_f32_16x16x32_f16 -- with A = weights (rows = output channels, resident in VGPRs for the whole kernel) and
+//     B = im2col (columns = spatial positions) read from LDS with one ds_read_b128 per K-step: activations live in LDS as
+//     8-channel planes [y][x][8] of f16 so that the 16-lane groups of a ds_read_b128 cover 256 contiguous bytes;
 //   * operands are fixed-point integers (|w| <= 127, activations 0..255, |acc| < 2^24) so the fp32
 //     accumulation is exact in any order -> the integer depth map is bit-exact against the CPU oracle; every conv
-//     carries its 2^-shift in the bf16 weights (still exact) and starts from the pre-scaled bias as the MFMA's C operand;
-//   * the waves run with fp32 rounding toward -inf, which turns v_cvt_pk_u8_f32 into floor + ReLU + clamp + pack
-//     (conv3's whole epilogue); every other fp32 operation of the kernel is exact, so the mode changes nothing else;
-//   * ReLU/requant/max-pool are fused into the MFMA epilogue (in-lane max for the vertical pair,
-//     DPP quad_perm for the horizontal pair), FC heads run on v_dot4_u32_u8 with weights resident in LDS;
-//   * conv1 folds the 2x2 max-pool window into the MFMA's M dimension: A rows = (16 filters) x (2x2 pre-pool
-//     positions) = 64 rows = two MFMAs, K = the 4x4 input window (all 16 slots used, read as row-pair dwords), so a
-//     lane holds all four pre-pool outputs of its pooled position: the pool is three in-lane max, no DPP;
+//     carries its 2^-shift in the weights (still exact) and starts from the pre-scaled bias as the MFMA's C operand;
+//   * the waves run with fp32 rounding toward -inf, which turns v_cvt_pk_u8_f32 into floor + ReLU + clamp + pack: conv3's
+//     whole epilogue, and the first half of conv1's and conv2's (v_cvt_f16_u16 with SDWA byte select makes the f16 pairs);
+//     every other fp32 operation of the kernel is exact, so the mode changes nothing else;
+//   * the 2x2 max-pools are in-lane: conv1 folds the pool window into the MFMA's M dimension (A rows = 16 filters x 2x2
+//     pre-pool positions = two MFMAs, K = the 4x4 input window read as row-pair dwords), conv2 gives a lane one pooled
+//     position and four accumulators (dy, dx) over a parity-split column layout of conv1's output; no DPP in either;
+//   * FC heads on v_dot4_i32_i8 (int8 weights resident in LDS, conv3's output stored as a - 128, offsets folded into biases);
 //   * the next CTU's samples are prefetched into registers from the start of conv3 and staged into LDS after the heads;
 //   * MFMA chains read their fragments through a register ring that runs across the units of a phase; thread
 //     coordinates are re-derived per phase so that nothing address-like stays live across the conv2 phase (no spills).
