@@ -17,7 +17,7 @@ BACKEND_HIP = 1
 NODES_PER_CTU = 85
 LOGITS_PER_CTU = 42
 
-# every symbol include/fasthevc.h declares (tests/test_capi_symbols.py checks header <-> this list <-> the .so)
+# every symbol include/fasthevc.h declares (tests/test_host_logic.py::test_c_abi_exports_every_declared_symbol checks header <-> this list <-> the .so)
 SYMBOLS = [
     "fhevc_create", "fhevc_destroy", "fhevc_set_weights", "fhevc_predict_frame", "fhevc_satd",
     "fhevc_intra_first_pass", "fhevc_predict_frames_device", "fhevc_band", "fhevc_kernel_timing",
@@ -56,6 +56,26 @@ class FastHevcError(RuntimeError):
 _lib = None
 
 
+def _share_the_hosts_hip_runtime():
+    """A PyTorch wheel bundles its own libamdhip64.so with the SONAME of /opt/rocm's.  Whichever copy a process maps first
+    serves every later DT_NEEDED of that SONAME, and torch's other bundled libraries only work with torch's copy: if this
+    library came first (binding /opt/rocm's), a later `import torch` finds "No HIP GPUs".  So when torch is installed and not
+    yet imported, map ITS runtime first (without importing torch); the in-tree library then shares it, in either order."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return  # torch's runtime is already mapped
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return  # no torch in this interpreter (e.g. a plain C++ host): the system runtime is the only one
+    rt = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(rt):
+        C.CDLL(rt, mode=C.RTLD_GLOBAL)
+
+
 def load_library():
     """dlopen the in-tree HIP library; raises if it has not been built (no silent fallback)."""
     global _lib
@@ -63,6 +83,7 @@ def load_library():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise FileNotFoundError(f"{LIB_PATH} not built: run `python -m fasthevc_amd.build` (or __graft_entry__.build())")
+    _share_the_hosts_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     lib.fhevc_create.argtypes = [C.POINTER(vp), C.POINTER(Cfg)]

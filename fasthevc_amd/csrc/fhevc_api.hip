@@ -289,7 +289,11 @@ int fhevc_create(fhevc_ctx** out, const fhevc_cfg* cfg)
   c->ctus_y = (cfg->height + 63) / 64;
   c->num_ctus = c->ctus_x * c->ctus_y;
   c->dev_stride = c->ctus_x * 64;
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return FHEVC_E_NO_DEVICE; }
+  // A BLOCKING stream (hipStreamDefault): it is ordered after everything issued earlier on the legacy default stream and before
+  // everything issued later on it, so a caller that works on the default stream (stream 0, torch's default) and passes
+  // stream = NULL needs no extra synchronisation; callers on their own non-blocking streams pass that stream explicitly
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamDefault) != hipSuccess) { delete c; return FHEVC_E_NO_DEVICE; }
+  if (fhevc_cnn_prepare_device() != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return FHEVC_E_NO_DEVICE; }  // per device, not per process
   bool ok = true;
   ok &= hipMalloc(&c->d_luma, (size_t)c->dev_stride * c->ctus_y * 64 * sizeof(int16_t)) == hipSuccess;
   ok &= hipMalloc(&c->d_depth, (size_t)c->num_ctus * 256) == hipSuccess;
@@ -379,6 +383,7 @@ int fhevc_predict_frames_device_range(fhevc_ctx* c, const void* d_luma, int samp
   if (margin_split < 0 || margin_split > (1 << 30) || margin_stop < 0 || margin_stop > (1 << 30)) return fail(c, FHEVC_E_INVALID, "bad decision margin");
   if (num_frames > 1 && frame_stride_samples < (long long)stride_samples * (c->cfg.height - 1) + c->cfg.width) return fail(c, FHEVC_E_INVALID, "frames overlap");
   if (ctu_row_begin == ctu_row_end) return FHEVC_OK;
+  (void)hipSetDevice(c->device);
   hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
   const FhevcFrames fr = frames_of(c, d_luma, sample_bytes, stride_samples, frame_stride_samples, num_frames, ctu_row_begin, ctu_row_end, qp);
   if (d_hadamard) {
@@ -399,6 +404,7 @@ int fhevc_predict_frames_device_range(fhevc_ctx* c, const void* d_luma, int samp
 int fhevc_expand_depth_flags_device(fhevc_ctx* c, const uint32_t* d_flags, int num_frames, uint8_t* d_depth_map, void* stream)
 {
   if (!c || !d_flags || !d_depth_map || num_frames < 1) return FHEVC_E_INVALID;
+  (void)hipSetDevice(c->device);
   hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
   const FhevcFrames fr = frames_of(c, nullptr, 1, c->cfg.width, 0, num_frames, 0, c->ctus_y);
   HIP_TRY(c, fhevc_launch_expand_flags(fr, d_flags, d_depth_map, s));

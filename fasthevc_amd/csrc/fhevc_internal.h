@@ -37,6 +37,7 @@ struct FhevcCnnWeights {
   float scale[3];            // 2^-shift per conv layer (folded into the fragments; the kernel pre-scales the biases with it)
 };
 
+hipError_t fhevc_cnn_prepare_device();  // LDS opt-in of the depth kernel on the current device (once per context)
 // d_depth_max / margins: soft decisions (nullptr / 0, 0 = the plain map only)
 hipError_t fhevc_launch_cnn(const FhevcFrames& fr, const FhevcCnnWeights& w, uint8_t* d_depth, int32_t* d_logits,
                             uint32_t* d_flags, uint8_t* d_depth_max, int margin_split, int margin_stop, int num_cus, hipStream_t stream);

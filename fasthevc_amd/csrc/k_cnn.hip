@@ -851,6 +851,12 @@ hipError_t fhevc_launch_expand_flags(const FhevcFrames& fr, const uint32_t* d_fl
   return hipGetLastError();
 }
 
+// > 64 KiB of dynamic LDS needs an opt-in per function AND per device: fhevc_create calls this with its device current
+hipError_t fhevc_cnn_prepare_device()
+{
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+}
+
 hipError_t fhevc_launch_cnn(const FhevcFrames& fr, const FhevcCnnWeights& w, uint8_t* d_depth, int32_t* d_logits,
                             uint32_t* d_flags, uint8_t* d_depth_max, int margin_split, int margin_stop, int num_cus, hipStream_t stream)
 {
@@ -858,13 +864,6 @@ hipError_t fhevc_launch_cnn(const FhevcFrames& fr, const FhevcCnnWeights& w, uin
   if (total <= 0) return hipSuccess;
   int grid = 2 * num_cus;
   if (total < grid) grid = (int)total;
-  static bool attr_set = false;  // > 64 KiB of LDS needs the opt-in; one device per process
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_kernel<false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
   hipLaunchKernelGGL(fhevc_cnn_depth_kernel<false>, dim3(grid), dim3(256), LDS_BYTES, stream, fr, w, d_depth, d_logits,
                      d_flags, (unsigned long long*)nullptr, d_depth_max, margin_split, margin_stop);
   return hipGetLastError();

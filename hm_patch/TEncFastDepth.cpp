@@ -13,7 +13,7 @@
 #endif
 
 TEncFastDepth::TEncFastDepth()
-  : m_enabled(false), m_valid(false), m_external(false), m_ctx(NULL), m_width(0), m_height(0), m_bitDepth(0), m_marginSplit(0), m_marginStop(0), m_pWindow(-1)
+  : m_enabled(false), m_valid(false), m_external(false), m_cachePic(NULL), m_cachePoc(-1), m_cacheQp(-1), m_cacheType(-1), m_cacheFp(0), m_ctx(NULL), m_width(0), m_height(0), m_bitDepth(0), m_marginSplit(0), m_marginStop(0), m_pWindow(-1)
 {
   readKnobs();
 }
@@ -54,7 +54,24 @@ void TEncFastDepth::setExternalRange(const unsigned char* mapMin, const unsigned
 bool TEncFastDepth::predictPicture(TComPic* pcPic, int sliceQp, int sliceType)
 {
   if (m_external) return true;       // validation feed wins
+  // compressSlice runs once per slice and once more per precompressSlice iteration (DeltaQpRD): the map of a picture is
+  // computed once per (picture object, POC, slice QP, slice type, fingerprint of the original luma) and kept; the fingerprint
+  // (every 16th row, FNV-1a) tells a recycled TComPic with a repeated POC (IDR-only streams) from the same picture
+  unsigned long long fp = 1469598103934665603ULL;
+  {
+    const TComPicYuv* o = pcPic->getPicYuvOrg();
+    const Pel* p = o->getAddr(COMPONENT_Y);
+    const int w = o->getWidth(COMPONENT_Y), h = o->getHeight(COMPONENT_Y), st = o->getStride(COMPONENT_Y);
+    for (int y = 0; y < h; y += 16)
+      for (int x = 0; x < w; x++) { fp ^= (unsigned long long)(unsigned short)p[(size_t)y * st + x]; fp *= 1099511628211ULL; }
+  }
+  if (m_valid && pcPic == m_cachePic && pcPic->getPOC() == m_cachePoc && sliceQp == m_cacheQp && sliceType == m_cacheType && fp == m_cacheFp) return true;
   m_valid = false;
+  m_cachePic = pcPic; m_cachePoc = pcPic->getPOC(); m_cacheQp = sliceQp; m_cacheType = sliceType; m_cacheFp = fp;
+  // the depth-map layout (16x16 units of a 64x64 CTU, depths 0..3) is what the library produces and forcedRange() reads:
+  // any other CTU geometry runs stock RDO
+  const TComSPS& sps = pcPic->getPicSym()->getSPS();
+  if (sps.getMaxCUWidth() != 64 || sps.getMaxCUHeight() != 64 || sps.getLog2DiffMaxMinCodingBlockSize() != 3) return false;
   if (sliceType != I_SLICE)
   {
     // Inter-CU depth reuse (config 4): the classifier is trained on intra decisions, so P/B pictures take their depth range
@@ -141,20 +158,4 @@ bool TEncFastDepth::forcedRange(const TComDataCU* pcCU, int& dmin, int& dmax) co
   dmin = lo;
   dmax = hi;
   return dmax >= dmin;
-}
-
-/* C entry for the oracle harness (oracle/ref_rdo_harness.cpp, FHEVC_HOOK builds) */
-static TEncFastDepth* g_hookInstance = NULL;
-void fhevc_hook_register(TEncFastDepth* p) { g_hookInstance = p; }
-extern "C" void fhevc_hook_set_external_map(const unsigned char* map, int num_ctus)
-{
-  if (g_hookInstance != NULL) g_hookInstance->setExternalMap(map, num_ctus);
-}
-extern "C" void fhevc_hook_reload_knobs()   // the harness changes the environment between pictures
-{
-  if (g_hookInstance != NULL) g_hookInstance->readKnobs();
-}
-extern "C" void fhevc_hook_set_external_range(const unsigned char* map_min, const unsigned char* map_max, int num_ctus)
-{
-  if (g_hookInstance != NULL) g_hookInstance->setExternalRange(map_min, map_max, num_ctus);
 }

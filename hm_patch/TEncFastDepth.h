@@ -37,13 +37,16 @@ public:
   /// depth range [dmin, dmax] (each 0..3) of the CU whose top-left 4x4 unit is (ctuRsAddr, zorderIdx): the caller
   /// forces a split while uiDepth < dmin and forbids one once uiDepth >= dmax; false -> no prediction
   bool forcedRange(const TComDataCU* pcCU, int& dmin, int& dmax) const;
-  /// validation feed (oracle harness): use these maps instead of the GPU for the next picture; NULL clears them
+  /// explicit maps from another source (e.g. a validation harness) instead of the GPU, until cleared with NULL
   void setExternalMap(const unsigned char* map, int numCtus) { setExternalRange(map, map, numCtus); }
   void setExternalRange(const unsigned char* mapMin, const unsigned char* mapMax, int numCtus);
   const std::vector<unsigned char>& depthMap() const { return m_depth; }
 
 private:
   bool       m_enabled, m_valid, m_external;
+  const TComPic* m_cachePic;               // the picture m_depth belongs to (+ POC, slice QP, slice type)
+  int        m_cachePoc, m_cacheQp, m_cacheType;
+  unsigned long long m_cacheFp;
   fhevc_ctx* m_ctx;
   int        m_width, m_height, m_bitDepth, m_marginSplit, m_marginStop, m_pWindow;
   std::vector<unsigned char> m_depth;     // numCtus * 256, raster 16x16 per CTU: depth_min

@@ -29,7 +29,10 @@ def patch_cu_cpp(s):
     s = sub_once(s, r'(^\s*const Bool bBoundary = .*;\n)',
                  r'\1\n    Int iDepthMin = 0, iDepthMax = 0;                                        // predicted depth range of this CU\n'
                  r'    const Bool bHaveRange   = m_fastDepth.forcedRange( rpcBestCU, iDepthMin, iDepthMax );\n'
-                 r'    const Bool bForceSplit  = bHaveRange && !bBoundary && iDepthMin > (Int)uiDepth;   // skip the mode loop at this depth\n'
+                 r'    // (a split may only be forced where the recursion below really runs -- the condition of the "further split" branch --\n'
+                 r'    //  otherwise rpcBestCU would stay at MAX_DOUBLE and the assert at the end of xCompressCU fires)\n'
+                 r'    const Bool bCanRecurse  = uiDepth < sps.getLog2DiffMaxMinCodingBlockSize() && ( !getFastDeltaQp() || uiWidth > fastDeltaQPCuMaxSize );\n'
+                 r'    const Bool bForceSplit  = bHaveRange && !bBoundary && bCanRecurse && iDepthMin > (Int)uiDepth;   // skip the mode loop at this depth\n'
                  r'    const Bool bForceStop   = bHaveRange && !bBoundary && iDepthMax <= (Int)uiDepth;  // do not recurse below it\n',
                  "bBoundary")
     # 2. the mode loop runs only when the node is not forced to split

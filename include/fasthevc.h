@@ -118,7 +118,10 @@ int  fhevc_intra_first_pass_device(fhevc_ctx* ctx, const void* d_luma, int sampl
  * d_luma: sample_bytes = 2 -> int16 Pel plane(s) as HM lays them out, 1 -> uint8 (8-bit content);
  * frame f starts at d_luma + f * frame_stride_samples.  Outputs are device pointers, compact over the band:
  * entry ((f * band_rows + (row - ctu_row_begin)) * ctus_per_row + col).  d_hadamard / d_logits / d_flags may be NULL.
- * stream: hipStream_t (NULL = the context's stream).  Asynchronous with respect to the host. */
+ * stream: hipStream_t.  NULL = the context's own stream, a BLOCKING stream: work on it is ordered after everything issued
+ * earlier on the legacy default stream (stream 0) and before everything issued later on it, so a caller that lives on the
+ * default stream needs no extra synchronisation; a caller on its own non-blocking stream passes that stream.
+ * Asynchronous with respect to the host. */
 int  fhevc_predict_frames_device(fhevc_ctx* ctx, const void* d_luma, int sample_bytes, int stride_samples,
                                  long long frame_stride_samples, int num_frames, int ctu_row_begin, int ctu_row_end,
                                  int qp, uint8_t* d_depth_map, int32_t* d_hadamard, int32_t* d_logits, uint32_t* d_flags,

@@ -7,7 +7,7 @@
 // encoder is unbuildable here and is not built.
 //
 // This file only CALLS reference code; it contains none of it.  It is used by oracle/gen_golden.py
-// to produce tests/golden/ref_*.npz and by tests/test_oracle_vs_ref.py when oracle/_ref exists.
+// to produce tests/golden/ref_*.npz and by tests/test_reference_rdo.py when oracle/_ref exists.
 #include <cstring>
 #include <cstdint>
 #include "TLibCommon/CommonDef.h"

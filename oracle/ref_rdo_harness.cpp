@@ -53,13 +53,6 @@
 #undef private
 #undef protected
 
-#ifdef FHEVC_HOOK
-// provided by the hook build (hm_patch/TEncFastDepth.cpp compiled into this library): explicit depth map feed
-extern "C" void fhevc_hook_set_external_map(const unsigned char* map, int num_ctus);
-extern "C" void fhevc_hook_set_external_range(const unsigned char* map_min, const unsigned char* map_max, int num_ctus);
-extern "C" void fhevc_hook_reload_knobs();
-void fhevc_hook_register(TEncFastDepth* p);
-#endif
 
 namespace {
 
@@ -333,9 +326,9 @@ int href_rdo_encode_frame_yuv(const int16_t* luma, int stride, const int16_t* cb
   load_picture(*e, luma, stride, cb, cr);
   init_slice(*e, qp);
 #ifdef FHEVC_HOOK
-  fhevc_hook_register(&e->cu.getFastDepth());
-  if (forced_depth && g_forced_max) fhevc_hook_set_external_range(forced_depth, g_forced_max, (int)e->pic->getNumberOfCtusInFrame());
-  else fhevc_hook_set_external_map(forced_depth, forced_depth ? (int)e->pic->getNumberOfCtusInFrame() : 0);
+  // explicit depth-map feed of the hook (TEncFastDepth's public validation interface); NULL clears it
+  if (forced_depth && g_forced_max) e->cu.getFastDepth().setExternalRange(forced_depth, g_forced_max, (int)e->pic->getNumberOfCtusInFrame());
+  else e->cu.getFastDepth().setExternalMap(forced_depth, forced_depth ? (int)e->pic->getNumberOfCtusInFrame() : 0);
   g_forced_max = nullptr;  // one-shot
 #else
   if (forced_depth) return -2;
@@ -475,10 +468,9 @@ int href_rdo_encode_next_p(const int16_t* luma, const int16_t* cb, const int16_t
   s->setMaxNumMergeCand(5); s->setDepth(0);
   s->setLFCrossSliceBoundaryFlag(true);
   e->slice.setSearchRange(s);
-  fhevc_hook_register(&e->cu.getFastDepth());
-  fhevc_hook_reload_knobs();
-  if (forced_min && forced_max) fhevc_hook_set_external_range(forced_min, forced_max, n);
-  else fhevc_hook_set_external_map(forced_min, forced_min ? n : 0);
+  e->cu.getFastDepth().readKnobs();  // the harness changes the environment between pictures
+  if (forced_min && forced_max) e->cu.getFastDepth().setExternalRange(forced_min, forced_max, n);
+  else e->cu.getFastDepth().setExternalMap(forced_min, forced_min ? n : 0);
   const auto t0 = std::chrono::steady_clock::now();
   e->slice.compressSlice(e->pic, false, false);
   const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

@@ -22,14 +22,3 @@ def oracle():
 def golden():
     import numpy as np
     return np.load(os.path.join(ROOT, "tests", "golden", "ref_vectors.npz"))
-
-
-@pytest.fixture(scope="session", autouse=True)
-def _torch_hip_runtime_first(request):
-    """torch ships its own copy of the HIP runtime; when GPU tests are selected bring it up before the in-tree
-    library initialises the system one, so that the order does not depend on which test file runs first."""
-    if any(item.get_closest_marker("gpu") for item in request.session.items):
-        import torch
-        if torch.cuda.is_available():
-            torch.cuda.init()
-    yield
