@@ -24,6 +24,7 @@ SYMBOLS = [
     "fhevc_enable_kernel_timing", "fhevc_get_stats", "fhevc_last_error", "fhevc_version",
     "fhevc_expand_depth_flags_device", "fhevc_aq_parts", "fhevc_preanalyze", "fhevc_preanalyze_frames_device", "fhevc_aq_qp", "fhevc_intra_first_pass_device",
     "fhevc_predict_frame_range", "fhevc_predict_frames_device_range",
+    "fhevc_motion_search", "fhevc_motion_search_device",
 ]
 
 
@@ -45,6 +46,7 @@ class Stats(C.Structure):
 
 
 NODE_DTYPE = np.dtype([("satd", np.uint32), ("mode", np.uint32), ("cost", np.float64)])
+MOTION_DTYPE = np.dtype([("satd_zero", np.uint32), ("satd_best", np.uint32), ("cost_best", np.uint32), ("mvx", np.int16), ("mvy", np.int16)])
 
 
 class FastHevcError(RuntimeError):
@@ -107,6 +109,8 @@ def load_library():
     lib.fhevc_aq_qp.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     lib.fhevc_preanalyze_frames_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_int,
                                                    C.c_int, vp, vp]
+    lib.fhevc_motion_search.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]
+    lib.fhevc_motion_search_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
     lib.fhevc_kernel_timing.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     lib.fhevc_enable_kernel_timing.argtypes = [vp, C.c_int]
     lib.fhevc_get_stats.argtypes = [vp, vp, C.c_size_t]
@@ -196,6 +200,24 @@ class Context:
         out = np.zeros(self.num_ctus * NODES_PER_CTU, NODE_DTYPE)
         self._check(self.lib.fhevc_intra_first_pass(self.h, flat.ctypes.data + 2 * origin, stride, qp, out.ctypes.data))
         return out.reshape(self.num_ctus, NODES_PER_CTU)
+
+    def motion_search(self, cur_plane, ref_plane, origin=0, stride=None, qp=32, search_range=4):
+        """config 4: [numCtus, 85] MOTION_DTYPE nodes of cur searched in ref (two Pel planes of the same layout)."""
+        cur = np.ascontiguousarray(cur_plane).reshape(-1)
+        ref = np.ascontiguousarray(ref_plane).reshape(-1)
+        assert cur.dtype == np.int16 and ref.dtype == np.int16
+        stride = stride if stride is not None else cur_plane.shape[-1]
+        out = np.zeros(self.num_ctus * NODES_PER_CTU, MOTION_DTYPE)
+        self._check(self.lib.fhevc_motion_search(self.h, cur.ctypes.data + 2 * origin, ref.ctypes.data + 2 * origin, stride, qp,
+                                                 search_range, out.ctypes.data))
+        return out.reshape(self.num_ctus, NODES_PER_CTU)
+
+    def motion_search_device(self, d_luma, sample_bytes, stride, frame_stride, num_frames, d_out, rows=None, stream=None, qp=32,
+                             search_range=4):
+        """frames 1.. of the batch, each searched in the frame before it; d_out: (num_frames - 1) * band CTUs * 85 nodes (16 B)."""
+        rb, re = rows if rows is not None else (0, self.ctus_y)
+        self._check(self.lib.fhevc_motion_search_device(self.h, d_luma, sample_bytes, stride, frame_stride, num_frames, rb, re, qp,
+                                                        search_range, d_out, stream))
 
     def aq_layout(self, max_aq_depth):
         """Offsets of the AQ layers in the concatenated activity array (max_aq_depth + 1 entries)."""

@@ -34,9 +34,11 @@ struct fhevc_ctx {
   bool timing = false;
   std::vector<TimedLaunch> pending;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
-  double sum_ms[4] = { 0, 0, 0, 0 };
-  uint64_t launches[4] = { 0, 0, 0, 0 };
+  double sum_ms[5] = { 0, 0, 0, 0, 0 };
+  uint64_t launches[5] = { 0, 0, 0, 0, 0 };
   double* d_act = nullptr;
+  int16_t* d_pair = nullptr;          // two staging planes (reference, current) of fhevc_motion_search
+  FhevcMotionNode* d_motion = nullptr;
   uint8_t* d_depth_max = nullptr;
   fhevc_stats stats{};
   std::string err;
@@ -326,7 +328,7 @@ void fhevc_destroy(fhevc_ctx* c)
   for (auto& p : c->pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   (void)hipFree(c->d_frag); (void)hipFree(c->d_bias); (void)hipFree(c->d_whead); (void)hipFree(c->d_bhead);
-  (void)hipFree(c->d_luma); (void)hipFree(c->d_depth); (void)hipFree(c->d_had); (void)hipFree(c->d_nodes); (void)hipFree(c->d_satd); (void)hipFree(c->d_satd_out); (void)hipFree(c->d_act); (void)hipFree(c->d_depth_max);
+  (void)hipFree(c->d_luma); (void)hipFree(c->d_depth); (void)hipFree(c->d_had); (void)hipFree(c->d_nodes); (void)hipFree(c->d_satd); (void)hipFree(c->d_satd_out); (void)hipFree(c->d_act); (void)hipFree(c->d_depth_max); (void)hipFree(c->d_pair); (void)hipFree(c->d_motion);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -354,7 +356,7 @@ int fhevc_enable_kernel_timing(fhevc_ctx* c, int on)
 
 int fhevc_kernel_timing(fhevc_ctx* c, int which, int reset, double* avg_ms, uint64_t* launches)
 {
-  if (!c || which < 0 || which > 3) return FHEVC_E_INVALID;
+  if (!c || which < 0 || which > 4) return FHEVC_E_INVALID;
   time_resolve(c);
   if (avg_ms) *avg_ms = c->launches[which] ? c->sum_ms[which] / (double)c->launches[which] : 0.0;
   if (launches) *launches = c->launches[which];
@@ -599,6 +601,64 @@ int fhevc_intra_first_pass_device(fhevc_ctx* c, const void* d_luma, int sample_b
   HIP_TRY(c, fhevc_launch_first_pass(fr, sqrt_lambda, reinterpret_cast<FhevcNodeCost*>(d_out), st));
   time_end(c, st);
   c->stats.kernels_launched++;
+  return FHEVC_OK;
+}
+
+// the vector-cost table of the window, with HM's own arithmetic (TComRdCost.h:166-174, TComRdCost.cpp:109-114, 177-190)
+static FhevcMvCost mv_cost_table(int qp, int range)
+{
+  FhevcMvCost t;
+  const double sqrt_lambda = std::sqrt(0.57 * std::pow(2.0, ((double)qp - 12.0) / 3.0));
+  const double motion_lambda = 65536.0 * sqrt_lambda;
+  auto eg = [](int v) { unsigned len = 1, u = (v <= 0) ? (((unsigned)(-v)) << 1) + 1 : ((unsigned)v) << 1; while (u != 1) { u >>= 1; len += 2; } return len; };
+  const int side = 2 * range + 1;
+  for (int m = 0; m < side * side; ++m) {
+    const unsigned bits = eg(((m % side) - range) << 2) + eg(((m / side) - range) << 2);
+    t.c[m] = (uint32_t)((motion_lambda * bits) / 65536.0);
+  }
+  return t;
+}
+
+int fhevc_motion_search_device(fhevc_ctx* c, const void* d_luma, int sample_bytes, int stride_samples, long long frame_stride_samples,
+                               int num_frames, int ctu_row_begin, int ctu_row_end, int qp, int search_range, fhevc_motion_node* d_out, void* stream)
+{
+  if (!c || !d_luma || !d_out) return FHEVC_E_INVALID;
+  if ((sample_bytes != 1 && sample_bytes != 2) || stride_samples < c->cfg.width || num_frames < 2 || qp < 0 || qp > 51 ||
+      ctu_row_begin < 0 || ctu_row_end > c->ctus_y || ctu_row_begin > ctu_row_end || search_range < 1 || search_range > FHEVC_MOTION_MAX_RANGE)
+    return fail(c, FHEVC_E_INVALID, "bad motion-search arguments");
+  if (sample_bytes == 1 && c->cfg.bit_depth != 8) return fail(c, FHEVC_E_INVALID, "uint8 samples need bit depth 8");
+  if (frame_stride_samples < (long long)stride_samples * (c->cfg.height - 1) + c->cfg.width) return fail(c, FHEVC_E_INVALID, "frames overlap");
+  if (ctu_row_begin == ctu_row_end) return FHEVC_OK;
+  (void)hipSetDevice(c->device);
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  const FhevcFrames fr = frames_of(c, d_luma, sample_bytes, stride_samples, frame_stride_samples, num_frames, ctu_row_begin, ctu_row_end, qp);
+  static_assert(sizeof(fhevc_motion_node) == sizeof(FhevcMotionNode), "motion node layout");
+  time_begin(c, st, 4);
+  HIP_TRY(c, fhevc_launch_motion(fr, search_range, mv_cost_table(qp, search_range), reinterpret_cast<FhevcMotionNode*>(d_out), c->num_cus, st));
+  time_end(c, st);
+  c->stats.kernels_launched++;
+  return FHEVC_OK;
+}
+
+int fhevc_motion_search(fhevc_ctx* c, const int16_t* cur_luma, const int16_t* ref_luma, int stride_samples, int qp, int search_range,
+                        fhevc_motion_node* out)
+{
+  if (!c || !cur_luma || !ref_luma || !out || stride_samples < c->cfg.width) return FHEVC_E_INVALID;
+  (void)hipSetDevice(c->device);
+  const size_t plane = (size_t)c->dev_stride * c->ctus_y * 64;
+  if (!c->d_pair) HIP_TRY(c, hipMalloc(&c->d_pair, 2 * plane * sizeof(int16_t)));
+  if (!c->d_motion) HIP_TRY(c, hipMalloc(&c->d_motion, (size_t)c->num_ctus * FHEVC_NODES * sizeof(FhevcMotionNode)));
+  HIP_TRY(c, hipMemcpy2DAsync(c->d_pair, (size_t)c->dev_stride * 2, ref_luma, (size_t)stride_samples * 2, (size_t)c->cfg.width * 2,
+                              (size_t)c->cfg.height, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpy2DAsync(c->d_pair + plane, (size_t)c->dev_stride * 2, cur_luma, (size_t)stride_samples * 2, (size_t)c->cfg.width * 2,
+                              (size_t)c->cfg.height, hipMemcpyHostToDevice, c->stream));
+  c->stats.bytes_h2d += (uint64_t)c->cfg.width * c->cfg.height * 4;
+  const int rc = fhevc_motion_search_device(c, c->d_pair, 2, c->dev_stride, (long long)plane, 2, 0, c->ctus_y, qp, search_range,
+                                            reinterpret_cast<fhevc_motion_node*>(c->d_motion), c->stream);
+  if (rc != FHEVC_OK) return rc;
+  HIP_TRY(c, hipMemcpyAsync(out, c->d_motion, (size_t)c->num_ctus * FHEVC_NODES * sizeof(FhevcMotionNode), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->stats.bytes_d2h += (uint64_t)c->num_ctus * FHEVC_NODES * sizeof(FhevcMotionNode);
   return FHEVC_OK;
 }
 

@@ -55,6 +55,14 @@ hipError_t fhevc_launch_satd(const int16_t* d_org, int org_stride, const int16_t
 struct FhevcNodeCost { uint32_t satd; uint32_t mode; double cost; };
 hipError_t fhevc_launch_first_pass(const FhevcFrames& fr, double sqrt_lambda, FhevcNodeCost* d_out, hipStream_t stream);
 
+// ---- source-only motion search per CU node (k_motion.hip; config 4) -----------------------------------------
+#define FHEVC_NODES 85
+#define FHEVC_MOTION_MAX_RANGE 8
+struct FhevcMotionNode { uint32_t satd_zero, satd_best, cost_best; int16_t mvx, mvy; };
+struct FhevcMvCost { uint32_t c[(2 * FHEVC_MOTION_MAX_RANGE + 1) * (2 * FHEVC_MOTION_MAX_RANGE + 1)]; };  // [dy + R][dx + R] of the window in use
+// frames 1 .. num_frames-1 of fr, each searched in the frame before it; d_out: (num_frames - 1) * band CTUs * 85 nodes
+hipError_t fhevc_launch_motion(const FhevcFrames& fr, int range, const FhevcMvCost& mvc, FhevcMotionNode* d_out, int num_cus, hipStream_t stream);
+
 // ---- adaptive-QP pre-analysis (k_preanalyze.hip) -----------------------------------------------------------
 // d_activity: per frame parts_per_frame doubles, layers concatenated (layer d: ceil(H/P) x ceil(W/P), P = 64 >> d)
 hipError_t fhevc_launch_preanalyze(const FhevcFrames& fr, int layers, long long parts_per_frame, double* d_activity,

@@ -1,0 +1,266 @@
+// k_motion.hip -- source-only integer motion search per CU node (config 4: P slices), gfx950 only.
+//
+// Bit-exact twin of oracle/fhevc_oracle.c: fho_motion_ctu.  For every CU node (64x64, 32x32, 16x16, 8x8: 85 per CTU) of a
+// picture: full search over [-R, R]^2 integer vectors in the PREVIOUS ORIGINAL picture, cost = Hadamard SATD + vector cost,
+// raster order over the window and strict "<" as TEncSearch::xPatternSearch (TEncSearch.cpp:3786-3848), distortion as
+// TComRdCost::xGetHADs (TComRdCost.cpp:1753-1824; HM's HADME distortion, TEncSearch.cpp:836), vector cost as
+// TComRdCost::getCostOfVectorWithPredictor (TComRdCost.h:166-174; the host tabulates it with HM's double arithmetic),
+// reference samples outside the picture replicated from the border (TComPicYuv::extendPicBorder, TComPicYuv.cpp:229-270).
+// The SATD of a node is the sum of its 8x8 tile SATDs (xGetHADs tiles every block of these sizes in 8x8), so ONE pass over
+// the 64 tiles of a CTU per vector serves all four levels.
+//
+// Mapping: workgroup (4 waves) = one CTU at a time, grid-stride; lane = one 8x8 tile (its 64 original samples stay in
+// registers as 32 packed pairs); the four waves split the vectors of the window; the reference window ((64 + 2R)^2
+// samples, border replicated) is staged in LDS once per CTU: each HBM sample is read once per CTU (+ the 2R halo).
+// Per vector a lane reads its displaced 8x8 block from LDS (dword reads + v_alignbit for odd offsets), subtracts, runs the
+// packed-16 Hadamard of k_hadamard.hip (|coefficients| stay below 2^15 through five stages up to 10 bit; the sixth, inside a
+// packed pair, is folded into the absolute sum: |a+b| + |a-b| = 2 max(|a|,|b|)) and the level sums meet through lane shuffles.
+#include "fhevc_internal.h"
+
+namespace {
+
+constexpr int MAXR = FHEVC_MOTION_MAX_RANGE;
+constexpr int RP = 64 + 2 * MAXR + 8;  // LDS row pitch of the reference window in samples (multiple of 8: 16-byte row starts)
+constexpr int WIN_ROWS = 64 + 2 * MAXR;
+
+typedef __attribute__((ext_vector_type(2))) short i16x2;
+__device__ __forceinline__ unsigned pk_add(unsigned a, unsigned b)
+{
+  return __builtin_bit_cast(unsigned, (i16x2)(__builtin_bit_cast(i16x2, a) + __builtin_bit_cast(i16x2, b)));
+}
+__device__ __forceinline__ unsigned pk_sub(unsigned a, unsigned b)
+{
+  return __builtin_bit_cast(unsigned, (i16x2)(__builtin_bit_cast(i16x2, a) - __builtin_bit_cast(i16x2, b)));
+}
+__device__ __forceinline__ unsigned pk_abs(unsigned a)
+{
+  const i16x2 v = __builtin_bit_cast(i16x2, a);
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(v, (i16x2)(-v)));
+}
+// sum of |WHT8x8(d)| of a block held as 8 rows x 4 packed pairs (low half = even column), |samples| < 2^10
+__device__ __forceinline__ unsigned had8x8_packed(unsigned (&d)[32])
+{
+#pragma unroll
+  for (int hs = 1; hs < 8; hs <<= 1)  // vertical: rows y, y + hs
+#pragma unroll
+    for (int i = 0; i < 8; i += hs << 1)
+#pragma unroll
+      for (int y = i; y < i + hs; ++y)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const unsigned a = d[y * 4 + j], b = d[(y + hs) * 4 + j];
+          d[y * 4 + j] = pk_add(a, b); d[(y + hs) * 4 + j] = pk_sub(a, b);
+        }
+#pragma unroll
+  for (int hs = 1; hs < 4; hs <<= 1)  // horizontal distance 2 and 4: pairs j, j + hs
+#pragma unroll
+    for (int y = 0; y < 8; ++y)
+#pragma unroll
+      for (int i = 0; i < 4; i += hs << 1)
+#pragma unroll
+        for (int j = i; j < i + hs; ++j) {
+          const unsigned a = d[y * 4 + j], b = d[y * 4 + j + hs];
+          d[y * 4 + j] = pk_add(a, b); d[y * 4 + j + hs] = pk_sub(a, b);
+        }
+  unsigned acc = 0;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {  // horizontal distance 1, inside a pair: |a + b| + |a - b| = 2 max(|a|, |b|)
+    const unsigned a = pk_abs(d[i]);
+    acc += max(a & 0xFFFFu, a >> 16);
+  }
+  return 2 * acc;
+}
+// 32-bit twin (12-bit content): d[64] row-major
+__device__ __forceinline__ unsigned had8x8_wide(int (&v)[64])
+{
+#pragma unroll
+  for (int y = 0; y < 8; ++y)
+#pragma unroll
+    for (int hs = 1; hs < 8; hs <<= 1)
+#pragma unroll
+      for (int i = 0; i < 8; i += hs << 1)
+#pragma unroll
+        for (int j = i; j < i + hs; ++j) {
+          const int a = v[8 * y + j], b = v[8 * y + j + hs];
+          v[8 * y + j] = a + b; v[8 * y + j + hs] = a - b;
+        }
+#pragma unroll
+  for (int x = 0; x < 8; ++x)
+#pragma unroll
+    for (int hs = 1; hs < 8; hs <<= 1)
+#pragma unroll
+      for (int i = 0; i < 8; i += hs << 1)
+#pragma unroll
+        for (int j = i; j < i + hs; ++j) {
+          const int a = v[8 * j + x], b = v[8 * (j + hs) + x];
+          v[8 * j + x] = a + b; v[8 * (j + hs) + x] = a - b;
+        }
+  unsigned s = 0;
+#pragma unroll
+  for (int i = 0; i < 64; ++i) s += (unsigned)abs(v[i]);
+  return s;
+}
+
+template <typename T>
+__device__ __forceinline__ int sample_at(const T* plane, long long off) { return (int)plane[off]; }
+
+// T = int16_t (HM Pel planes) or uint8_t; PACKED = bit depth <= 10
+template <typename T, bool PACKED>
+__global__ __launch_bounds__(256) void fhevc_motion_kernel(FhevcFrames F, int range, FhevcMvCost mvc, FhevcMotionNode* __restrict__ out)
+{
+  __shared__ __attribute__((aligned(16))) short s_ref[WIN_ROWS * RP + 8];
+  __shared__ unsigned s_cost[4][4][64], s_satd[4][4][64], s_idx[4][4][64], s_zero[4][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tx = lane & 7, ty = lane >> 3;
+  const int band_rows = F.row_end - F.row_begin;
+  const int per_frame = band_rows * F.ctus_x;
+  const int total = per_frame * (F.num_frames - 1);  // frame f >= 1 is searched in frame f - 1
+  const int side = 2 * range + 1, nmv = side * side, centre = (nmv - 1) >> 1;
+  const int win = 64 + 2 * range;
+  const int shift = F.bit_depth - 8;
+  const T* plane = reinterpret_cast<const T*>(F.luma);
+
+  for (int work = blockIdx.x; work < total; work += gridDim.x) {
+    const int f = 1 + work / per_frame;
+    const int rem = work % per_frame;
+    const int cy = F.row_begin + rem / F.ctus_x, cx = rem % F.ctus_x;
+    const long long cur_base = (long long)f * F.frame_stride, ref_base = (long long)(f - 1) * F.frame_stride;
+    // ---- stage the reference window: rows cy*64 - R .. + win, columns cx*64 - R .. + win, coordinates clamped to the picture ----
+    __syncthreads();  // the previous CTU's readers are done
+    {
+      const int chunks = (win + 7) >> 3;
+      for (int it = tid; it < win * chunks; it += 256) {
+        const int wr = it / chunks, wc = (it - wr * chunks) * 8;
+        const int py = min(max(cy * 64 - range + wr, 0), F.height - 1);
+        const int px0 = cx * 64 - range + wc;
+        short v[8];
+        const long long row = ref_base + (long long)py * F.stride;
+        if (px0 >= 0 && px0 + 8 <= F.width) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = (short)sample_at(plane, row + px0 + k);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = (short)sample_at(plane, row + min(max(px0 + k, 0), F.width - 1));
+        }
+        short* dst = s_ref + wr * RP + wc;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dst[k] = v[k];
+      }
+    }
+    // ---- this lane's original 8x8 tile (all four waves hold the same 64 tiles) ----
+    const int px = cx * 64 + tx * 8, py = cy * 64 + ty * 8;
+    const bool inside = (px + 8 <= F.width) && (py + 8 <= F.height);
+    unsigned O[32];
+    if (inside) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const long long row = cur_base + (long long)(py + j) * F.stride + px;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          O[4 * j + k] = ((unsigned)sample_at(plane, row + 2 * k) & 0xFFFFu) | ((unsigned)sample_at(plane, row + 2 * k + 1) << 16);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 32; ++i) O[i] = 0;
+    }
+    __syncthreads();
+
+    unsigned bc[4], bs[4], bi[4], zero8 = 0;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) { bc[l] = 0xFFFFFFFFu; bs[l] = 0; bi[l] = 0; }
+    unsigned z[4] = { 0, 0, 0, 0 };
+    (void)zero8;
+    for (int m = wave; m < nmv; m += 4) {  // raster order inside a wave; the waves interleave and are merged by (cost, index)
+      const int dy = m / side - range, dx = m % side - range;
+      const int col = tx * 8 + range + dx, row0 = ty * 8 + range + dy;
+      const unsigned sh = (unsigned)(col & 1) * 16u;  // uniform: R + dx
+      unsigned t8;
+      if (PACKED) {
+        unsigned D[32];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const unsigned* q = reinterpret_cast<const unsigned*>(s_ref) + (((row0 + j) * RP + col) >> 1);
+          const unsigned d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
+          D[4 * j + 0] = pk_sub(O[4 * j + 0], __builtin_amdgcn_alignbit(d1, d0, sh));
+          D[4 * j + 1] = pk_sub(O[4 * j + 1], __builtin_amdgcn_alignbit(d2, d1, sh));
+          D[4 * j + 2] = pk_sub(O[4 * j + 2], __builtin_amdgcn_alignbit(d3, d2, sh));
+          D[4 * j + 3] = pk_sub(O[4 * j + 3], __builtin_amdgcn_alignbit(d4, d3, sh));
+        }
+        t8 = had8x8_packed(D);
+      } else {
+        int v[64];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const unsigned o = O[4 * j + (k >> 1)];
+            const int os = (k & 1) ? (int)(short)(o >> 16) : (int)(short)(o & 0xFFFFu);
+            v[8 * j + k] = os - (int)s_ref[(row0 + j) * RP + col + k];
+          }
+        t8 = had8x8_wide(v);
+      }
+      t8 = inside ? ((t8 + 2) >> 2) : 0u;  // xCalcHADs8x8: (sum + 2) >> 2 (TComRdCost.cpp:1747)
+      // node sums: 16x16 = tiles (tx ^ 1, ty ^ 1), 32x32 = + bits 1, 64x64 = + bits 2
+      unsigned s[4];
+      s[3] = t8;
+      unsigned a = t8 + __shfl_xor(t8, 1);
+      s[2] = a + __shfl_xor(a, 8);
+      a = s[2] + __shfl_xor(s[2], 2);
+      s[1] = a + __shfl_xor(a, 16);
+      a = s[1] + __shfl_xor(s[1], 4);
+      s[0] = a + __shfl_xor(a, 32);
+      const unsigned vc = mvc.c[m];
+#pragma unroll
+      for (int l = 0; l < 4; ++l) {
+        const unsigned sd = s[l] >> shift;  // DISTORTION_PRECISION_ADJUSTMENT on the block's sum (TComRdCost.cpp:1823)
+        const unsigned c = sd + vc;
+        if (m == centre) z[l] = sd;
+        if (c < bc[l]) { bc[l] = c; bs[l] = sd; bi[l] = (unsigned)m; }
+      }
+    }
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      s_cost[wave][l][lane] = bc[l]; s_satd[wave][l][lane] = bs[l]; s_idx[wave][l][lane] = bi[l];
+      if ((centre & 3) == wave) s_zero[l][lane] = z[l];
+    }
+    __syncthreads();
+    if (tid < FHEVC_NODES) {
+      int l, ni;
+      if (tid == 0) { l = 0; ni = 0; } else if (tid < 5) { l = 1; ni = tid - 1; } else if (tid < 21) { l = 2; ni = tid - 5; } else { l = 3; ni = tid - 21; }
+      const int n = 64 >> l, cnt = 1 << l, tn = n >> 3;
+      const int bx = ni % cnt, by = ni / cnt;
+      const int rep = (by * tn) * 8 + bx * tn;  // a lane of the node (all of them hold the node's sums)
+      FhevcMotionNode o;
+      if (cx * 64 + bx * n + n > F.width || cy * 64 + by * n + n > F.height) {
+        o.satd_zero = o.satd_best = o.cost_best = 0xFFFFFFFFu; o.mvx = 0; o.mvy = 0;
+      } else {
+        unsigned c = s_cost[0][l][rep], sd = s_satd[0][l][rep], ix = s_idx[0][l][rep];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+          const unsigned c2 = s_cost[w][l][rep], i2 = s_idx[w][l][rep];
+          if (c2 < c || (c2 == c && i2 < ix)) { c = c2; ix = i2; sd = s_satd[w][l][rep]; }
+        }
+        o.satd_zero = s_zero[l][rep]; o.satd_best = sd; o.cost_best = c;
+        o.mvx = (short)((int)(ix % side) - range); o.mvy = (short)((int)(ix / side) - range);
+      }
+      const long long oc = (long long)((f - 1) * band_rows + (cy - F.row_begin)) * F.ctus_x + cx;
+      out[oc * FHEVC_NODES + tid] = o;
+    }
+  }
+}
+
+}  // namespace
+
+hipError_t fhevc_launch_motion(const FhevcFrames& fr, int range, const FhevcMvCost& mvc, FhevcMotionNode* d_out, int num_cus, hipStream_t stream)
+{
+  const long long total = (long long)(fr.row_end - fr.row_begin) * fr.ctus_x * (fr.num_frames - 1);
+  if (total <= 0) return hipSuccess;
+  const int grid = (int)(total < 4LL * num_cus ? total : 4LL * num_cus);
+  if (fr.sample_bytes == 2 && fr.bit_depth <= 10)
+    hipLaunchKernelGGL((fhevc_motion_kernel<int16_t, true>), dim3(grid), dim3(256), 0, stream, fr, range, mvc, d_out);
+  else if (fr.sample_bytes == 2)
+    hipLaunchKernelGGL((fhevc_motion_kernel<int16_t, false>), dim3(grid), dim3(256), 0, stream, fr, range, mvc, d_out);
+  else
+    hipLaunchKernelGGL((fhevc_motion_kernel<uint8_t, true>), dim3(grid), dim3(256), 0, stream, fr, range, mvc, d_out);
+  return hipGetLastError();
+}

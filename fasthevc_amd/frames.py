@@ -196,6 +196,22 @@ def deadleaves_luma(width, height, seed=777, leaves=900):
     return np.clip(np.rint(_box_blur(y, 3)), 0, 255).astype(np.uint8)
 
 
+def pan_clip(width, height, nframes=4, seed=1234, v_structure=3, v_noise=3):
+    """SURVEY Appendix B's config-4 clip (texture16 content): texture mask and noise drawn once; base and edges move
+    v_structure px per frame one way, the noise v_noise px per frame the other way (two overlaid motions), flat chroma.
+    -> list of uint8 [H, W].  The defaults are the pinned clip."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:height, 0:width]
+    tex = rng.integers(0, 2, size=(height // 16 + 1, width // 16 + 1)).repeat(16, 0).repeat(16, 1)[:height, :width]
+    noise = rng.normal(0, 18, size=(height, width)) * tex
+    out = []
+    for f in range(nframes):
+        base = 128 + 60 * np.sin((xx + v_structure * f) / 37.0) * np.cos(yy / 23.0)
+        edges = (((xx + v_structure * f) // 48 + yy // 40) % 2) * 30
+        out.append(np.clip(base + np.roll(noise, v_noise * f, axis=1) + edges, 0, 255).astype(np.uint8))
+    return out
+
+
 def to_pel_plane(luma_u8, internal_bit_depth=8, margin=HM_MARGIN):
     """uint8 luma -> int16 `Pel` plane laid out like TComPicYuv (TComPicYuv.cpp:81-119): stride = W + 2*margin,
     origin at (margin, margin), samples left-shifted to the internal bit depth (TVideoIOYuv.cpp:70-84,730).

@@ -159,11 +159,34 @@ int  fhevc_preanalyze_frames_device(fhevc_ctx* ctx, const void* d_luma, int samp
                                     long long frame_stride_samples, int num_frames, int ctu_row_begin, int ctu_row_end,
                                     int max_aq_depth, double* d_activity, void* stream);
 
+/* ---- config 4 (P slices): source-only motion search per CU node ----------------------------------------------------
+ * For every CU node of every CTU (node order as fhevc_node_cost): integer full search over [-search_range, search_range]^2
+ * in the PREVIOUS ORIGINAL picture, raster order and strict "<" as TEncSearch::xPatternSearch (TEncSearch.cpp:3786-3848),
+ * cost = Hadamard SATD (TComRdCost::xGetHADs, the distortion HM uses under HADME) + TComRdCost::getCostOfVectorWithPredictor
+ * (TComRdCost.h:166-174; zero predictor, lambda of slice QP qp), samples outside the picture replicated from the border
+ * (TComPicYuv::extendPicBorder).  HM's own search runs on reconstructed references inside its serial CTU loop; this is
+ * its source-only twin, available for the whole picture before that loop starts.  search_range 1..8. */
+#define FHEVC_MOTION_MAX_RANGE 8
+typedef struct {
+  uint32_t satd_zero;       /* SATD at vector (0, 0) */
+  uint32_t satd_best;       /* SATD at the cheapest vector */
+  uint32_t cost_best;       /* its SATD + vector cost; 0xFFFFFFFF in all three for nodes crossing the picture edge */
+  int16_t  mvx, mvy;        /* the cheapest vector, integer samples */
+} fhevc_motion_node;
+/* one picture pair, host buffers (both planes with the same stride), synchronous; out: numCtus * 85 */
+int  fhevc_motion_search(fhevc_ctx* ctx, const int16_t* cur_luma, const int16_t* ref_luma, int stride_samples, int qp,
+                         int search_range, fhevc_motion_node* out);
+/* device-resident batch (layout as fhevc_predict_frames_device): frame f = 1 .. num_frames-1 is searched in frame f-1;
+ * d_out: (num_frames - 1) * band CTUs * 85 nodes in HBM */
+int  fhevc_motion_search_device(fhevc_ctx* ctx, const void* d_luma, int sample_bytes, int stride_samples,
+                                long long frame_stride_samples, int num_frames, int ctu_row_begin, int ctu_row_end,
+                                int qp, int search_range, fhevc_motion_node* d_out, void* stream);
+
 /* CTU-row band of rank `rank` out of `world`: rows [begin, end) */
 int  fhevc_band(int ctu_rows, int rank, int world, int* begin, int* end);
 
 /* average duration in ms of the dominant kernels over launches since the last reset, measured with HIP
- * events on the launch stream; which: 0 = depth CNN, 1 = source Hadamard, 2 = first pass, 3 = pre-analysis */
+ * events on the launch stream; which: 0 = depth CNN, 1 = source Hadamard, 2 = first pass, 3 = pre-analysis, 4 = motion search */
 int  fhevc_kernel_timing(fhevc_ctx* ctx, int which, int reset, double* avg_ms, uint64_t* launches);
 int  fhevc_enable_kernel_timing(fhevc_ctx* ctx, int on);
 

@@ -490,6 +490,66 @@ void fho_first_pass_ctu(const int16_t* luma, int stride, int width, int height,
 }
 
 /* ------------------------------------------------------------------------------------------
+ * A13 / N4: source-only integer motion search per CU node (config 4).  Search loop as TEncSearch::xPatternSearch
+ * (TEncSearch.cpp:3786-3848): y outer, x inner, strict "<"; vector cost as TComRdCost::getCostOfVectorWithPredictor
+ * (TComRdCost.h:166-174) with a zero predictor and iCostScale 2; distortion = xGetHADs (8x8 tiles).
+ * ------------------------------------------------------------------------------------------ */
+static unsigned exp_golomb_bits(int v) /* TComRdCost.cpp:177-190 */
+{
+  unsigned len = 1;
+  unsigned t = (v <= 0) ? (((unsigned)(-v)) << 1) + 1 : ((unsigned)v) << 1;
+  while (t != 1) { t >>= 1; len += 2; }
+  return len;
+}
+uint32_t fho_mv_cost(int x, int y, double sqrt_lambda)
+{
+  const double motion_lambda = 65536.0 * sqrt_lambda;  /* m_dLambdaMotionSAD[0], TComRdCost.cpp:113 */
+  const unsigned bits = exp_golomb_bits(x << 2) + exp_golomb_bits(y << 2);
+  return (uint32_t)((motion_lambda * bits) / 65536.0);
+}
+void fho_motion_ctu(const int16_t* cur, int cs, const int16_t* ref, int rs, int width, int height,
+                    int ctu_x, int ctu_y, int bit_depth, int range, double sqrt_lambda, fho_motion_node out[85])
+{
+  static uint32_t tile[17 * 17][64]; /* [mv][tile], not re-entrant: test infrastructure */
+  const int side = 2 * range + 1, x0 = ctu_x * CTU, y0 = ctu_y * CTU;
+  for (int m = 0; m < side * side; m++) {
+    const int dy = m / side - range, dx = m % side - range;
+    for (int t = 0; t < 64; t++) {
+      const int tx = x0 + (t & 7) * 8, ty = y0 + (t >> 3) * 8;
+      if (tx + 8 > width || ty + 8 > height) { tile[m][t] = 0; continue; }
+      int16_t blk[64]; /* the displaced reference block, border samples replicated (extendPicBorder) */
+      for (int y = 0; y < 8; y++)
+        for (int x = 0; x < 8; x++)
+          blk[y * 8 + x] = ref[clip3(0, height - 1, ty + y + dy) * rs + clip3(0, width - 1, tx + x + dx)];
+      tile[m][t] = fho_had8x8(cur + ty * cs + tx, cs, blk, 8);
+    }
+  }
+  int idx = 0;
+  for (int lvl = 0; lvl < 4; lvl++) {
+    const int n = CTU >> lvl, cnt = 1 << lvl, tn = n / 8;
+    for (int by = 0; by < cnt; by++)
+      for (int bx = 0; bx < cnt; bx++, idx++) {
+        fho_motion_node* o = &out[idx];
+        if (x0 + bx * n + n > width || y0 + by * n + n > height) {
+          o->satd_zero = o->satd_best = o->cost_best = 0xFFFFFFFFu; o->mvx = o->mvy = 0;
+          continue;
+        }
+        uint32_t best = 0xFFFFFFFFu;
+        for (int m = 0; m < side * side; m++) {
+          const int dy = m / side - range, dx = m % side - range;
+          uint32_t s = 0;
+          for (int j = 0; j < tn; j++)
+            for (int i = 0; i < tn; i++) s += tile[m][(by * tn + j) * 8 + bx * tn + i];
+          s >>= (bit_depth - 8);
+          if (dx == 0 && dy == 0) o->satd_zero = s;
+          const uint32_t c = s + fho_mv_cost(dx, dy, sqrt_lambda);
+          if (c < best) { best = c; o->cost_best = c; o->satd_best = s; o->mvx = (int16_t)dx; o->mvy = (int16_t)dy; }
+        }
+      }
+  }
+}
+
+/* ------------------------------------------------------------------------------------------
  * A15: depth classifier (integer-valued).
  * ------------------------------------------------------------------------------------------ */
 static inline uint8_t requant(int32_t acc, int shift)

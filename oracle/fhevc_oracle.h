@@ -100,6 +100,23 @@ void fho_first_pass_node(const int16_t* luma, int stride, int width, int height,
 void fho_first_pass_ctu(const int16_t* luma, int stride, int width, int height,
                         int ctu_x, int ctu_y, int bit_depth, double sqrt_lambda, fho_node_cost out[85]);
 
+/* ---- A13 / N4 (config 4): source-only motion search per CU node -------------------------------
+ * Twin of the integer full search TEncSearch::xPatternSearch (TEncSearch.cpp:3786-3848: raster order over the window,
+ * strict "<", cost = distortion + TComRdCost::getCostOfVectorWithPredictor, TComRdCost.h:166-174) with the Hadamard
+ * distortion HM uses under HADME (TComRdCost::xGetHADs, TComRdCost.cpp:1753-1824; setDistParam(..., bHadamard),
+ * TEncSearch.cpp:836) -- evaluated against the PREVIOUS ORIGINAL picture instead of the reconstructed reference (that
+ * one exists only inside HM's serial loop), zero motion-vector predictor, samples outside the picture replicated from
+ * the border as TComPicYuv::extendPicBorder does (TComPicYuv.cpp:229-270).  The depth decision of a P picture reads
+ * these costs next to the co-located depths of its reference picture (TEncFastDepth::predictPicture). */
+typedef struct { uint32_t satd_zero, satd_best, cost_best; int16_t mvx, mvy; } fho_motion_node;
+/* cost of vector (x, y) in integer samples: Distortion((m_motionLambda * bits) / 65536.0) with m_motionLambda =
+ * 65536 * sqrt(lambda) (TComRdCost.cpp:109-114), bits = xGetExpGolombNumberOfBits(x << 2) + ...(y << 2)
+ * (quarter-sample units, TComRdCost.cpp:177-190), zero predictor */
+uint32_t fho_mv_cost(int x, int y, double sqrt_lambda);
+/* one CTU: out[85] in the node order of fho_first_pass_ctu; nodes crossing the picture edge get 0xFFFFFFFF / mv 0.
+ * range <= 8.  cost of a node at mv = (sum of its 8x8 tile SATDs >> (bit_depth - 8)) + fho_mv_cost(mv). */
+void fho_motion_ctu(const int16_t* cur, int cur_stride, const int16_t* ref, int ref_stride, int width, int height,
+                    int ctu_x, int ctu_y, int bit_depth, int range, double sqrt_lambda, fho_motion_node out[85]);
 /* ---- A15: depth classifier, integer-valued restatement --------------------------------- */
 /* Architecture follows matlab/dataExtraction/Train...Example.m:75-96 run convolutionally on the
  * 64x64 CTU: conv3x3x16 pad1 -> ReLU -> maxpool2 -> conv3x3x32 pad1 -> ReLU -> maxpool2 ->

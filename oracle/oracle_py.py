@@ -74,6 +74,11 @@ def load_oracle():
     lib.fho_aq_qp.restype = C.c_int
     lib.fho_lambda_intra.argtypes = [C.c_int, C.c_int]
     lib.fho_lambda_intra.restype = C.c_double
+    lib.fho_mv_cost.argtypes = [C.c_int, C.c_int, C.c_double]
+    lib.fho_mv_cost.restype = C.c_uint32
+    lib.fho_motion_ctu.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_double, C.c_void_p]
+    lib.fho_motion_ctu.restype = None
     lib.fho_fill_ref.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _i16p]
     lib.fho_fill_ref_flags.argtypes = [C.c_void_p, C.c_int, _u8p, C.c_int, C.c_int, _i16p]
     lib.fho_filter_ref.argtypes = [_i16p, C.c_int, C.c_int, C.c_int, _i16p]

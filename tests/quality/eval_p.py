@@ -41,18 +41,7 @@ def load_p():
 
 
 def pan_clip(W, H, nframes=2, seed=1234):
-    """SURVEY Appendix B's config-4 clip: texture and noise drawn once, noise rolled 3 px per frame, base and edges evaluated
-    at x + 3f, flat chroma."""
-    rng = np.random.default_rng(seed)
-    yy, xx = np.mgrid[0:H, 0:W]
-    tex = rng.integers(0, 2, size=(H // 16 + 1, W // 16 + 1)).repeat(16, 0).repeat(16, 1)[:H, :W]
-    noise = rng.normal(0, 18, size=(H, W)) * tex
-    out = []
-    for f in range(nframes):
-        base = 128 + 60 * np.sin((xx + 3 * f) / 37.0) * np.cos(yy / 23.0)
-        edges = (((xx + 3 * f) // 48 + yy // 40) % 2) * 30
-        out.append(np.clip(base + np.roll(noise, 3 * f, axis=1) + edges, 0, 255).astype(np.uint8))
-    return out
+    return frames.pan_clip(W, H, nframes, seed)
 
 
 def cnn_ranges(oracle, ws, y, qp, margin_split, margin_stop):

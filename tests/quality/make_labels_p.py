@@ -26,6 +26,8 @@ W, H = 1024, 576
 
 def clip(seed):
     rng = np.random.default_rng(90_000 + seed)
+    if seed >= 1000:  # two overlaid motions (structure one way, noise the other), as in the config-4 evaluation clip
+        return frames.pan_clip(W, H, 4, seed=70_000 + seed, v_structure=int(rng.integers(-4, 5)), v_noise=int(rng.integers(-4, 5)))
     gen = [frames.hetero_luma, frames.texture16_luma, frames.fractal_luma, frames.gratings_luma, frames.polygon_luma,
            frames.chirp_luma, frames.deadleaves_luma][seed % 7]
     big = gen(W + 64, H + 64, seed=80_000 + seed)

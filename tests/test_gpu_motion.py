@@ -1,0 +1,94 @@
+"""Config 4 (P slices): the source-only motion search per CU node on the MI355X against the CPU oracle (fho_motion_ctu),
+bit for bit: SATD at zero motion, cheapest vector, its SATD and cost, for all 85 nodes of every CTU."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from fasthevc_amd import capi, frames
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_motion(oracle, cur, ref, origin, stride, W, H, bd, qp, rng, ctus=None):
+    cw, ch = (W + 63) // 64, (H + 63) // 64
+    out = np.zeros((cw * ch, 85), capi.MOTION_DTYPE)
+    sl = oracle.fho_lambda_intra(qp, bd) ** 0.5
+    cp, rp = cur.reshape(-1).ctypes.data + 2 * origin, ref.reshape(-1).ctypes.data + 2 * origin
+    for c in (range(cw * ch) if ctus is None else ctus):
+        oracle.fho_motion_ctu(C.c_void_p(cp), stride, C.c_void_p(rp), stride, W, H, c % cw, c // cw, bd, rng, C.c_double(sl),
+                              C.c_void_p(out[c].ctypes.data))
+    return out
+
+
+def same(a, b):
+    return all(np.array_equal(a[k], b[k]) for k in capi.MOTION_DTYPE.names)
+
+
+@pytest.mark.parametrize("bd,rng,qp", [(8, 4, 38), (8, 1, 22), (8, 8, 43), (10, 3, 33), (12, 2, 38)])
+def test_motion_search_vs_oracle_small(oracle, bd, rng, qp):
+    W, H = 416, 240  # ragged: last CTU column 32 wide, last row 48 tall
+    ys = frames.pan_clip(W, H, 2, seed=7 + bd)
+    planes = [frames.to_pel_plane(y, bd) for y in ys]
+    (rb, org, stride), (cb, _, _) = planes
+    if bd > 8:  # use the low bits too
+        noise = np.random.default_rng(bd).integers(0, 1 << (bd - 8), size=cb.shape, dtype=np.int16)
+        cb = (cb + noise).astype(np.int16)
+    ctx = capi.Context(W, H, bd)
+    got = ctx.motion_search(cb, rb, org, stride, qp=qp, search_range=rng)
+    exp = oracle_motion(oracle, cb, rb, org, stride, W, H, bd, qp, rng)
+    assert same(got, exp)
+    # border nodes are flagged, interior ones are not
+    assert got["cost_best"][6, 0] == 0xFFFFFFFF and got["cost_best"][0, 0] != 0xFFFFFFFF
+    ctx.close()
+
+
+def test_motion_search_finds_a_pure_pan(oracle):
+    W, H = 256, 192
+    base = frames.hetero_luma(W + 16, H + 16, seed=99)
+    ref, cur = base[8:8 + H, 8:8 + W], base[6:6 + H, 11:11 + W]   # cur(x, y) = ref(x + 3, y - 2)
+    (rb, org, stride), (cb, _, _) = frames.to_pel_plane(np.ascontiguousarray(ref), 8), frames.to_pel_plane(np.ascontiguousarray(cur), 8)
+    ctx = capi.Context(W, H, 8)
+    got = ctx.motion_search(cb, rb, org, stride, qp=30, search_range=4)
+    inner = got[5]  # CTU (1, 1): no border replication inside the window
+    assert (inner["mvx"] == 3).all() and (inner["mvy"] == -2).all() and (inner["satd_best"] == 0).all()
+    assert (inner["satd_zero"] > 0).any()
+    ctx.close()
+
+
+def test_motion_search_1080p_device_batch(oracle):
+    """BASELINE config 4 geometry: the 1080p pan clip I P P P as a device-resident batch (uint8 planes and HM int16 planes),
+    whole pictures and a CTU-row band; oracle on a sample of CTUs of every picture pair."""
+    import torch
+    assert torch.cuda.is_available()
+    dev = torch.device("cuda:0")
+    W, H, NF, qp, rng = 1920, 1080, 4, 38, 4
+    ys = frames.pan_clip(W, H, NF)
+    ctx = capi.Context(W, H, 8, max_frames=NF)
+    n = ctx.num_ctus
+    d8 = torch.from_numpy(np.stack(ys)).to(dev)
+    out8 = torch.zeros(((NF - 1) * n * 85, 4), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ctx.motion_search_device(d8.data_ptr(), 1, W, W * H, NF, out8.data_ptr(), qp=qp, search_range=rng)
+    planes = [frames.to_pel_plane(y, 8) for y in ys]
+    org, stride = planes[0][1], planes[0][2]
+    d16 = torch.from_numpy(np.stack([p[0] for p in planes])).to(dev)
+    out16 = torch.zeros_like(out8)
+    band = torch.zeros(((NF - 1) * 3 * ctx.ctus_x * 85, 4), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    fs = planes[0][0].size
+    ctx.motion_search_device(d16.data_ptr() + 2 * org, 2, stride, fs, NF, out16.data_ptr(), qp=qp, search_range=rng)
+    ctx.motion_search_device(d16.data_ptr() + 2 * org, 2, stride, fs, NF, band.data_ptr(), rows=(14, 17), qp=qp, search_range=rng)
+    torch.cuda.synchronize()
+    g8 = out8.cpu().numpy().view(capi.MOTION_DTYPE).reshape(NF - 1, n, 85)
+    g16 = out16.cpu().numpy().view(capi.MOTION_DTYPE).reshape(NF - 1, n, 85)
+    gb = band.cpu().numpy().view(capi.MOTION_DTYPE).reshape(NF - 1, 3 * ctx.ctus_x, 85)
+    assert same(g8, g16) and same(gb, g16[:, 14 * ctx.ctus_x:17 * ctx.ctus_x])
+    sample = sorted(set(np.random.default_rng(5).integers(0, n, 40).tolist()) | {0, 29, n - 30, n - 1})
+    for f in range(1, NF):
+        exp = oracle_motion(oracle, planes[f][0], planes[f - 1][0], org, stride, W, H, 8, qp, rng, ctus=sample)
+        assert same(g16[f - 1][sample], exp[sample]), f
+    # the clip's two motions (noise 3 px one way, structure 3 px the other) both show up among the 8x8 nodes
+    mv = g16[0][:, 21:]["mvx"][g16[0][:, 21:]["cost_best"] != 0xFFFFFFFF]
+    assert (mv == -3).mean() > 0.2 and (mv == 3).any() and (mv == 0).any()
+    ctx.close()

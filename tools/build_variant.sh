@@ -10,7 +10,7 @@ if [ "$REV" = WORK ]; then cp "$ROOT"/fasthevc_amd/csrc/* "$T/csrc/"; cp "$ROOT"
 else for f in $(git -C "$ROOT" ls-tree --name-only "$REV" fasthevc_amd/csrc/ include/); do git -C "$ROOT" show "$REV:$f" > "$T/$( [ "${f#include/}" != "$f" ] && echo include || echo csrc)/$(basename $f)"; done; fi
 sed -i 's|#include "../../include/fasthevc.h"|#include "../include/fasthevc.h"|' "$T"/csrc/* 2>/dev/null || true
 cd "$T/csrc"
-for s in fhevc_api k_cnn k_hadamard k_firstpass k_preanalyze; do
+for s in $(cd "$T/csrc" && ls *.hip | sed "s/.hip//"); do
   X=""; [ $s = k_cnn ] && X="-ffinite-math-only -fno-signed-zeros"
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -w $X -I"$T/include" -c $s.hip -o $s.o &
 done
