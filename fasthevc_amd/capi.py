@@ -24,7 +24,7 @@ SYMBOLS = [
     "fhevc_enable_kernel_timing", "fhevc_get_stats", "fhevc_last_error", "fhevc_version",
     "fhevc_expand_depth_flags_device", "fhevc_aq_parts", "fhevc_preanalyze", "fhevc_preanalyze_frames_device", "fhevc_aq_qp", "fhevc_intra_first_pass_device",
     "fhevc_predict_frame_range", "fhevc_predict_frames_device_range",
-    "fhevc_motion_search", "fhevc_motion_search_device",
+    "fhevc_motion_search", "fhevc_motion_search_device", "fhevc_intra_first_pass_all",
 ]
 
 
@@ -98,6 +98,7 @@ def load_library():
                                                       C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
     lib.fhevc_satd.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32)]
     lib.fhevc_intra_first_pass.argtypes = [vp, vp, C.c_int, C.c_int, vp]
+    lib.fhevc_intra_first_pass_all.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
     lib.fhevc_intra_first_pass_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_int,
                                                   C.c_int, vp, vp]
     lib.fhevc_predict_frames_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_int,
@@ -218,6 +219,15 @@ class Context:
         rb, re = rows if rows is not None else (0, self.ctus_y)
         self._check(self.lib.fhevc_motion_search_device(self.h, d_luma, sample_bytes, stride, frame_stride, num_frames, rb, re, qp,
                                                         search_range, d_out, stream))
+
+    def intra_first_pass_all(self, plane, origin=0, stride=None, qp=32):
+        """(best [numCtus, 85], all [numCtus, 85, 35]): every mode's SATD and cost per node (parity entry point)"""
+        flat = np.ascontiguousarray(plane).reshape(-1)
+        stride = stride if stride is not None else plane.shape[-1]
+        best = np.zeros(self.num_ctus * NODES_PER_CTU, NODE_DTYPE)
+        allm = np.zeros(self.num_ctus * NODES_PER_CTU * 35, NODE_DTYPE)
+        self._check(self.lib.fhevc_intra_first_pass_all(self.h, flat.ctypes.data + 2 * origin, stride, qp, best.ctypes.data, allm.ctypes.data))
+        return best.reshape(self.num_ctus, NODES_PER_CTU), allm.reshape(self.num_ctus, NODES_PER_CTU, 35)
 
     def aq_layout(self, max_aq_depth):
         """Offsets of the AQ layers in the concatenated activity array (max_aq_depth + 1 entries)."""

@@ -497,13 +497,35 @@ int fhevc_intra_first_pass(fhevc_ctx* c, const int16_t* luma, int stride_samples
   const double sqrt_lambda = std::sqrt(0.57 * std::pow(2.0, ((double)qp - 12.0) / 3.0));
   const FhevcFrames fr = frames_of(c, c->d_luma, 2, c->dev_stride, 0, 1, 0, c->ctus_y);
   time_begin(c, c->stream, 2);
-  HIP_TRY(c, fhevc_launch_first_pass(fr, sqrt_lambda, c->d_nodes, c->stream));
+  HIP_TRY(c, fhevc_launch_first_pass(fr, sqrt_lambda, c->d_nodes, nullptr, c->stream));
   time_end(c, c->stream);
   static_assert(sizeof(fhevc_node_cost) == sizeof(FhevcNodeCost), "node cost layout");
   HIP_TRY(c, hipMemcpyAsync(out, c->d_nodes, (size_t)c->num_ctus * FHEVC_NODES_PER_CTU * sizeof(FhevcNodeCost), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->stats.kernels_launched++;
   return FHEVC_OK;
+}
+
+int fhevc_intra_first_pass_all(fhevc_ctx* c, const int16_t* luma, int stride_samples, int qp, fhevc_node_cost* best, fhevc_node_cost* all)
+{
+  if (!c || !luma || !all || stride_samples < c->cfg.width || qp < 0 || qp > 51) return FHEVC_E_INVALID;
+  (void)hipSetDevice(c->device);
+  const size_t n_all = (size_t)c->num_ctus * FHEVC_NODES_PER_CTU * 35;
+  FhevcNodeCost* d_all = nullptr;  // a parity entry point: allocated per call
+  HIP_TRY(c, hipMalloc(&d_all, n_all * sizeof(FhevcNodeCost)));
+  int rc = upload_frame(c, luma, stride_samples);
+  if (rc == FHEVC_OK) {
+    const double sqrt_lambda = std::sqrt(0.57 * std::pow(2.0, ((double)qp - 12.0) / 3.0));
+    const FhevcFrames fr = frames_of(c, c->d_luma, 2, c->dev_stride, 0, 1, 0, c->ctus_y);
+    hipError_t e = fhevc_launch_first_pass(fr, sqrt_lambda, c->d_nodes, d_all, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(all, d_all, n_all * sizeof(FhevcNodeCost), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && best) e = hipMemcpyAsync(best, c->d_nodes, (size_t)c->num_ctus * FHEVC_NODES_PER_CTU * sizeof(FhevcNodeCost), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) rc = fail(c, FHEVC_E_HIP, "first pass (all modes)", e);
+  }
+  (void)hipFree(d_all);
+  c->stats.kernels_launched++;
+  return rc;
 }
 
 int fhevc_aq_parts(int width, int height, int max_aq_depth, long long* layer_offsets)
@@ -598,7 +620,7 @@ int fhevc_intra_first_pass_device(fhevc_ctx* c, const void* d_luma, int sample_b
   const double sqrt_lambda = std::sqrt(0.57 * std::pow(2.0, ((double)qp - 12.0) / 3.0));
   const FhevcFrames fr = frames_of(c, d_luma, sample_bytes, stride_samples, frame_stride_samples, num_frames, ctu_row_begin, ctu_row_end);
   time_begin(c, st, 2);
-  HIP_TRY(c, fhevc_launch_first_pass(fr, sqrt_lambda, reinterpret_cast<FhevcNodeCost*>(d_out), st));
+  HIP_TRY(c, fhevc_launch_first_pass(fr, sqrt_lambda, reinterpret_cast<FhevcNodeCost*>(d_out), nullptr, st));
   time_end(c, st);
   c->stats.kernels_launched++;
   return FHEVC_OK;

@@ -53,7 +53,8 @@ hipError_t fhevc_launch_satd(const int16_t* d_org, int org_stride, const int16_t
 
 // ---- 35-mode first pass (k_firstpass.hip) ------------------------------------------------------------------
 struct FhevcNodeCost { uint32_t satd; uint32_t mode; double cost; };
-hipError_t fhevc_launch_first_pass(const FhevcFrames& fr, double sqrt_lambda, FhevcNodeCost* d_out, hipStream_t stream);
+// d_all (optional): every (node, mode) pair, [CTU][85][35] -- the parity output behind fhevc_intra_first_pass_all
+hipError_t fhevc_launch_first_pass(const FhevcFrames& fr, double sqrt_lambda, FhevcNodeCost* d_out, FhevcNodeCost* d_all, hipStream_t stream);
 
 // ---- source-only motion search per CU node (k_motion.hip; config 4) -----------------------------------------
 #define FHEVC_NODES 85

@@ -224,7 +224,7 @@ __device__ __forceinline__ int satd8x8(const unsigned (&o)[32], const unsigned (
 
 template <typename T, bool PACKED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PACKED ? 3 : 1, PACKED ? 3 : 2))) void fhevc_first_pass_kernel(FhevcFrames F, double sqrt_lambda,
-                                                                FhevcNodeCost* __restrict__ out)
+                                                                FhevcNodeCost* __restrict__ out, FhevcNodeCost* __restrict__ out_all)
 {
   // s_org holds the CTU while the lines are built; afterwards the same bytes are the four per-wave projected references
   __shared__ __attribute__((aligned(16))) short s_org[4 * kMainPerWave];
@@ -520,23 +520,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PACKED ? 3 
       const long long o = (long long)(f * band_rows + (cy - F.row_begin)) * F.ctus_x + cx;
       out[o * 85 + tid] = r;
     }
+    if (out_all != nullptr) {  // parity output: every (node, mode) pair, not only the winner
+      const long long o = (long long)(f * band_rows + (cy - F.row_begin)) * F.ctus_x + cx;
+      for (int i = tid; i < 85 * 35; i += 256) {
+        const int node = i / 35, m = i - node * 35;
+        FhevcNodeCost r;
+        if (!s_valid[node]) { r.satd = 0xFFFFFFFFu; r.mode = 255; r.cost = -1.0; }
+        else {
+          r.satd = (unsigned)s_satd[i] >> (bd - 8);
+          r.mode = (unsigned)m;
+          const int bits = (m == 0) ? 2 : ((m == 1 || m == 26) ? 3 : 6);
+          r.cost = __dadd_rn((double)r.satd, __dmul_rn((double)bits, sqrt_lambda));
+        }
+        out_all[o * (85 * 35) + i] = r;
+      }
+    }
     __syncthreads();
   }
 }
 
 }  // namespace
 
-hipError_t fhevc_launch_first_pass(const FhevcFrames& fr, double sqrt_lambda, FhevcNodeCost* d_out, hipStream_t stream)
+hipError_t fhevc_launch_first_pass(const FhevcFrames& fr, double sqrt_lambda, FhevcNodeCost* d_out, FhevcNodeCost* d_all, hipStream_t stream)
 {
   const long long total = (long long)(fr.row_end - fr.row_begin) * fr.ctus_x * fr.num_frames;
   if (total <= 0) return hipSuccess;
   const int grid = (int)(total < 2048 ? total : 2048);
   const bool packed = fr.bit_depth <= 10;
   if (fr.sample_bytes == 2) {
-    if (packed) hipLaunchKernelGGL((fhevc_first_pass_kernel<int16_t, true>), dim3(grid), dim3(256), 0, stream, fr, sqrt_lambda, d_out);
-    else hipLaunchKernelGGL((fhevc_first_pass_kernel<int16_t, false>), dim3(grid), dim3(256), 0, stream, fr, sqrt_lambda, d_out);
+    if (packed) hipLaunchKernelGGL((fhevc_first_pass_kernel<int16_t, true>), dim3(grid), dim3(256), 0, stream, fr, sqrt_lambda, d_out, d_all);
+    else hipLaunchKernelGGL((fhevc_first_pass_kernel<int16_t, false>), dim3(grid), dim3(256), 0, stream, fr, sqrt_lambda, d_out, d_all);
   } else {
-    hipLaunchKernelGGL((fhevc_first_pass_kernel<uint8_t, true>), dim3(grid), dim3(256), 0, stream, fr, sqrt_lambda, d_out);
+    hipLaunchKernelGGL((fhevc_first_pass_kernel<uint8_t, true>), dim3(grid), dim3(256), 0, stream, fr, sqrt_lambda, d_out, d_all);
   }
   return hipGetLastError();
 }

@@ -108,6 +108,13 @@ int  fhevc_satd(fhevc_ctx* ctx, const int16_t* org, int org_stride, const int16_
  * (TEncSlice.cpp:433-527) would give it for qp; pass qp. */
 int  fhevc_intra_first_pass(fhevc_ctx* ctx, const int16_t* luma, int stride_samples, int qp, fhevc_node_cost* out);
 
+/* Parity entry point: the same pass, returning EVERY (node, mode) pair -- all: numCtus * 85 * 35 entries, [CTU][node][mode]
+ * with satd = xGetHADs of that mode's prediction, mode = the mode, cost = satd + modeBits * sqrt(lambda) (nodes crossing the
+ * picture edge: satd 0xFFFFFFFF, mode 255, cost -1); best (optional) as fhevc_intra_first_pass.  Lets a test see the
+ * predictors and SATDs of modes that never win. */
+int  fhevc_intra_first_pass_all(fhevc_ctx* ctx, const int16_t* luma, int stride_samples, int qp, fhevc_node_cost* best,
+                                fhevc_node_cost* all);
+
 /* first pass over a device-resident batch (layout and band arguments as fhevc_predict_frames_device below);
  * d_out: (num_frames * band CTUs) * 85 entries in HBM.  Asynchronous with respect to the host. */
 int  fhevc_intra_first_pass_device(fhevc_ctx* ctx, const void* d_luma, int sample_bytes, int stride_samples,

@@ -112,6 +112,7 @@ def main():
     np.savez_compressed(dst, **out)
     print("wrote", dst, os.path.getsize(dst), "bytes")
     preanalyze_golden(ref)
+    intra_lines_golden(ref)
 
 
 PREANALYZE_CASES = (("texture16", 416, 240, 8, 3), ("hetero", 1000, 568, 10, 4), ("hetero", 64, 64, 8, 1))
@@ -137,8 +138,58 @@ def preanalyze_golden(ref):
     print("wrote", dst, os.path.getsize(dst), "bytes")
 
 
+INTRA_LINE_CASES = (("hetero", 416, 240, 8, 32, (0, 1, 6, 7, 9, 13, 21, 24, 27)), ("texture16", 416, 240, 10, 27, (0, 6, 8, 20, 27)))
+
+
+def intra_lines_golden(ref):
+    """A7: unfiltered + smoothed reference lines from the reference's own initIntraPatternChType on live CUs (availability
+    rule, substitution walk, [1 2 1] and strong smoothing), neighbours read from the original picture; and the reference's
+    own xModeBitsIntra for the CU at the picture origin.  Expected outputs only."""
+    import ctypes as C
+    lib = op.bind_rdo(ref)
+    lib.href_intra_lines.argtypes = [C.c_int] * 7 + [C.c_void_p, C.c_void_p]
+    lib.href_mode_bits_origin.argtypes = [C.c_int] * 5 + [C.c_void_p]
+    out = {"cases": np.array([f"{c[0]}:{c[1]}x{c[2]}:bd{c[3]}:qp{c[4]}" for c in INTRA_LINE_CASES])}
+    for k, (content, w, h, bd, qp, ctus) in enumerate(INTRA_LINE_CASES):
+        luma = frames.texture16_luma(w, h) if content == "texture16" else frames.hetero_luma(w, h)
+        buf, org, stride = frames.to_pel_plane(luma, bd)
+        if bd > 8:  # use the low bits too (the same recipe as the tests)
+            m = org % stride
+            buf[m:m + h, m:m + w] += np.random.default_rng(bd).integers(0, 1 << (bd - 8), (h, w)).astype(np.int16)
+        op.rdo_encode(lib, buf, org, stride, w, h, bd, qp)  # live TComPic / TComDataCU objects for this geometry
+        cw = (w + 63) // 64
+        meta, unf, flt = [], [], []
+        first = True
+        for c in ctus:
+            for depth in range(4):
+                n = 64 >> depth
+                for by in range(1 << depth):
+                    for bx in range(1 << depth):
+                        x0, y0 = (c % cw) * 64 + bx * n, (c // cw) * 64 + by * n
+                        if x0 + n > w or y0 + n > h:
+                            continue
+                        a, b = np.zeros(4 * n + 1, np.int16), np.zeros(4 * n + 1, np.int16)
+                        rc = lib.href_intra_lines(w, h, bd, c, depth, (by * n // 4) * 16 + bx * n // 4, 1 if first else 0, a.ctypes.data, b.ctypes.data)
+                        assert rc == 4 * n + 1, rc
+                        first = False
+                        meta.append((c, depth, x0, y0, n)); unf.append(a); flt.append(b)
+        out[f"meta{k}"] = np.array(meta, np.int32)
+        out[f"unf{k}"] = np.concatenate(unf)
+        out[f"flt{k}"] = np.concatenate(flt)
+    bits = np.zeros((3, 4, 35), np.uint32)
+    for i, qp in enumerate((22, 32, 37)):
+        for depth in range(4):
+            assert lib.href_mode_bits_origin(416, 240, 8, qp, depth, bits[i, depth].ctypes.data) == 35
+    out["mode_bits_qp22_32_37"] = bits
+    dst = os.path.join(os.path.dirname(HERE), "tests", "golden", "ref_intra_lines.npz")
+    np.savez_compressed(dst, **out)
+    print("wrote", dst, os.path.getsize(dst), "bytes")
+
+
 if __name__ == "__main__":
-    if "--preanalyze-only" in sys.argv:
+    if "--intra-lines-only" in sys.argv:
+        intra_lines_golden(op.load_ref())
+    elif "--preanalyze-only" in sys.argv:
         preanalyze_golden(op.load_ref())
     else:
         main()

@@ -38,6 +38,9 @@
 #include "TLibCommon/TComPic.h"
 #include "TLibCommon/TComSlice.h"
 #include "TLibCommon/TComTrQuant.h"
+#include "TLibCommon/TComTU.h"
+#include "TLibCommon/TComPattern.h"
+#include "TLibCommon/TComPrediction.h"
 #include "TLibCommon/TComRdCost.h"
 #include "TLibEncoder/TEncCfg.h"
 #include "TLibEncoder/TEncCu.h"
@@ -493,6 +496,70 @@ int href_rdo_encode_next_p(const int16_t* luma, const int16_t* cb, const int16_t
   return 0;
 }
 #endif
+
+// ---- A7 goldens: the reference's OWN TComPrediction::initIntraPatternChType (TComPattern.cpp:115-320: availability
+// isAbove/Left/AboveRight/BelowLeftAvailable :568-746, fillReferenceSamples :322-539, [1 2 1] / strong smoothing :196-295) on live CUs of
+// the picture encoded last in this geometry.  from_original != 0 first copies the original picture into the reconstruction
+// plane the function reads (the GPU first pass takes its neighbours from the original: source-only twin), so that only the
+// availability rule, the substitution walk and the smoothing are under test.  The node is the CU of size 64 >> depth whose
+// top-left 4x4 unit has raster index part_raster inside CTU `ctu`.  Lines in the oracle's layout: line[2N] = top-left,
+// line[2N + 1 + i] = above / above-right i, line[2N - 1 - j] = left / below-left j  (4N + 1 samples each).
+int href_intra_lines(int width, int height, int bit_depth, int ctu, int depth, int part_raster, int from_original,
+                     int16_t* unfiltered, int16_t* filtered)
+{
+  Encoder* e = get_encoder(width, height, bit_depth);
+  if (!e->last) return -3;
+  TComPic* pic = e->last;
+  if (ctu < 0 || ctu >= (int)pic->getNumberOfCtusInFrame() || depth < 0 || depth > 3 || part_raster < 0 || part_raster > 255) return -1;
+  if (from_original) pic->getPicYuvOrg()->copyToPic(pic->getPicYuvRec());
+  TComDataCU* cu = pic->getCtu(ctu);
+  const UInt z = g_auiRasterToZscan[part_raster];
+  const int n = 64 >> depth;
+  // the TU rectangle comes from the CU's stored size at that partition (TComTU.cpp:63-75): set it for the call, restore after
+  const UChar w0 = cu->getWidth()[z], h0 = cu->getHeight()[z], d0 = cu->getDepth()[z];
+  cu->getWidth()[z] = (UChar)n; cu->getHeight()[z] = (UChar)n; cu->getDepth()[z] = (UChar)depth;
+  {
+    TComTURecurse tu(cu, z, (UInt)depth);
+    e->search.initIntraPatternChType(tu, COMPONENT_Y, true);
+  }
+  cu->getWidth()[z] = w0; cu->getHeight()[z] = h0; cu->getDepth()[z] = d0;
+  const int stride = 2 * n + 1;
+  const Pel* bufs[2] = { e->search.m_piYuvExt[COMPONENT_Y][PRED_BUF_UNFILTERED], e->search.m_piYuvExt[COMPONENT_Y][PRED_BUF_FILTERED] };
+  int16_t* outs[2] = { unfiltered, filtered };
+  for (int b = 0; b < 2; b++) {
+    outs[b][2 * n] = bufs[b][0];
+    for (int i = 0; i < 2 * n; i++) outs[b][2 * n + 1 + i] = bufs[b][1 + i];
+    for (int j = 0; j < 2 * n; j++) outs[b][2 * n - 1 - j] = bufs[b][(1 + j) * stride];
+  }
+  return 4 * n + 1;
+}
+
+// ---- first-pass mode bits: the reference's OWN TEncSearch::xModeBitsIntra (TEncSearch.cpp:5353-5381) for the CU at the
+// origin of CTU 0 of a fresh I slice at slice QP qp (CABAC contexts at their slice-initial state, TEncSlice.cpp:719-720, 826;
+// no neighbours: the default MPM set).  bits[35]: what estIntraPredLumaQT adds times sqrt(lambda) (TEncSearch.cpp:2288).
+int href_mode_bits_origin(int width, int height, int bit_depth, int qp, int depth, unsigned* bits)
+{
+  Encoder* e = get_encoder(width, height, bit_depth);
+  if (!e->last || depth < 0 || depth > 3) return -3;
+  e->pic = e->last;
+  init_slice(*e, qp);
+  TComSlice* slice = e->pic->getSlice(0);
+  e->entropy.setEntropyCoder(e->rdSbac[0][CI_CURR_BEST]);
+  e->entropy.resetEntropy(slice);
+  for (int d = 1; d < 5; d++) e->rdSbac[d][CI_CURR_BEST]->load(e->rdSbac[0][CI_CURR_BEST]);
+  e->entropy.setEntropyCoder(&e->rdGoOnSbac);
+  TComBitCounter counter;                       // as compressSlice's tempBitCounter (TEncSlice.cpp:726, 827-828)
+  e->entropy.setBitstream(&counter);
+  counter.resetBits();
+  e->rdGoOnSbac.load(e->rdSbac[0][CI_CURR_BEST]);
+  TComDataCU* cu = e->pic->getCtu(0);
+  cu->initCtu(e->pic, 0);
+  cu->setPartSizeSubParts(SIZE_2Nx2N, 0, (UInt)depth);
+  cu->setPredModeSubParts(MODE_INTRA, 0, (UInt)depth);
+  for (int m = 0; m < 35; m++) bits[m] = e->search.xModeBitsIntra(cu, (UInt)m, 0, (UInt)depth, CHANNEL_TYPE_LUMA);
+  e->rdGoOnSbac.setBitstream(NULL);             // stop use of the local counter (TEncSlice.cpp:971-972)
+  return 35;
+}
 
 // debugging aid: histograms of the decisions of the last encoded picture of that geometry
 int href_rdo_debug_hist(int width, int height, int bit_depth, int* modes35, int* part2, int* trdepth4, int* tskip2, int* cbf2)

@@ -43,6 +43,7 @@ def test_config3_4k_eight_bands(oracle):
         rb, re = bands.band(ctx.ctus_y, rank, 8)
         n = (re - rb) * ctx.ctus_x
         part = torch.full((max(n, 1), 256), 7, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()  # the fills above run on torch's stream: order them explicitly before the library call
         ctx.predict_frames_device(d16.data_ptr() + 2 * org, 2, stride, 0, 1, part.data_ptr(),
                                   had[rb * ctx.ctus_x:].data_ptr() if n else None, None, rows=(rb, re), qp=QP,
                                   d_flags=flags[rb * ctx.ctus_x:].data_ptr() if n else None)
@@ -51,6 +52,7 @@ def test_config3_4k_eight_bands(oracle):
         covered += n
     assert covered == ctx.num_ctus
     full = torch.zeros((ctx.num_ctus, 256), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()  # the fills above run on torch's stream: order them explicitly before the library call
     ctx.expand_depth_flags_device(flags.data_ptr(), 1, full.data_ptr())
     torch.cuda.synchronize()
     assert np.array_equal(full.cpu().numpy(), depth_ref)
@@ -101,6 +103,7 @@ def test_bench_gop_64_frames_properties(oracle):
         depth = torch.zeros((NF, n, 256), dtype=torch.uint8, device=dev)
         had = torch.zeros((NF, n), dtype=torch.int32, device=dev)
         flags = torch.zeros((NF, n), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()  # the fills above run on torch's stream: order them explicitly before the library call
         ctx.predict_frames_device(d16.data_ptr() + 2 * org, 2, stride, fs, NF, depth.data_ptr(), had.data_ptr(), None,
                                   qp=QP, d_flags=flags.data_ptr())
         torch.cuda.synchronize()
@@ -110,6 +113,7 @@ def test_bench_gop_64_frames_properties(oracle):
     depth_b, had_b, flags_b = run()
     assert torch.equal(depth, depth_b) and torch.equal(had, had_b) and torch.equal(flags, flags_b)  # deterministic
     expanded = torch.zeros_like(depth)
+    torch.cuda.synchronize()  # the fills above run on torch's stream: order them explicitly before the library call
     ctx.expand_depth_flags_device(flags.data_ptr(), NF, expanded.data_ptr())
     torch.cuda.synchronize()
     assert torch.equal(expanded, depth)  # flag words carry the whole map, all 32 640 CTUs

@@ -77,7 +77,9 @@ def test_motion_search_1080p_device_batch(oracle):
     band = torch.zeros(((NF - 1) * 3 * ctx.ctus_x * 85, 4), dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
     fs = planes[0][0].size
+    torch.cuda.synchronize()  # the fills above run on torch's stream: order them explicitly before the library call
     ctx.motion_search_device(d16.data_ptr() + 2 * org, 2, stride, fs, NF, out16.data_ptr(), qp=qp, search_range=rng)
+    torch.cuda.synchronize()  # the fills above run on torch's stream: order them explicitly before the library call
     ctx.motion_search_device(d16.data_ptr() + 2 * org, 2, stride, fs, NF, band.data_ptr(), rows=(14, 17), qp=qp, search_range=rng)
     torch.cuda.synchronize()
     g8 = out8.cpu().numpy().view(capi.MOTION_DTYPE).reshape(NF - 1, n, 85)

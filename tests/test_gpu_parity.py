@@ -107,9 +107,11 @@ def test_device_batch_logits_and_bands(oracle, torch_cuda):
     had = torch.zeros((NF, n), dtype=torch.int32, device=dev)
     logits = torch.zeros((NF, n, 42), dtype=torch.int32, device=dev)
     flags = torch.zeros((NF, n), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()  # the fills above run on torch's stream: order them explicitly before the library call
     ctx.predict_frames_device(d8.data_ptr(), 1, W, W * H, NF, depth.data_ptr(), had.data_ptr(), logits.data_ptr(), qp=37,
                               d_flags=flags.data_ptr())
     expanded = torch.full((NF, n, 256), 9, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()  # the fills above run on torch's stream: order them explicitly before the library call
     ctx.expand_depth_flags_device(flags.data_ptr(), NF, expanded.data_ptr())
     torch.cuda.synchronize()
     assert torch.equal(expanded, depth)  # the 4-byte word per CTU carries the whole map (multi-GPU all-gather payload)
@@ -127,6 +129,7 @@ def test_device_batch_logits_and_bands(oracle, torch_cuda):
     _, org, stride = frames.to_pel_plane(lumas[0], 8)
     d16 = torch.from_numpy(planes).to(dev)
     band = torch.full((NF, 2 * ctx.ctus_x, 256), 255, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()  # the fills above run on torch's stream: order them explicitly before the library call
     ctx.predict_frames_device(d16.data_ptr() + 2 * org, 2, stride, planes.shape[1] * planes.shape[2], NF,
                               band.data_ptr(), None, None, rows=(1, 3), stream=torch.cuda.current_stream().cuda_stream, qp=37)
     torch.cuda.synchronize()
@@ -150,8 +153,10 @@ def test_split_flag_words_on_ragged_pictures(oracle, torch_cuda, W, H):
     d8 = torch.from_numpy(np.stack(lumas)).to(dev)
     depth = torch.full((NF, n, 256), 7, dtype=torch.uint8, device=dev)
     flags = torch.zeros((NF, n), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()  # the fills above run on torch's stream: order them explicitly before the library call
     ctx.predict_frames_device(d8.data_ptr(), 1, W, W * H, NF, depth.data_ptr(), None, None, qp=27, d_flags=flags.data_ptr())
     expanded = torch.full((NF, n, 256), 9, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()  # the fills above run on torch's stream: order them explicitly before the library call
     ctx.expand_depth_flags_device(flags.data_ptr(), NF, expanded.data_ptr())
     torch.cuda.synchronize()
     for f in range(NF):
@@ -211,9 +216,11 @@ def test_soft_decision_ranges(oracle, torch_cuda):
     dmin = torch.zeros((n, 256), dtype=torch.uint8, device=dev)
     dmax = torch.zeros((n, 256), dtype=torch.uint8, device=dev)
     flags = torch.zeros(n, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
     ctx._check(ctx.lib.fhevc_predict_frames_device_range(ctx.h, d16.data_ptr() + 2 * org, 2, stride, 0, 1, 0, ctx.ctus_y, QP, 20000, 5000,
                                                          dmin.data_ptr(), dmax.data_ptr(), None, None, flags.data_ptr(), None))
     expanded = torch.zeros_like(dmin)
+    torch.cuda.synchronize()  # the fills above run on torch's stream: order them explicitly before the library call
     ctx.expand_depth_flags_device(flags.data_ptr(), 1, expanded.data_ptr())
     torch.cuda.synchronize()
     assert torch.equal(expanded, dmin) and bool((dmin <= dmax).all())
@@ -277,6 +284,7 @@ def test_first_pass_1080p_and_device_batch(oracle, torch_cuda):
     n = ctx.num_ctus
     d16 = torch.from_numpy(planes).to(dev)
     out = torch.zeros((NF, n * 85, 2), dtype=torch.float64, device=dev)  # 16 bytes per node
+    torch.cuda.synchronize()  # the fills above run on torch's stream: order them explicitly before the library call
     ctx.intra_first_pass_device(d16.data_ptr() + 2 * org, 2, stride, planes.shape[1] * planes.shape[2], NF, out.data_ptr(), qp=32)
     torch.cuda.synchronize()
     got = out.cpu().numpy().view(capi.NODE_DTYPE).reshape(NF, n, 85)
@@ -285,6 +293,7 @@ def test_first_pass_1080p_and_device_batch(oracle, torch_cuda):
     d8 = torch.from_numpy(np.stack(lumas)).to(dev)
     rb, re = 5, 11
     band = torch.zeros((NF, (re - rb) * ctx.ctus_x * 85, 2), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()  # the fills above run on torch's stream: order them explicitly before the library call
     ctx.intra_first_pass_device(d8.data_ptr(), 1, W, W * H, NF, band.data_ptr(), rows=(rb, re), qp=32)
     torch.cuda.synchronize()
     gb = band.cpu().numpy().view(capi.NODE_DTYPE).reshape(NF, (re - rb) * ctx.ctus_x, 85)
@@ -326,3 +335,49 @@ def test_errors_are_status_codes():
     odd.close()
     with pytest.raises(capi.FastHevcError):
         capi.Context(416, 240, 7)
+
+
+def _oracle_first_pass_all(oracle, buf, org, stride, W, H, bd, qp, ctus):
+    """every (node, mode) pair of the given CTUs through fho_first_pass_node: satd [len(ctus), 85, 35] (-1 = node outside)"""
+    sl = oracle.fho_lambda_intra(qp, bd) ** 0.5
+    cw, _ = frames.ctu_grid(W, H)
+    out = np.full((len(ctus), 85, 35), -1, np.int64)
+    best = op.NodeCost()
+    sat = np.zeros(35, np.uint32)
+    for i, c in enumerate(ctus):
+        idx = 0
+        for lvl in range(4):
+            n, cnt = 64 >> lvl, 1 << lvl
+            for by in range(cnt):
+                for bx in range(cnt):
+                    x0, y0 = (c % cw) * 64 + bx * n, (c // cw) * 64 + by * n
+                    if x0 + n <= W and y0 + n <= H:
+                        oracle.fho_first_pass_node(op.ptr(buf.reshape(-1), org), stride, W, H, x0, y0, n, bd, sl, C.byref(best), C.c_void_p(sat.ctypes.data))
+                        out[i, idx] = sat
+                    idx += 1
+    return out, sl
+
+
+@pytest.mark.parametrize("bd", [8, 10, 12])
+def test_first_pass_all_35_modes_per_node(oracle, bd):
+    """A7/A8 on the GPU beyond the arg-min: the SATD and the cost of EVERY mode of every node (fhevc_intra_first_pass_all),
+    i.e. reference lines, smoothing decision, all 35 predictors and the Hadamard of modes that never win."""
+    W, H = 416, 240
+    luma = frames.hetero_luma(W, H, seed=31 + bd)
+    buf, org, stride = frames.to_pel_plane(luma, bd)
+    if bd > 8:
+        m = org % stride
+        buf[m:m + H, m:m + W] += np.random.default_rng(bd).integers(0, 1 << (bd - 8), (H, W)).astype(np.int16)
+    ctx = capi.Context(W, H, bd)
+    qp = 27
+    best, allm = ctx.intra_first_pass_all(buf, org, stride, qp=qp)
+    ctus = list(range(ctx.num_ctus))
+    exp, sl = _oracle_first_pass_all(oracle, buf, org, stride, W, H, bd, qp, ctus)
+    valid = exp[:, :, 0] >= 0
+    assert np.array_equal(allm["satd"][valid].astype(np.int64), exp[valid])
+    assert (allm["mode"][valid] == np.arange(35)).all() and (allm["mode"][~valid] == 255).all() and (allm["satd"][~valid] == 0xFFFFFFFF).all()
+    bits = np.full(35, 6.0); bits[0] = 2.0; bits[1] = bits[26] = 3.0   # fho_first_pass_node's mode-bit model
+    assert np.array_equal(allm["cost"][valid], exp[valid].astype(np.float64) + bits * sl)
+    # the winner is the first minimum of those costs
+    assert np.array_equal(best["mode"][valid], allm["cost"][valid].argmin(axis=1).astype(np.uint32))
+    ctx.close()

@@ -118,6 +118,7 @@ def test_kernel_device_batch_bands_and_extremes(oracle):
     out = torch.full((NF, off[-1]), -1.0, dtype=torch.float64, device=dev)
     rows = ctx.ctus_y
     for rb, re in ((0, 5), (5, rows)):  # two CTU-row bands fill the whole-picture layout between them
+        torch.cuda.synchronize()  # the fills above run on torch's stream: order them explicitly before the library call
         ctx.preanalyze_frames_device(d16.data_ptr() + 2 * org, 2, stride, planes.shape[1] * planes.shape[2], NF,
                                      out.data_ptr(), D, rows=(rb, re))
     torch.cuda.synchronize()
