@@ -24,7 +24,8 @@ SYMBOLS = [
     "fhevc_enable_kernel_timing", "fhevc_get_stats", "fhevc_last_error", "fhevc_version",
     "fhevc_expand_depth_flags_device", "fhevc_aq_parts", "fhevc_preanalyze", "fhevc_preanalyze_frames_device", "fhevc_aq_qp", "fhevc_intra_first_pass_device",
     "fhevc_predict_frame_range", "fhevc_predict_frames_device_range",
-    "fhevc_motion_search", "fhevc_motion_search_device", "fhevc_intra_first_pass_all",
+    "fhevc_motion_search", "fhevc_motion_search_device", "fhevc_intra_first_pass_all", "fhevc_p_rule_default", "fhevc_p_depth_range",
+    "fhevc_predict_frames", "fhevc_alloc_host", "fhevc_free_host",
 ]
 
 
@@ -32,6 +33,10 @@ class Cfg(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("bit_depth", C.c_int), ("ctu_size", C.c_int),
                 ("max_depth", C.c_int), ("num_devices", C.c_int), ("device_ids", C.POINTER(C.c_int)),
                 ("weights_path", C.c_char_p), ("backend", C.c_int), ("max_frames", C.c_int)]
+
+
+class PRule(C.Structure):
+    _fields_ = [("w", (C.c_int32 * 10) * 3), ("t_split", C.c_int32 * 3), ("t_stop", C.c_int32 * 3), ("window", C.c_int32)]
 
 
 class NodeCost(C.Structure):
@@ -112,6 +117,14 @@ def load_library():
                                                    C.c_int, vp, vp]
     lib.fhevc_motion_search.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]
     lib.fhevc_motion_search_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
+    lib.fhevc_p_rule_default.argtypes = [C.POINTER(PRule)]
+    lib.fhevc_p_rule_default.restype = None
+    lib.fhevc_p_depth_range.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(PRule), vp, vp]
+    lib.fhevc_predict_frames.argtypes = [vp, vp, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int, vp, vp]
+    lib.fhevc_alloc_host.argtypes = [vp, C.c_size_t]
+    lib.fhevc_alloc_host.restype = vp
+    lib.fhevc_free_host.argtypes = [vp, vp]
+    lib.fhevc_free_host.restype = None
     lib.fhevc_kernel_timing.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     lib.fhevc_enable_kernel_timing.argtypes = [vp, C.c_int]
     lib.fhevc_get_stats.argtypes = [vp, vp, C.c_size_t]
@@ -120,6 +133,30 @@ def load_library():
     lib.fhevc_version.restype = C.c_char_p
     _lib = lib
     return lib
+
+
+def p_rule_default():
+    r = PRule()
+    load_library().fhevc_p_rule_default(C.byref(r))
+    return r
+
+
+def p_depth_range(nodes, prev_depth, width, height, qp, rule=None):
+    """config 4, host side: (depth_min, depth_max) [numCtus, 256] of a P picture from its motion nodes [numCtus, 85] and the
+    co-located depths [numCtus, 256] of its reference picture"""
+    lib = load_library()
+    rule = rule if rule is not None else p_rule_default()
+    nodes = np.ascontiguousarray(nodes)
+    prev = np.ascontiguousarray(prev_depth, np.uint8)
+    cw = (width + 63) // 64
+    n = nodes.shape[0]
+    dmin, dmax = np.zeros((n, 256), np.uint8), np.zeros((n, 256), np.uint8)
+    for c in range(n):
+        vw, vh = min(64, width - (c % cw) * 64), min(64, height - (c // cw) * 64)
+        rc = lib.fhevc_p_depth_range(nodes[c].ctypes.data, prev[c].ctypes.data, vw, vh, qp, C.byref(rule), dmin[c].ctypes.data, dmax[c].ctypes.data)
+        if rc != OK:
+            raise FastHevcError(rc, "fhevc_p_depth_range")
+    return dmin, dmax
 
 
 def band(ctu_rows, rank, world):
@@ -174,6 +211,38 @@ class Context:
         self._check(self.lib.fhevc_predict_frame(self.h, flat.ctypes.data + 2 * origin, stride, qp, slice_type,
                                                  depth.ctypes.data, had.ctypes.data if want_hadamard else None))
         return depth.reshape(self.num_ctus, 256), had
+
+    def alloc_host(self, shape, dtype):
+        """numpy array over pinned host memory of the library (fhevc_alloc_host); release with free_host(array)"""
+        dtype = np.dtype(dtype)
+        nbytes = int(np.prod(shape)) * dtype.itemsize
+        p = self.lib.fhevc_alloc_host(self.h, nbytes)
+        if not p:
+            raise FastHevcError(E_NOMEM, "fhevc_alloc_host")
+        arr = np.frombuffer((C.c_uint8 * nbytes).from_address(p), dtype=dtype).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.ctypes.data] = p
+        return arr
+
+    def free_host(self, arr):
+        p = getattr(self, "_pinned", {}).pop(arr.ctypes.data, None)
+        if p:
+            self.lib.fhevc_free_host(self.h, p)
+
+    def predict_frames(self, luma, qp=32, want_hadamard=True, depth_out=None, had_out=None, origin=0, stride=None, frame_stride=None):
+        """Host batch: luma [F, H, W] uint8 (8-bit content) or an int16 Pel buffer with origin/stride/frame_stride; returns
+        (depth [F, numCtus, 256], hadamard [F, numCtus] or None) in host memory."""
+        arr = np.asarray(luma)
+        if arr.dtype == np.uint8:
+            assert arr.ndim == 3 and arr.shape[1:] == (self.height, self.width) and arr.flags.c_contiguous
+            nf, sb, st, fst, ptr = arr.shape[0], 1, self.width, self.width * self.height, arr.ctypes.data
+        else:
+            assert arr.dtype == np.int16 and arr.flags.c_contiguous and stride is not None and frame_stride is not None
+            nf, sb, st, fst, ptr = arr.shape[0], 2, stride, frame_stride, arr.ctypes.data + 2 * origin
+        depth = depth_out if depth_out is not None else np.zeros((nf, self.num_ctus, 256), np.uint8)
+        had = had_out if had_out is not None else (np.zeros((nf, self.num_ctus), np.int32) if want_hadamard else None)
+        self._check(self.lib.fhevc_predict_frames(self.h, ptr, sb, st, fst, nf, qp, depth.ctypes.data, had.ctypes.data if had is not None else None))
+        return depth, had
 
     def predict_frame_range(self, plane, origin=0, stride=None, qp=32, margin=0, slice_type=2, margin_stop=None):
         """Soft decisions: (depth_min, depth_max), each [numCtus, 256]."""

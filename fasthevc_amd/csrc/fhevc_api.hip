@@ -3,6 +3,7 @@
 #include "../../include/fasthevc.h"
 #include "fhevc_internal.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -39,6 +40,15 @@ struct fhevc_ctx {
   double* d_act = nullptr;
   int16_t* d_pair = nullptr;          // two staging planes (reference, current) of fhevc_motion_search
   FhevcMotionNode* d_motion = nullptr;
+  // host-batch ring (fhevc_predict_frames): two slots, each with its own stream, device buffers and pinned staging
+  struct Slot {
+    hipStream_t st = nullptr;
+    uint8_t* d_in = nullptr; uint8_t* d_depth = nullptr; int32_t* d_had = nullptr;
+    uint8_t* h_in = nullptr; uint8_t* h_depth = nullptr; int32_t* h_had = nullptr;  // pinned staging (pageable callers)
+    size_t in_cap = 0, frames_cap = 0, h_in_cap = 0;
+    // what is in flight on this slot: where its outputs go once the stream has drained
+    int frames = 0; uint8_t* out_depth = nullptr; int32_t* out_had = nullptr; bool staged_out = false;
+  } slot[2];
   uint8_t* d_depth_max = nullptr;
   fhevc_stats stats{};
   std::string err;
@@ -450,6 +460,112 @@ int fhevc_predict_frame(fhevc_ctx* c, const int16_t* luma, int stride_samples, i
   return FHEVC_OK;
 }
 
+void* fhevc_alloc_host(fhevc_ctx* c, size_t bytes)
+{
+  if (!c || bytes == 0) return nullptr;
+  (void)hipSetDevice(c->device);
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+
+void fhevc_free_host(fhevc_ctx* c, void* p)
+{
+  if (!c || !p) return;
+  (void)hipSetDevice(c->device);
+  (void)hipHostFree(p);
+}
+
+static bool is_pinned(const void* p)
+{
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }  // pageable memory: "invalid value"
+  return a.type == hipMemoryTypeHost;
+}
+
+// wait for the slot's stream and hand its outputs to the caller (pageable destinations were staged in pinned memory)
+static int drain_slot(fhevc_ctx* c, fhevc_ctx::Slot& sl)
+{
+  if (sl.frames == 0) return FHEVC_OK;
+  HIP_TRY(c, hipStreamSynchronize(sl.st));
+  if (sl.staged_out) {
+    std::memcpy(sl.out_depth, sl.h_depth, (size_t)sl.frames * c->num_ctus * 256);
+    if (sl.out_had) std::memcpy(sl.out_had, sl.h_had, (size_t)sl.frames * c->num_ctus * 4);
+  }
+  sl.frames = 0;
+  return FHEVC_OK;
+}
+
+int fhevc_predict_frames(fhevc_ctx* c, const void* luma, int sample_bytes, int stride_samples, long long frame_stride_samples, int num_frames,
+                         int qp, uint8_t* depth_map, int32_t* ctu_src_hadamard)
+{
+  if (!c || !luma || !depth_map) return FHEVC_E_INVALID;
+  if (!c->have_weights) return fail(c, FHEVC_E_STATE, "weights not set");
+  if ((sample_bytes != 1 && sample_bytes != 2) || stride_samples < c->cfg.width || num_frames < 1) return fail(c, FHEVC_E_INVALID, "bad frame layout");
+  if (sample_bytes == 1 && c->cfg.bit_depth != 8) return fail(c, FHEVC_E_INVALID, "uint8 samples need bit_depth 8");
+  const long long frame_extent = (long long)stride_samples * (c->cfg.height - 1) + c->cfg.width;  // samples of one frame, first to last
+  if (num_frames > 1 && frame_stride_samples < frame_extent) return fail(c, FHEVC_E_INVALID, "frames overlap");
+  (void)hipSetDevice(c->device);
+  const int chunk = c->cfg.max_frames;
+  const size_t fs_bytes = (size_t)(num_frames > 1 ? frame_stride_samples : frame_extent) * sample_bytes;
+  const size_t chunk_in = (size_t)(chunk - 1) * fs_bytes + (size_t)frame_extent * sample_bytes;  // bytes from the first sample of a chunk to its last
+  const bool in_pinned = is_pinned(luma), out_pinned = is_pinned(depth_map) && (!ctu_src_hadamard || is_pinned(ctu_src_hadamard));
+  for (auto& sl : c->slot) {
+    if (!sl.st) HIP_TRY(c, hipStreamCreateWithFlags(&sl.st, hipStreamNonBlocking));
+    if (sl.in_cap < chunk_in) {
+      (void)hipFree(sl.d_in);
+      sl.d_in = nullptr; sl.in_cap = 0;
+      HIP_TRY(c, hipMalloc(&sl.d_in, chunk_in + 64));
+      sl.in_cap = chunk_in;
+    }
+    if (sl.frames_cap < (size_t)chunk) {
+      (void)hipFree(sl.d_depth); (void)hipFree(sl.d_had);
+      if (sl.h_depth) (void)hipHostFree(sl.h_depth);
+      if (sl.h_had) (void)hipHostFree(sl.h_had);
+      sl.d_depth = nullptr; sl.d_had = nullptr; sl.h_depth = nullptr; sl.h_had = nullptr; sl.frames_cap = 0;
+      HIP_TRY(c, hipMalloc(&sl.d_depth, (size_t)chunk * c->num_ctus * 256));
+      HIP_TRY(c, hipMalloc(&sl.d_had, (size_t)chunk * c->num_ctus * 4));
+      HIP_TRY(c, hipHostMalloc(&sl.h_depth, (size_t)chunk * c->num_ctus * 256, hipHostMallocDefault));
+      HIP_TRY(c, hipHostMalloc(&sl.h_had, (size_t)chunk * c->num_ctus * 4, hipHostMallocDefault));
+      sl.frames_cap = (size_t)chunk;
+    }
+    if (!in_pinned && sl.h_in_cap < chunk_in) {
+      if (sl.h_in) (void)hipHostFree(sl.h_in);
+      sl.h_in = nullptr; sl.h_in_cap = 0;
+      HIP_TRY(c, hipHostMalloc(&sl.h_in, chunk_in, hipHostMallocDefault));
+      sl.h_in_cap = chunk_in;
+    }
+  }
+  int rc = FHEVC_OK;
+  for (int f0 = 0, k = 0; f0 < num_frames && rc == FHEVC_OK; f0 += chunk, ++k) {
+    fhevc_ctx::Slot& sl = c->slot[k & 1];
+    rc = drain_slot(c, sl);  // chunk k-2: its maps reach the caller while chunk k-1 computes
+    if (rc != FHEVC_OK) break;
+    const int nf = std::min(chunk, num_frames - f0);
+    const uint8_t* src = static_cast<const uint8_t*>(luma) + (size_t)f0 * fs_bytes;
+    const size_t bytes = (size_t)(nf - 1) * fs_bytes + (size_t)frame_extent * sample_bytes;
+    if (!in_pinned) { std::memcpy(sl.h_in, src, bytes); src = sl.h_in; }
+    HIP_TRY(c, hipMemcpyAsync(sl.d_in, src, bytes, hipMemcpyHostToDevice, sl.st));
+    rc = fhevc_predict_frames_device(c, sl.d_in, sample_bytes, stride_samples, (long long)(fs_bytes / sample_bytes), nf, 0, c->ctus_y, qp, sl.d_depth,
+                                     ctu_src_hadamard ? sl.d_had : nullptr, nullptr, nullptr, sl.st);
+    if (rc != FHEVC_OK) break;
+    sl.frames = nf;
+    sl.out_depth = depth_map + (size_t)f0 * c->num_ctus * 256;
+    sl.out_had = ctu_src_hadamard ? ctu_src_hadamard + (size_t)f0 * c->num_ctus : nullptr;
+    sl.staged_out = !out_pinned;
+    HIP_TRY(c, hipMemcpyAsync(out_pinned ? sl.out_depth : sl.h_depth, sl.d_depth, (size_t)nf * c->num_ctus * 256, hipMemcpyDeviceToHost, sl.st));
+    if (ctu_src_hadamard)
+      HIP_TRY(c, hipMemcpyAsync(out_pinned ? (void*)sl.out_had : (void*)sl.h_had, sl.d_had, (size_t)nf * c->num_ctus * 4, hipMemcpyDeviceToHost, sl.st));
+    c->stats.bytes_h2d += bytes;
+    c->stats.bytes_d2h += (uint64_t)nf * c->num_ctus * (256 + (ctu_src_hadamard ? 4 : 0));
+  }
+  for (auto& sl : c->slot) {
+    const int r2 = drain_slot(c, sl);
+    if (rc == FHEVC_OK) rc = r2;
+  }
+  return rc;
+}
+
 int fhevc_predict_frame_range(fhevc_ctx* c, const int16_t* luma, int stride_samples, int qp, int slice_type, int margin_split, int margin_stop,
                               uint8_t* depth_min, uint8_t* depth_max, int32_t* ctu_src_hadamard)
 {
@@ -681,6 +797,105 @@ int fhevc_motion_search(fhevc_ctx* c, const int16_t* cur_luma, const int16_t* re
   HIP_TRY(c, hipMemcpyAsync(out, c->d_motion, (size_t)c->num_ctus * FHEVC_NODES * sizeof(FhevcMotionNode), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->stats.bytes_d2h += (uint64_t)c->num_ctus * FHEVC_NODES * sizeof(FhevcMotionNode);
+  return FHEVC_OK;
+}
+
+// ---- P-picture depth range from motion nodes + co-located depths (host-side integer rule; spec in include/fasthevc.h) ----
+namespace {
+inline int32_t ilog2_q8(uint32_t x)  // floor(256 log2 x) by integer squaring
+{
+  const int msb = 31 - __builtin_clz(x | 1u);
+  uint64_t y = ((uint64_t)x << 31) >> msb;
+  int32_t r = msb << 8;
+  for (int b = 7; b >= 0; --b) {
+    y = (y * y) >> 31;
+    if (y >> 32) { r |= 1 << b; y >>= 1; }
+  }
+  return r;
+}
+struct PNodeRef { int first, per_row; };
+constexpr PNodeRef kLevel[4] = { { 0, 1 }, { 1, 2 }, { 5, 4 }, { 21, 8 } };
+int64_t p_split_score(const fhevc_motion_node* nodes, const uint8_t* prev, int lvl, int nx, int ny, int qp, const fhevc_p_rule& r)
+{
+  const fhevc_motion_node& n = nodes[kLevel[lvl].first + ny * kLevel[lvl].per_row + nx];
+  int64_t child_cost = 0, child_satd = 0;
+  int moved = 0;
+  for (int k = 0; k < 4; ++k) {
+    const fhevc_motion_node& c = nodes[kLevel[lvl + 1].first + (2 * ny + (k >> 1)) * kLevel[lvl + 1].per_row + 2 * nx + (k & 1)];
+    child_cost += c.cost_best; child_satd += c.satd_best;
+    moved += (c.mvx != n.mvx) || (c.mvy != n.mvy);
+  }
+  const int units = 16 >> lvl;
+  int deepest = 0, shallowest = 3;
+  for (int y = 0; y < units; ++y)
+    for (int x = 0; x < units; ++x) {
+      const int d = prev[(ny * units + y) * 16 + nx * units + x];
+      deepest = std::max(deepest, d); shallowest = std::min(shallowest, d);
+    }
+  const int64_t gain = std::max<int64_t>(0, (int64_t)n.cost_best - child_cost);
+  const int norm = 512 * (6 - lvl) + (qp * 256) / 6;
+  const int64_t f[9] = { ilog2_q8(n.satd_best + 1u) - norm, ilog2_q8((uint32_t)gain + 1u) - norm, ilog2_q8((uint32_t)child_satd + 1u) - norm,
+                         ilog2_q8(n.satd_zero + 1u) - ilog2_q8(n.satd_best + 1u), deepest > lvl ? 256 : 0, shallowest > lvl ? 256 : 0,
+                         deepest > lvl + 1 ? 256 : 0, 64 * moved, 8 * qp };
+  int64_t s = r.w[lvl][9];
+  for (int i = 0; i < 9; ++i) s += (int64_t)r.w[lvl][i] * f[i];
+  return s;
+}
+}  // namespace
+
+void fhevc_p_rule_default(fhevc_p_rule* rule)
+{
+  if (!rule) return;
+  // logistic fit of HM-16.14's own P-picture split decisions (vanilla decision path, tests/quality/make_labels_p.py +
+  // p_features.py + fit_p_rule.py) on seeded pan clips of all synthetic families; weights Q10, bias and thresholds Q18
+  static const int32_t w[3][10] = FHEVC_P_RULE_WEIGHTS;
+  std::memcpy(rule->w, w, sizeof w);
+  const int32_t ts[3] = FHEVC_P_RULE_T_SPLIT, tp[3] = FHEVC_P_RULE_T_STOP;
+  std::memcpy(rule->t_split, ts, sizeof ts);
+  std::memcpy(rule->t_stop, tp, sizeof tp);
+  rule->window = 4;  // off
+}
+
+int fhevc_p_depth_range(const fhevc_motion_node* nodes, const uint8_t* prev_depth, int valid_w, int valid_h, int qp, const fhevc_p_rule* rule,
+                        uint8_t* depth_min, uint8_t* depth_max)
+{
+  if (!nodes || !prev_depth || !rule || !depth_min || !depth_max || valid_w < 8 || valid_w > 64 || valid_h < 8 || valid_h > 64 || qp < 0 || qp > 51)
+    return FHEVC_E_INVALID;
+  std::memset(depth_min, 0, 256);
+  std::memset(depth_max, 0, 256);
+  // split decisions of the 21 nodes, both thresholds, evaluated lazily top-down; -1 = not evaluated
+  int8_t sure[21], maybe[21];
+  std::memset(sure, -1, sizeof sure);
+  std::memset(maybe, -1, sizeof maybe);
+  auto decide = [&](int lvl, int nx, int ny) {
+    const int id = kLevel[lvl].first + ny * kLevel[lvl].per_row + nx, n = 64 >> lvl;
+    if (sure[id] >= 0) return id;
+    if (nx * n + n > valid_w || ny * n + n > valid_h) { sure[id] = maybe[id] = 1; return id; }  // crosses the picture edge
+    const int64_t s = p_split_score(nodes, prev_depth, lvl, nx, ny, qp, *rule);
+    sure[id] = s > rule->t_split[lvl];
+    maybe[id] = s >= -(int64_t)rule->t_stop[lvl];
+    return id;
+  };
+  for (int uy = 0; uy * 4 < valid_h; ++uy)
+    for (int ux = 0; ux * 4 < valid_w; ++ux) {
+      int lo = 0, hi = 0;
+      bool lo_open = true, hi_open = true;
+      for (int lvl = 0; lvl < 3 && (lo_open || hi_open); ++lvl) {
+        const int id = decide(lvl, ux >> (4 - lvl), uy >> (4 - lvl));
+        lo_open = lo_open && sure[id];
+        hi_open = hi_open && maybe[id];
+        if (lo_open) lo = lvl + 1;
+        if (hi_open) hi = lvl + 1;
+      }
+      if (rule->window < 4) {
+        const int p = prev_depth[uy * 16 + ux];
+        lo = std::min(3, std::max(0, std::max(lo, p - rule->window)));
+        hi = std::min(3, std::max(0, std::min(hi, p + rule->window)));
+        if (lo > hi) lo = hi;
+      }
+      depth_min[uy * 16 + ux] = (uint8_t)lo;
+      depth_max[uy * 16 + ux] = (uint8_t)hi;
+    }
   return FHEVC_OK;
 }
 

@@ -64,6 +64,13 @@ struct FhevcMvCost { uint32_t c[(2 * FHEVC_MOTION_MAX_RANGE + 1) * (2 * FHEVC_MO
 // frames 1 .. num_frames-1 of fr, each searched in the frame before it; d_out: (num_frames - 1) * band CTUs * 85 nodes
 hipError_t fhevc_launch_motion(const FhevcFrames& fr, int range, const FhevcMvCost& mvc, FhevcMotionNode* d_out, int num_cus, hipStream_t stream);
 
+// the shipped P-picture rule (fhevc_p_rule_default): see fasthevc.h; regenerate with tests/quality/fit_p_rule.py
+#define FHEVC_P_RULE_WEIGHTS { { 3101, 188, -94, 80, 1149, 1149, 3174, -138, 15748, -351620 }, \
+                               { 594, 101, 375, -8, 1078, 1078, -197, 436, 3462, 256745 },      \
+                               { 317, -3, 366, -216, 745, 745, 0, 1344, 2780, -18423 } }
+#define FHEVC_P_RULE_T_SPLIT { 524288, 524288, 1048576 }
+#define FHEVC_P_RULE_T_STOP  { 524288, 524288, 262144 }
+
 // ---- adaptive-QP pre-analysis (k_preanalyze.hip) -----------------------------------------------------------
 // d_activity: per frame parts_per_frame doubles, layers concatenated (layer d: ceil(H/P) x ceil(W/P), P = 64 >> d)
 hipError_t fhevc_launch_preanalyze(const FhevcFrames& fr, int layers, long long parts_per_frame, double* d_activity,

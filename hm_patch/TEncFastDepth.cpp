@@ -2,7 +2,9 @@
 #include "TEncFastDepth.h"
 
 #include <cstdio>
+#include <algorithm>
 #include <cstdlib>
+#include <cstring>
 
 #include "TLibCommon/TComPic.h"
 #include "TLibCommon/TComDataCU.h"
@@ -10,10 +12,12 @@
 
 #ifndef FHEVC_HOOK_NO_GPU
 #include "fasthevc.h"
+static_assert(sizeof(fhevc_p_rule) == 37 * sizeof(int), "TEncFastDepth::m_pRule holds a fhevc_p_rule");
+#define P_RULE (reinterpret_cast<fhevc_p_rule*>(m_pRule))
 #endif
 
 TEncFastDepth::TEncFastDepth()
-  : m_enabled(false), m_valid(false), m_external(false), m_cachePic(NULL), m_cachePoc(-1), m_cacheQp(-1), m_cacheType(-1), m_cacheFp(0), m_ctx(NULL), m_width(0), m_height(0), m_bitDepth(0), m_marginSplit(0), m_marginStop(0), m_pWindow(-1)
+  : m_enabled(false), m_valid(false), m_external(false), m_cachePic(NULL), m_cachePoc(-1), m_cacheQp(-1), m_cacheType(-1), m_cacheFp(0), m_ctx(NULL), m_width(0), m_height(0), m_bitDepth(0), m_marginSplit(0), m_marginStop(0), m_pWindow(1), m_pMode(P_OFF), m_pRange(4)
 {
   readKnobs();
 }
@@ -30,7 +34,27 @@ void TEncFastDepth::readKnobs()
   if (m_marginSplit < 0) m_marginSplit = 0;
   if (m_marginStop < 0) m_marginStop = 0;
   const char* pw = std::getenv("FHEVC_P_WINDOW");
-  m_pWindow = pw ? std::atoi(pw) : -1;
+  const char* pm = std::getenv("FHEVC_P_MODE");
+  m_pWindow = pw ? std::atoi(pw) : 1;
+  m_pMode = P_OFF;
+  if (pm != NULL && std::strcmp(pm, "window") == 0) m_pMode = P_WINDOW;
+  if (pm != NULL && std::strcmp(pm, "motion") == 0) m_pMode = P_MOTION;
+  if (pm == NULL && pw != NULL && m_pWindow >= 0) m_pMode = P_WINDOW;   // FHEVC_P_WINDOW alone keeps its round-1 meaning
+  const char* pr = std::getenv("FHEVC_P_RANGE");
+  m_pRange = pr ? std::atoi(pr) : 4;
+  if (m_pRange < 1) m_pRange = 1;
+  if (m_pRange > 8) m_pRange = 8;
+#ifndef FHEVC_HOOK_NO_GPU
+  fhevc_p_rule_default(P_RULE);
+  const char* pt = std::getenv("FHEVC_P_THRESH");   // "split64,split32,split16,stop64,stop32,stop16" in score units (1.0 = 2^18)
+  if (pt != NULL)
+  {
+    double v[6];
+    if (std::sscanf(pt, "%lf,%lf,%lf,%lf,%lf,%lf", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5]) == 6)
+      for (int l = 0; l < 3; l++) { P_RULE->t_split[l] = (int)(v[l] * 262144.0); P_RULE->t_stop[l] = (int)(v[3 + l] * 262144.0); }
+  }
+  if (pm != NULL && std::strcmp(pm, "motion") == 0 && pw != NULL) P_RULE->window = m_pWindow;
+#endif
 }
 
 TEncFastDepth::~TEncFastDepth()
@@ -74,10 +98,12 @@ bool TEncFastDepth::predictPicture(TComPic* pcPic, int sliceQp, int sliceType)
   if (sps.getMaxCUWidth() != 64 || sps.getMaxCUHeight() != 64 || sps.getLog2DiffMaxMinCodingBlockSize() != 3) return false;
   if (sliceType != I_SLICE)
   {
-    // Inter-CU depth reuse (config 4): the classifier is trained on intra decisions, so P/B pictures take their depth range
-    // from the co-located depths of their first reference picture, +- FHEVC_P_WINDOW levels -- but only when that picture
-    // was itself inter coded (intra depths say little about inter depths).  No GPU work: the depths are in the DPB.
-    if (m_pWindow < 0) return false;
+    // Config 4, "inter-CU depth reuse": a P/B picture takes its depth range from the co-located depths of its first reference
+    // picture -- but only when that picture was itself inter coded (intra depths say little about inter depths).
+    //   FHEVC_P_MODE=window : those depths +- FHEVC_P_WINDOW levels; host logic only (the depths sit in the DPB)
+    //   FHEVC_P_MODE=motion : the GPU searches every CU node of the picture in the ORIGINAL of the reference picture
+    //                         (fhevc_motion_search) and fhevc_p_depth_range turns node costs + co-located depths into ranges
+    if (m_pMode == P_OFF) return false;
     TComSlice* slice = pcPic->getSlice(pcPic->getCurrSliceIdx());
     if (slice->getNumRefIdx(REF_PIC_LIST_0) < 1) return false;
     TComPic* ref = slice->getRefPic(REF_PIC_LIST_0, 0);
@@ -85,44 +111,56 @@ bool TEncFastDepth::predictPicture(TComPic* pcPic, int sliceQp, int sliceType)
     const int numCtus = (int)pcPic->getNumberOfCtusInFrame();
     m_depth.resize((size_t)numCtus * 256);
     m_depthMax.resize(m_depth.size());
+    std::vector<unsigned char> prev((size_t)numCtus * 256);
     for (int c = 0; c < numCtus; c++)
     {
       const TComDataCU* ctu = ref->getCtu(c);
-      for (int r = 0; r < 256; r++)
+      for (int r = 0; r < 256; r++) prev[(size_t)c * 256 + r] = ctu->getDepth(g_auiRasterToZscan[r]);
+    }
+    if (m_pMode == P_WINDOW)
+    {
+      for (size_t i = 0; i < prev.size(); i++)
       {
-        const int d = (int)ctu->getDepth(g_auiRasterToZscan[r]);
-        m_depth[(size_t)c * 256 + r]    = (unsigned char)(d - m_pWindow < 0 ? 0 : d - m_pWindow);
-        m_depthMax[(size_t)c * 256 + r] = (unsigned char)(d + m_pWindow > 3 ? 3 : d + m_pWindow);
+        const int d = (int)prev[i];
+        m_depth[i]    = (unsigned char)(d - m_pWindow < 0 ? 0 : d - m_pWindow);
+        m_depthMax[i] = (unsigned char)(d + m_pWindow > 3 ? 3 : d + m_pWindow);
       }
+      m_valid = true;
+      return true;
+    }
+#ifdef FHEVC_HOOK_NO_GPU
+    return false;
+#else
+    if (!ensureContext(pcPic)) return false;
+    TComPicYuv* org = pcPic->getPicYuvOrg();
+    TComPicYuv* rorg = ref->getPicYuvOrg();
+    if (rorg == NULL || rorg->getStride(COMPONENT_Y) != org->getStride(COMPONENT_Y)) return false;
+    std::vector<fhevc_motion_node> nodes((size_t)numCtus * FHEVC_NODES_PER_CTU);
+    const int rc = fhevc_motion_search(m_ctx, org->getAddr(COMPONENT_Y), rorg->getAddr(COMPONENT_Y), org->getStride(COMPONENT_Y), sliceQp,
+                                       m_pRange, &nodes[0]);
+    if (rc != FHEVC_OK)
+    {
+      std::fprintf(stderr, "[fasthevc] P picture falls back to full RDO: %s\n", fhevc_last_error(m_ctx));
+      return false;
+    }
+    const int w = org->getWidth(COMPONENT_Y), h = org->getHeight(COMPONENT_Y), cw = (w + 63) / 64;
+    for (int c = 0; c < numCtus; c++)
+    {
+      const int vw = std::min(64, w - (c % cw) * 64), vh = std::min(64, h - (c / cw) * 64);
+      if (fhevc_p_depth_range(&nodes[(size_t)c * FHEVC_NODES_PER_CTU], &prev[(size_t)c * 256], vw, vh, sliceQp, P_RULE,
+                              &m_depth[(size_t)c * 256], &m_depthMax[(size_t)c * 256]) != FHEVC_OK) return false;
     }
     m_valid = true;
     return true;
+#endif
   }
   if (!m_enabled) return false;
 #ifdef FHEVC_HOOK_NO_GPU
   (void)pcPic; (void)sliceQp; (void)sliceType;
   return false;
 #else
+  if (!ensureContext(pcPic)) return false;
   TComPicYuv* org = pcPic->getPicYuvOrg();
-  const int w = org->getWidth(COMPONENT_Y), h = org->getHeight(COMPONENT_Y);
-  const int bd = pcPic->getPicSym()->getSPS().getBitDepth(CHANNEL_TYPE_LUMA);
-  if (m_ctx == NULL || w != m_width || h != m_height || bd != m_bitDepth)
-  {
-    if (m_ctx != NULL) { fhevc_destroy(m_ctx); m_ctx = NULL; }
-    const char* dev = std::getenv("FHEVC_DEVICE");
-    int device = dev ? std::atoi(dev) : 0;
-    fhevc_cfg cfg;
-    cfg.width = w; cfg.height = h; cfg.bit_depth = bd; cfg.ctu_size = 64; cfg.max_depth = 3;
-    cfg.num_devices = 1; cfg.device_ids = &device; cfg.weights_path = std::getenv("FHEVC_WEIGHTS");
-    cfg.backend = FHEVC_BACKEND_HIP; cfg.max_frames = 1;
-    if (cfg.weights_path == NULL || fhevc_create(&m_ctx, &cfg) != FHEVC_OK)
-    {
-      std::fprintf(stderr, "[fasthevc] disabled: cannot create the GPU context (weights/device)\n");
-      m_enabled = false; m_ctx = NULL;
-      return false;
-    }
-    m_width = w; m_height = h; m_bitDepth = bd;
-  }
   m_depth.resize((size_t)pcPic->getNumberOfCtusInFrame() * 256);
   m_depthMax.resize(m_depth.size());
   const int rc = fhevc_predict_frame_range(m_ctx, org->getAddr(COMPONENT_Y), org->getStride(COMPONENT_Y), sliceQp, sliceType,
@@ -133,6 +171,35 @@ bool TEncFastDepth::predictPicture(TComPic* pcPic, int sliceQp, int sliceType)
     return false;
   }
   m_valid = true;
+  return true;
+#endif
+}
+
+bool TEncFastDepth::ensureContext(TComPic* pcPic)
+{
+#ifdef FHEVC_HOOK_NO_GPU
+  (void)pcPic;
+  return false;
+#else
+  if (!m_enabled) return false;
+  TComPicYuv* org = pcPic->getPicYuvOrg();
+  const int w = org->getWidth(COMPONENT_Y), h = org->getHeight(COMPONENT_Y);
+  const int bd = pcPic->getPicSym()->getSPS().getBitDepth(CHANNEL_TYPE_LUMA);
+  if (m_ctx != NULL && w == m_width && h == m_height && bd == m_bitDepth) return true;
+  if (m_ctx != NULL) { fhevc_destroy(m_ctx); m_ctx = NULL; }
+  const char* dev = std::getenv("FHEVC_DEVICE");
+  int device = dev ? std::atoi(dev) : 0;
+  fhevc_cfg cfg;
+  cfg.width = w; cfg.height = h; cfg.bit_depth = bd; cfg.ctu_size = 64; cfg.max_depth = 3;
+  cfg.num_devices = 1; cfg.device_ids = &device; cfg.weights_path = std::getenv("FHEVC_WEIGHTS");
+  cfg.backend = FHEVC_BACKEND_HIP; cfg.max_frames = 1;
+  if (cfg.weights_path == NULL || fhevc_create(&m_ctx, &cfg) != FHEVC_OK)
+  {
+    std::fprintf(stderr, "[fasthevc] disabled: cannot create the GPU context (weights/device)\n");
+    m_enabled = false; m_ctx = NULL;
+    return false;
+  }
+  m_width = w; m_height = h; m_bitDepth = bd;
   return true;
 #endif
 }

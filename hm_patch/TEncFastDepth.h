@@ -13,8 +13,11 @@
  *   FHEVC_MARGIN_SPLIT / FHEVC_MARGIN_STOP set the two sides separately (not forcing unsure splits is almost free,
  *                             not forbidding unsure ones costs the recursion it allows).  Defaults: split 32000, stop 0;
  *                             FHEVC_MARGIN=0 gives hard decisions
- *   FHEVC_P_WINDOW=<w>        P/B pictures: restrict the depth search to the co-located depth of the first reference picture
- *                             +- w levels when that picture was inter coded (default: off); independent of FHEVC_ENABLE
+ *   FHEVC_P_MODE=window|motion  P/B pictures whose first reference picture was inter coded (default: off = stock RDO):
+ *                             window = co-located depth of that picture +- FHEVC_P_WINDOW levels (host logic only, independent of
+ *                             FHEVC_ENABLE); motion = GPU motion search of every CU node in the reference's ORIGINAL picture
+ *                             (FHEVC_P_RANGE = window radius 1..8, default 4) + fhevc_p_depth_range (needs FHEVC_ENABLE=1);
+ *                             FHEVC_P_THRESH overrides the six thresholds of the rule, FHEVC_P_WINDOW adds the +- clip to it
  */
 #ifndef __TENCFASTDEPTH__
 #define __TENCFASTDEPTH__
@@ -49,6 +52,10 @@ private:
   unsigned long long m_cacheFp;
   fhevc_ctx* m_ctx;
   int        m_width, m_height, m_bitDepth, m_marginSplit, m_marginStop, m_pWindow;
+  enum PMode { P_OFF, P_WINDOW, P_MOTION };
+  int        m_pMode, m_pRange;
+  int        m_pRule[37];                     // fhevc_p_rule (include/fasthevc.h), kept opaque so that this header needs no library header
+  bool       ensureContext(TComPic* pcPic);   // (re-)create the GPU context for this picture geometry
   std::vector<unsigned char> m_depth;     // numCtus * 256, raster 16x16 per CTU: depth_min
   std::vector<unsigned char> m_depthMax;  // depth_max (== m_depth when the margin is 0)
 };

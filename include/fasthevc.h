@@ -89,6 +89,20 @@ int  fhevc_set_weights(fhevc_ctx* ctx, const void* blob, size_t bytes);
 int  fhevc_predict_frame(fhevc_ctx* ctx, const int16_t* luma, int stride_samples, int qp, int slice_type,
                          uint8_t* depth_map, int32_t* ctu_src_hadamard);
 
+/* Host batch ("one CTU's depth map delivered to host memory"): num_frames pictures in host memory ->
+ * depth maps (and, optionally, per-CTU source Hadamards) in host memory.  luma: sample_bytes = 2 (int16 Pel planes as HM lays
+ * them out) or 1 (uint8 planes of 8-bit content, e.g. straight from an 8-bit .yuv file: TVideoIOYuv.cpp:249-330 reads the
+ * same bytes and widens them); frame f starts at luma + f * frame_stride_samples.  The pictures travel in chunks of
+ * cfg.max_frames through two streams, so that the upload of chunk k+1 and the download of chunk k-1 overlap the kernels of
+ * chunk k.  Buffers from fhevc_alloc_host (or otherwise pinned) are read / written by DMA directly; pageable buffers go
+ * through the context's pinned staging ring (one extra host copy per chunk).  Synchronous. */
+int  fhevc_predict_frames(fhevc_ctx* ctx, const void* luma, int sample_bytes, int stride_samples, long long frame_stride_samples,
+                          int num_frames, int qp, uint8_t* depth_map /* num_frames * numCtus * 256 */,
+                          int32_t* ctu_src_hadamard /* num_frames * numCtus, or NULL */);
+/* pinned host memory for the batch entry point (a .yuv reader can read luma planes straight into it) */
+void* fhevc_alloc_host(fhevc_ctx* ctx, size_t bytes);
+void  fhevc_free_host(fhevc_ctx* ctx, void* p);
+
 /* Soft decisions for the xCompressCU hook (hm_patch/): depth_min holds only the splits whose logit difference exceeds
  * +margin_split, depth_max every split not rejected by more than -margin_stop (both >= 0, logit units; 0, 0: both maps
  * equal the map of fhevc_predict_frame).  The hook forces a split while depth < depth_min, forbids one at
@@ -188,6 +202,31 @@ int  fhevc_motion_search(fhevc_ctx* ctx, const int16_t* cur_luma, const int16_t*
 int  fhevc_motion_search_device(fhevc_ctx* ctx, const void* d_luma, int sample_bytes, int stride_samples,
                                 long long frame_stride_samples, int num_frames, int ctu_row_begin, int ctu_row_end,
                                 int qp, int search_range, fhevc_motion_node* d_out, void* stream);
+
+/* Depth range of every 4x4 unit of a P picture's CTU from its motion nodes and the co-located depths of its reference picture
+ * ("inter-CU depth reuse", BASELINE config 4).  Host-side integer arithmetic, no device work.  Per split decision (64->32,
+ * 32->16, 16->8) a linear score over nine features of the node, all in 1/256 units (L(x) = floor(256 log2 x) by integer
+ * squaring, lgN = 2 * 256 * log2(node size), qn = 256 * qp / 6):
+ *   f0 = L(satd_best + 1) - lgN - qn          residual per sample against the quantiser step
+ *   f1 = L(cost_best - sum of the four children's cost_best (clamped at 0) + 1) - lgN - qn     what splitting the search gains
+ *   f2 = L(sum of the children's satd_best + 1) - lgN - qn
+ *   f3 = L(satd_zero + 1) - L(satd_best + 1)  how much motion compensation helps at all
+ *   f4, f5 = 256 if the largest / smallest co-located depth of the reference picture inside the node is deeper than the node
+ *   f6 = 256 if the largest co-located depth is at least two levels deeper
+ *   f7 = 64 * number of children whose cheapest vector differs from the node's
+ *   f8 = 8 * qp
+ * score = sum w[level][i] * f_i + w[level][9]   (Q18).  depth_min follows the splits with score > t_split[level] top-down,
+ * depth_max those with score >= -t_stop[level]; CUs crossing the picture edge are split in both, units outside get 0; then
+ * both are clipped to the co-located depth +- window when window < 4.  The xCompressCU hook forces a split while depth <
+ * depth_min and forbids one at depth >= depth_max (as for I pictures). */
+typedef struct {
+  int32_t w[3][10];
+  int32_t t_split[3], t_stop[3];
+  int32_t window;
+} fhevc_p_rule;
+void fhevc_p_rule_default(fhevc_p_rule* rule);   /* the shipped rule (fitted on the reference's own P-picture decisions) */
+int  fhevc_p_depth_range(const fhevc_motion_node* nodes /* 85 */, const uint8_t* prev_depth /* 256, raster */, int valid_w,
+                         int valid_h, int qp, const fhevc_p_rule* rule, uint8_t* depth_min /* 256 */, uint8_t* depth_max /* 256 */);
 
 /* CTU-row band of rank `rank` out of `world`: rows [begin, end) */
 int  fhevc_band(int ctu_rows, int rank, int world, int* begin, int* end);

@@ -549,6 +549,84 @@ void fho_motion_ctu(const int16_t* cur, int cs, const int16_t* ref, int rs, int 
   }
 }
 
+/* P-picture depth range (include/fasthevc.h: fhevc_p_depth_range) */
+int32_t fho_ilog2_q8(uint32_t x)
+{
+  int msb = 0;
+  while ((x >> msb) > 1) msb++;
+  uint64_t y = ((uint64_t)x << 31) >> msb; /* Q31 in [1, 2) */
+  int32_t r = msb << 8;
+  for (int b = 7; b >= 0; b--) {
+    y = (y * y) >> 31;
+    if (y >= ((uint64_t)2 << 31)) { r |= 1 << b; y >>= 1; }
+  }
+  return r;
+}
+static int64_t p_score(const fho_motion_node* nd, const uint8_t* prev, int lvl, int bx, int by, int qp, const fho_p_rule* r)
+{
+  const int cnt = 1 << lvl, sz = 16 >> lvl, off = lvl == 0 ? 0 : (lvl == 1 ? 1 : 5), coff = lvl == 0 ? 1 : (lvl == 1 ? 5 : 21);
+  const fho_motion_node* n = &nd[off + by * cnt + bx];
+  int64_t jc = 0, sc = 0;
+  int mvd = 0;
+  for (int j = 0; j < 2; j++)
+    for (int i = 0; i < 2; i++) {
+      const fho_motion_node* c = &nd[coff + (2 * by + j) * 2 * cnt + 2 * bx + i];
+      jc += c->cost_best; sc += c->satd_best;
+      mvd += (c->mvx != n->mvx || c->mvy != n->mvy);
+    }
+  int pmax = 0, pmin = 3;
+  for (int y = by * sz; y < (by + 1) * sz; y++)
+    for (int x = bx * sz; x < (bx + 1) * sz; x++) { pmax = imax(pmax, prev[y * 16 + x]); pmin = imin(pmin, prev[y * 16 + x]); }
+  int64_t gain = (int64_t)n->cost_best - jc;
+  if (gain < 0) gain = 0;
+  const int lgn = 2 * (6 - lvl) * 256, qn = (qp * 256) / 6;
+  const int64_t f[9] = { fho_ilog2_q8(n->satd_best + 1u) - lgn - qn, fho_ilog2_q8((uint32_t)gain + 1u) - lgn - qn,
+                         fho_ilog2_q8((uint32_t)sc + 1u) - lgn - qn, fho_ilog2_q8(n->satd_zero + 1u) - fho_ilog2_q8(n->satd_best + 1u),
+                         pmax > lvl ? 256 : 0, pmin > lvl ? 256 : 0, pmax > lvl + 1 ? 256 : 0, 64 * mvd, 8 * qp };
+  int64_t s = r->w[lvl][9];
+  for (int i = 0; i < 9; i++) s += (int64_t)r->w[lvl][i] * f[i];
+  return s;
+}
+void fho_p_depth_range(const fho_motion_node nodes[85], const uint8_t prev_depth[256], int vw, int vh, int qp,
+                       const fho_p_rule* rule, uint8_t depth_min[256], uint8_t depth_max[256])
+{
+  for (int pass = 0; pass < 2; pass++) {
+    uint8_t* out = pass == 0 ? depth_min : depth_max;
+    memset(out, 0, 256);
+    /* top-down, one 16x16 block (4x4 units) at a time */
+    for (int b = 0; b < 16; b++) {
+      const int bx = b & 3, by = b >> 2;
+      int depth = 0;
+      for (int lvl = 0; lvl < 3; lvl++) {
+        const int sh = 2 - lvl, nx = bx >> sh, ny = by >> sh, n = 64 >> lvl;
+        if (nx * n >= vw || ny * n >= vh) { depth = -1; break; }     /* node outside the picture */
+        int split;
+        if (nx * n + n > vw || ny * n + n > vh) split = 1;           /* crosses the edge: HM forces the split */
+        else {
+          const int64_t s = p_score(nodes, prev_depth, lvl, nx, ny, qp, rule);
+          split = pass == 0 ? (s > rule->t_split[lvl]) : (s >= -(int64_t)rule->t_stop[lvl]);
+        }
+        if (!split) break;
+        depth = lvl + 1;
+      }
+      for (int y = 0; y < 4; y++)
+        for (int x = 0; x < 4; x++) {
+          const int ux = bx * 4 + x, uy = by * 4 + y;
+          if (depth < 0 || ux * 4 >= vw || uy * 4 >= vh) continue;
+          int d = depth;
+          if (rule->window < 4) {
+            const int p = prev_depth[uy * 16 + ux];
+            d = pass == 0 ? imax(d, p - rule->window) : imin(d, p + rule->window);
+            d = clip3(0, 3, d);
+          }
+          out[uy * 16 + ux] = (uint8_t)d;
+        }
+    }
+  }
+  if (rule->window < 4)   /* the window can cross the two maps: keep min <= max */
+    for (int i = 0; i < 256; i++) if (depth_min[i] > depth_max[i]) depth_min[i] = depth_max[i];
+}
+
 /* ------------------------------------------------------------------------------------------
  * A15: depth classifier (integer-valued).
  * ------------------------------------------------------------------------------------------ */

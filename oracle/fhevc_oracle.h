@@ -117,6 +117,13 @@ uint32_t fho_mv_cost(int x, int y, double sqrt_lambda);
  * range <= 8.  cost of a node at mv = (sum of its 8x8 tile SATDs >> (bit_depth - 8)) + fho_mv_cost(mv). */
 void fho_motion_ctu(const int16_t* cur, int cur_stride, const int16_t* ref, int ref_stride, int width, int height,
                     int ctu_x, int ctu_y, int bit_depth, int range, double sqrt_lambda, fho_motion_node out[85]);
+/* Depth range of a P picture's CTU from its motion nodes and the co-located depths of the reference picture: the integer rule
+ * that include/fasthevc.h specifies for fhevc_p_depth_range (this is its independent restatement). */
+typedef struct { int32_t w[3][10]; int32_t t_split[3], t_stop[3]; int32_t window; } fho_p_rule;
+int32_t fho_ilog2_q8(uint32_t x);   /* floor(256 log2 x) by integer squaring, x >= 1 */
+void fho_p_depth_range(const fho_motion_node nodes[85], const uint8_t prev_depth[256], int valid_w, int valid_h,
+                       int qp, const fho_p_rule* rule, uint8_t depth_min[256], uint8_t depth_max[256]);
+
 /* ---- A15: depth classifier, integer-valued restatement --------------------------------- */
 /* Architecture follows matlab/dataExtraction/Train...Example.m:75-96 run convolutionally on the
  * 64x64 CTU: conv3x3x16 pad1 -> ReLU -> maxpool2 -> conv3x3x32 pad1 -> ReLU -> maxpool2 ->

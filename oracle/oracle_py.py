@@ -26,6 +26,11 @@ class NodeCost(C.Structure):
     _fields_ = [("satd", C.c_uint32), ("mode", C.c_uint32), ("cost", C.c_double)]
 
 
+class PRule(C.Structure):
+    """Mirror of fho_p_rule"""
+    _fields_ = [("w", (C.c_int32 * 10) * 3), ("t_split", C.c_int32 * 3), ("t_stop", C.c_int32 * 3), ("window", C.c_int32)]
+
+
 class Weights(C.Structure):
     """Mirror of fho_weights (oracle/fhevc_oracle.h)."""
     _fields_ = [
@@ -79,6 +84,10 @@ def load_oracle():
     lib.fho_motion_ctu.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_double, C.c_void_p]
     lib.fho_motion_ctu.restype = None
+    lib.fho_ilog2_q8.argtypes = [C.c_uint32]
+    lib.fho_ilog2_q8.restype = C.c_int32
+    lib.fho_p_depth_range.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(PRule), C.c_void_p, C.c_void_p]
+    lib.fho_p_depth_range.restype = None
     lib.fho_fill_ref.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _i16p]
     lib.fho_fill_ref_flags.argtypes = [C.c_void_p, C.c_int, _u8p, C.c_int, C.c_int, _i16p]
     lib.fho_filter_ref.argtypes = [_i16p, C.c_int, C.c_int, C.c_int, _i16p]
@@ -117,6 +126,11 @@ def load_ref(hook=False):
     hm_patch/ applied; hook="gpu": libhmref_hookgpu.so, whose TEncFastDepth calls the real GPU library) with
     RTLD_LAZY: one never-called reference symbol stays unresolved, see oracle/Makefile."""
     path = HOOK_SO.replace("_hook.so", "_hookgpu.so") if hook == "gpu" else (HOOK_SO if hook else REF_SO)
+    if hook == "gpu":
+        # this library pulls in fasthevc_amd/lib/libfasthevc_hip.so; in a Python process that also holds torch the HIP runtime
+        # must be the one torch ships (same SONAME as /opt/rocm's): let the product loader map it first
+        from fasthevc_amd import capi
+        capi.load_library()
     libdl = C.CDLL(None)
     libdl.dlopen.restype = C.c_void_p
     libdl.dlopen.argtypes = [C.c_char_p, C.c_int]

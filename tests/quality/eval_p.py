@@ -61,7 +61,23 @@ def cnn_ranges(oracle, ws, y, qp, margin_split, margin_stop):
     return dmin, dmax
 
 
-def encode_seq(lib, ys, qp, window=None, cnn=None):
+def motion_ranges(oracle, rule, cur, ref, prev_depth, qp, search_range=4):
+    """depth range of a P picture from the source-only motion search (oracle twin of k_motion.hip) and the previous picture's
+    depths, through the oracle twin of fhevc_p_depth_range (the GPU path is bit-exact with both)"""
+    import p_features
+    H, W = cur.shape
+    cw = (W + 63) // 64
+    nodes = p_features.motion_frame(oracle, cur, ref, qp, search_range)
+    n = nodes.shape[0]
+    dmin, dmax = np.zeros((n, 256), np.uint8), np.zeros((n, 256), np.uint8)
+    prev = np.ascontiguousarray(prev_depth, np.uint8).reshape(n, 256)
+    for c in range(n):
+        vw, vh = min(64, W - (c % cw) * 64), min(64, H - (c // cw) * 64)
+        oracle.fho_p_depth_range(nodes[c].ctypes.data, prev[c].ctypes.data, vw, vh, qp, C.byref(rule), dmin[c].ctypes.data, dmax[c].ctypes.data)
+    return dmin, dmax
+
+
+def encode_seq(lib, ys, qp, window=None, cnn=None, motion=None):
     """I P P ...: POC 0 at qp, the P pictures at qp + 6.  window = (levels below, levels above) the co-located depth of
     the PREVIOUS picture (None = unrestricted search; the first P picture is unrestricted when its reference is the I
     picture: intra depths say little about inter depths).  -> per picture (depth [n,256], stats)."""
@@ -78,6 +94,9 @@ def encode_seq(lib, ys, qp, window=None, cnn=None):
         fmin = fmax = None
         if cnn is not None and f >= 2:  # classifier for inter pictures: (oracle, weights, margin_split, margin_stop)
             fmin, fmax = cnn_ranges(cnn[0], cnn[1], ys[f], qp + 6, cnn[2], cnn[3])
+            fmin, fmax = np.ascontiguousarray(fmin), np.ascontiguousarray(fmax)
+        elif motion is not None and f >= 2:  # (oracle, rule): motion features + the previous P picture's depths
+            fmin, fmax = motion_ranges(motion[0], motion[1], ys[f], ys[f - 1], out[-1][0], qp + 6)
             fmin, fmax = np.ascontiguousarray(fmin), np.ascontiguousarray(fmax)
         elif window is not None and f >= 2:
             prev = out[-1][0].astype(int)

@@ -76,3 +76,94 @@ def test_reference_encoder_driven_by_the_gpu_library(oracle):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+P_SO = os.path.join(ROOT, "oracle", "_ref", "libhmref_p.so")
+PGPU_SO = os.path.join(ROOT, "oracle", "_ref", "libhmref_pgpu.so")
+P_KNOBS = KNOBS + ("FHEVC_P_MODE", "FHEVC_P_WINDOW", "FHEVC_P_RANGE", "FHEVC_P_THRESH")
+
+
+def _load_p(path):
+    from fasthevc_amd import capi
+    capi.load_library()  # one HIP runtime per process: the product loader maps it before the harness library pulls it in
+    libdl = C.CDLL(None)
+    libdl.dlopen.restype = C.c_void_p
+    libdl.dlopen.argtypes = [C.c_char_p, C.c_int]
+    h = libdl.dlopen(path.encode(), os.RTLD_LAZY | os.RTLD_LOCAL)
+    assert h, path
+    lib = op.bind_rdo(C.CDLL(path, handle=h))
+    lib.href_rdo_encode_next_p.argtypes = [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_void_p] * 4
+    return lib
+
+
+def _next_p(lib, y, W, H, qp, poc, fmin=None, fmax=None):
+    buf, org, stride = frames.to_pel_plane(y, 8)
+    u = np.full((H // 2, W // 2), 128, np.int16)
+    n = (W // 64) * (H // 64)
+    d, s = np.zeros(n * 256, np.uint8), np.zeros(8)
+    rc = lib.href_rdo_encode_next_p(buf.reshape(-1).ctypes.data + 2 * org, u.ctypes.data, u.ctypes.data, stride, W, H, 8, qp, poc,
+                                    None if fmin is None else fmin.ctypes.data, None if fmax is None else fmax.ctypes.data, d.ctypes.data, s.ctypes.data)
+    assert rc == 0
+    return d.reshape(n, 256), s
+
+
+@pytest.mark.skipif(not os.path.exists(PGPU_SO), reason="oracle/_ref/libhmref_pgpu.so is built where /root/reference exists")
+def test_config4_p_pictures_driven_by_the_gpu_motion_search(oracle):
+    """BASELINE config 4 end to end: I P P P through the reference's compressSlice with HM-16.14's inter checks restored.  In the
+    GPU build TEncFastDepth::predictPicture asks the MI355X for the motion nodes of every P picture whose reference is a P
+    picture (fhevc_motion_search) and turns them into depth ranges (fhevc_p_depth_range); the result must equal the CPU-hook
+    build fed with the oracle's ranges (fho_motion_ctu + fho_p_depth_range), picture by picture, and differ from full RDO."""
+    from fasthevc_amd import capi
+    W, H, QPI, QPP = 640, 448, 32, 38
+    ys = frames.pan_clip(W, H, 4, seed=77)
+    cpu, gpu = _load_p(P_SO), _load_p(PGPU_SO)
+    n, cw = (W // 64) * (H // 64), W // 64
+    u = np.full((H // 2, W // 2), 128, np.int16)
+    rule = op.PRule.from_buffer_copy(bytes(capi.p_rule_default()))
+    saved = {k: os.environ.get(k) for k in P_KNOBS}
+    try:
+        for k in P_KNOBS:
+            os.environ.pop(k, None)
+        buf, org, stride = frames.to_pel_plane(ys[0], 8)
+
+        def run(lib, ranges):
+            maps, stats = [], []
+            d, s = op.rdo_encode(lib, buf, org, stride, W, H, 8, QPI, chroma=(u, u))  # POC 0: full RDO in both builds
+            maps.append(d)
+            stats.append(s["coded_bits"])
+            for f in range(1, 4):
+                fmin = fmax = None
+                if ranges and f >= 2:  # the oracle's ranges from the ORIGINAL pictures f, f - 1 and the depths HM chose for f - 1
+                    pb, po, ps = frames.to_pel_plane(ys[f], 8)
+                    rb, _, _ = frames.to_pel_plane(ys[f - 1], 8)
+                    nodes = np.zeros((n, 85), capi.MOTION_DTYPE)
+                    sl = oracle.fho_lambda_intra(QPP, 8) ** 0.5
+                    fmin, fmax = np.zeros((n, 256), np.uint8), np.zeros((n, 256), np.uint8)
+                    prev = np.ascontiguousarray(maps[-1])
+                    for c in range(n):
+                        oracle.fho_motion_ctu(C.c_void_p(pb.reshape(-1).ctypes.data + 2 * po), ps, C.c_void_p(rb.reshape(-1).ctypes.data + 2 * po), ps,
+                                              W, H, c % cw, c // cw, 8, 4, C.c_double(sl), C.c_void_p(nodes[c].ctypes.data))
+                        oracle.fho_p_depth_range(nodes[c].ctypes.data, prev[c].ctypes.data, 64, 64, QPP, C.byref(rule), fmin[c].ctypes.data, fmax[c].ctypes.data)
+                d, s = _next_p(lib, ys[f], W, H, QPP, f, fmin, fmax)
+                maps.append(d)
+                stats.append(float(s[6]))
+            return maps, stats
+
+        full_maps, full_bits = run(cpu, False)
+        ref_maps, ref_bits = run(cpu, True)
+        # TEncFastDepth reads the I-picture knobs when the encoder object of a geometry is built: build it before FHEVC_ENABLE is
+        # set, so that POC 0 runs stock RDO in both builds; the P pictures re-read the knobs (href_rdo_encode_next_p)
+        op.rdo_encode(gpu, buf, org, stride, W, H, 8, QPI, chroma=(u, u))
+        os.environ.update({"FHEVC_P_MODE": "motion", "FHEVC_ENABLE": "1", "FHEVC_WEIGHTS": BLOB, "FHEVC_P_RANGE": "4"})
+        gpu_maps, gpu_bits = run(gpu, False)
+        for f in range(4):
+            assert np.array_equal(gpu_maps[f], ref_maps[f]), f
+            assert gpu_bits[f] == ref_bits[f], f
+        assert np.array_equal(gpu_maps[1], full_maps[1])                       # POC 1 (reference picture is intra): stock RDO
+        assert any(not np.array_equal(gpu_maps[f], full_maps[f]) for f in (2, 3))   # the ranges did restrict POC 2 / 3
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
