@@ -2,13 +2,18 @@
 """bench.py -- CTU depth decisions/s of the MI355X fast-decision path (BASELINE.json metric).
 
 One step = one pass of the hot path (CTU load -> source Hadamard -> depth CNN -> depth map in HBM) over one GOP of
-synthetic 1080p luma already resident in HBM.  N > 1: one process per GPU (torch.distributed, "nccl" = RCCL over
-xGMI), every rank owns its own GOP (frames dealt to ranks: weak scaling) and the step ends with the single
-all-gather of the depth maps.  Prints ONE JSON line on rank 0.
+synthetic 1080p luma already resident in HBM.  N > 1: one process per GPU (torch.distributed, "nccl" = RCCL over xGMI);
+the step ends with the path's single all-gather of the depth decisions (fasthevc_amd/gather.py):
+  --scaling weak   (default) every rank owns its own GOP of --frames pictures (frames dealt to ranks, work grows with N)
+  --scaling strong           ONE GOP of --frames pictures split over the ranks
+  --bands                    CTU-row bands of every picture (BASELINE config 3: 3840x2160 unless --width/--height say otherwise)
+Prints ONE JSON line on rank 0.  The timed region (exactly --steps steps between barrier + synchronize) is repeated
+--repeats times; `value` is the median region, min / median / max are reported next to it.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -22,185 +27,263 @@ MAC_PER_CTU = 4096 * 9 * 16 + 1024 * 144 * 32 + 256 * 288 * 64 + (4096 + 4 * 409
 FLOP_PER_CTU = 2 * MAC_PER_CTU
 PEAK_BF16_TFLOPS = 2500.0   # dense 16-bit (bf16 = f16) MFMA, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
+PEAK_PCIE_GBS = 63.0        # PCIe Gen5 x16 (spec), MI355X_MICROARCH.md
 PEAK_INT32_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12  # 256 CUs x 4 SIMD x 16 lanes x 2.4 GHz: one 32-bit integer op per lane-cycle (39.3)
+CROPS = ((0, 0), (768, 0), (1152, 0), (0, 512), (768, 512), (1152, 512), (384, 256), (960, 256),
+         (192, 128), (576, 384), (1088, 64), (128, 448), (640, 192), (1024, 320))
+CROP_W, CROP_H = 768, 512   # 96 CTUs, about 1 s of the reference's full RDO
 
 
-def cpu_baseline(width, height, bit_depth, w, seconds=12.0):
-    """CPU baseline on a bounded sample of the same workload, 1 host thread.
-
-    kind "reference": HM's own full-RDO decision path (TEncSlice::compressSlice -> TEncCu::xCompressCU of the reference,
-    oracle/_ref/libhmref.so, built from /root/reference in the build container and shipped as a built artefact).
-    kind "port": the CPU oracle of the GPU path (depth CNN + source Hadamard) when that library is not present."""
+def _rdo_crops(lib, width, height, bit_depth, seconds, first=0):
+    """the reference's own compressSlice on crops of the pinned 1080p hetero picture for about `seconds`: (CTUs, seconds)"""
     from oracle import oracle_py as op
     from fasthevc_amd import frames
     luma = frames.hetero_luma(width, height)
-    if op.have_ref():
-        lib = op.bind_rdo(op.load_ref())
-        cu, cv = frames.chroma_planes("hetero", width, height)
-        cw_, ch_ = 768, 512  # crops of the picture: 96 CTUs each, about 1.5 s of full RDO
-        done, spent, crops = 0, 0.0, 0
-        for (ox, oy) in ((0, 0), (768, 0), (1152, 0), (0, 512), (768, 512), (1152, 512), (384, 256), (960, 256),
-                         (192, 128), (576, 384), (1088, 64), (128, 448), (640, 192), (1024, 320)):
-            if oy + ch_ > height or ox + cw_ > width:
-                continue
-            buf, org, stride = frames.to_pel_plane(luma[oy:oy + ch_, ox:ox + cw_].copy(), bit_depth)
-            chroma = tuple((c[oy // 2:(oy + ch_) // 2, ox // 2:(ox + cw_) // 2].astype(np.int16) << (bit_depth - 8)) for c in (cu, cv))
-            _, st = op.rdo_encode(lib, buf, org, stride, cw_, ch_, bit_depth, 32, chroma=chroma)
-            done += st["ctus"]
-            spent += st["seconds"]
-            crops += 1
-            if spent > seconds:
-                break
-        out = {"value": done / spent, "unit": "CTU depth decisions/s", "cores": 1, "kind": "reference",
-               "sample": f"{crops} crops of 768x512 ({done} CTUs) of the same 1080p hetero frame at QP32 through the reference's own "
-                         f"TEncSlice::compressSlice/TEncCu::xCompressCU full RDO (intra_main settings), {spent:.1f} s of 1 thread"}
-        # the same compressSlice with the hm_patch hook linked to the GPU library (oracle/_ref/libhmref_hookgpu.so): HM's
-        # decision stage end to end, GPU call (H2D + kernels + D2H) included, on the same crops
-        gpu_so = os.path.join(ROOT, "oracle", "_ref", "libhmref_hookgpu.so")
-        blob = os.path.join(ROOT, "fasthevc_amd", "weights", "depthnet_v1.fhw")
-        if os.path.exists(gpu_so) and os.path.exists(blob):
-            knobs = {"FHEVC_ENABLE": "1", "FHEVC_WEIGHTS": blob, "FHEVC_MARGIN_SPLIT": "32000", "FHEVC_MARGIN_STOP": "0"}
-            saved = {k: os.environ.get(k) for k in knobs}
-            os.environ.update(knobs)
-            try:
-                glib = op.bind_rdo(op.load_ref(hook="gpu"))
-                gdone, gspent = 0, 0.0
-                for (ox, oy) in ((0, 0), (768, 0), (1152, 0), (0, 512), (768, 512), (1152, 512), (384, 256), (960, 256))[:crops]:
-                    buf, org, stride = frames.to_pel_plane(luma[oy:oy + ch_, ox:ox + cw_].copy(), bit_depth)
-                    chroma = tuple((c[oy // 2:(oy + ch_) // 2, ox // 2:(ox + cw_) // 2].astype(np.int16) << (bit_depth - 8)) for c in (cu, cv))
-                    _, st = op.rdo_encode(glib, buf, org, stride, cw_, ch_, bit_depth, 32, chroma=chroma)
-                    gdone += st["ctus"]
-                    gspent += st["seconds"]
-                out["with_gpu_hook"] = {"value": gdone / gspent, "unit": "CTUs/s through compressSlice", "speedup": (gdone / gspent) / (done / spent),
-                                        "sample": f"{gdone} CTUs, same crops, hm_patch hook -> fhevc_predict_frame_range (margin_split 32000), "
-                                                  f"{gspent:.1f} s of 1 thread incl. the GPU calls"}
-            finally:
-                for k, v in saved.items():
-                    if v is None:
-                        os.environ.pop(k, None)
-                    else:
-                        os.environ[k] = v
-        return out
+    cu, cv = frames.chroma_planes("hetero", width, height)
+    done, spent, crops = 0, 0.0, 0
+    k = first
+    while spent < seconds:
+        ox, oy = CROPS[k % len(CROPS)]
+        k += 1
+        if oy + CROP_H > height or ox + CROP_W > width:
+            continue
+        buf, org, stride = frames.to_pel_plane(luma[oy:oy + CROP_H, ox:ox + CROP_W].copy(), bit_depth)
+        chroma = tuple((c[oy // 2:(oy + CROP_H) // 2, ox // 2:(ox + CROP_W) // 2].astype(np.int16) << (bit_depth - 8)) for c in (cu, cv))
+        _, st = op.rdo_encode(lib, buf, org, stride, CROP_W, CROP_H, bit_depth, 32, chroma=chroma)
+        done += st["ctus"]
+        spent += st["seconds"]
+        crops += 1
+    return done, spent, crops
+
+
+def cpu_worker(argv):
+    """child process of the all-cores CPU baseline (no GPU, no torch): prints {"ctus", "seconds", "crops"}"""
+    width, height, bit_depth, seconds, first = int(argv[0]), int(argv[1]), int(argv[2]), float(argv[3]), int(argv[4])
+    from oracle import oracle_py as op
+    lib = op.bind_rdo(op.load_ref())
+    done, spent, crops = _rdo_crops(lib, width, height, bit_depth, seconds, first)
+    print(json.dumps({"ctus": done, "seconds": spent, "crops": crops}), flush=True)
+
+
+def cpu_baseline_reference(width, height, bit_depth, seconds=10.0, procs=None):
+    """HM's own full-RDO decision path (TEncSlice::compressSlice -> TEncCu::xCompressCU of the reference, oracle/_ref/libhmref.so,
+    built from /root/reference in the build container and shipped as a built artefact) on the host cores: one process, then one
+    process per core (HM is single-threaded).  Runs BEFORE this process touches the GPU: the workers are plain children."""
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    procs = procs or max(1, min(avail, 16))   # a one-GPU box gives 16 cores to a command
+
+    def run(n):
+        t0 = time.perf_counter()
+        ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(width), str(height), str(bit_depth),
+                                str(seconds), str(3 * i)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for i in range(n)]
+        outs = [json.loads(p.communicate()[0].strip().splitlines()[-1]) for p in ps]
+        wall = time.perf_counter() - t0
+        return outs, wall
+
+    one, _ = run(1)
+    out = {"value": one[0]["ctus"] / one[0]["seconds"], "unit": "CTU depth decisions/s", "cores": 1, "kind": "reference",
+           "sample": f"{one[0]['crops']} crops of {CROP_W}x{CROP_H} ({one[0]['ctus']} CTUs) of the same 1080p hetero frame at QP32 through the "
+                     f"reference's own TEncSlice::compressSlice/TEncCu::xCompressCU full RDO (intra_main settings), {one[0]['seconds']:.1f} s of 1 thread"}
+    if procs > 1:
+        many, wall = run(procs)
+        out["all_cores"] = {"value": sum(o["ctus"] / o["seconds"] for o in many), "unit": "CTU depth decisions/s", "cores": procs,
+                            "per_process": [round(o["ctus"] / o["seconds"], 1) for o in many],
+                            "sample": f"{procs} concurrent single-threaded processes (HM has no threads), {sum(o['ctus'] for o in many)} CTUs, "
+                                      f"{np.mean([o['seconds'] for o in many]):.1f} s each inside compressSlice, {wall:.1f} s wall incl. start-up"}
+    return out
+
+
+def cpu_baseline_port(width, height, bit_depth, w, seconds=10.0):
+    """fallback when the reference library is not present: the CPU oracle of the GPU path (depth CNN + source Hadamard), 1 thread"""
+    from oracle import oracle_py as op
+    from fasthevc_amd import frames
     oracle = op.load_oracle()
     ws = op.weights_from_arrays(w)
+    luma = frames.hetero_luma(width, height)
     buf, org, stride = frames.to_pel_plane(luma, bit_depth)
     cw, ch = frames.ctu_grid(width, height)
     ctu = np.zeros(64 * 64, np.int8)
     logits = np.zeros(42, np.int32)
     depth = np.zeros(256, np.uint8)
     done, t0 = 0, time.perf_counter()
-    order = np.random.default_rng(0).permutation(cw * ch)
-    for a in order:
+    for a in np.random.default_rng(0).permutation(cw * ch):
         cx, cy = int(a % cw), int(a // cw)
         oracle.fho_load_ctu(op.ptr(buf.reshape(-1), org), stride, width, height, cx, cy, bit_depth, ctu)
         oracle.fho_cnn_ctu(ws, ctu, 32, logits)
         oracle.fho_depth_from_logits(logits, min(64, width - cx * 64), min(64, height - cy * 64), depth)
-        oracle.fho_ctu_src_hadamard(op.ptr(buf.reshape(-1), org + cy * 64 * stride + cx * 64), stride,
-                                    min(64, width - cx * 64), min(64, height - cy * 64))
+        oracle.fho_ctu_src_hadamard(op.ptr(buf.reshape(-1), org + cy * 64 * stride + cx * 64), stride, min(64, width - cx * 64), min(64, height - cy * 64))
         done += 1
         if time.perf_counter() - t0 > seconds:
             break
     dt = time.perf_counter() - t0
     return {"value": done / dt, "unit": "CTU depth decisions/s", "cores": 1, "kind": "port",
-            "sample": f"{done} CTUs of the same 1080p hetero frame through oracle/fhevc_oracle.c "
-                      f"(depth CNN + source Hadamard, 1 thread, {dt:.1f} s)"}
+            "sample": f"{done} CTUs of the same 1080p hetero frame through oracle/fhevc_oracle.c (depth CNN + source Hadamard, 1 thread, {dt:.1f} s)"}
+
+
+def gpu_hook_leg(width, height, bit_depth, crops):
+    """the same compressSlice with the hm_patch hook linked to the GPU library (oracle/_ref/libhmref_hookgpu.so): HM's decision
+    stage end to end, GPU call (H2D + kernels + D2H) included, on the same crops"""
+    from oracle import oracle_py as op
+    gpu_so = os.path.join(ROOT, "oracle", "_ref", "libhmref_hookgpu.so")
+    blob = os.path.join(ROOT, "fasthevc_amd", "weights", "depthnet_v1.fhw")
+    if not (os.path.exists(gpu_so) and os.path.exists(blob)):
+        return None
+    knobs = {"FHEVC_ENABLE": "1", "FHEVC_WEIGHTS": blob, "FHEVC_MARGIN_SPLIT": "32000", "FHEVC_MARGIN_STOP": "0"}
+    saved = {k: os.environ.get(k) for k in knobs}
+    os.environ.update(knobs)
+    try:
+        glib = op.bind_rdo(op.load_ref(hook="gpu"))
+        done, spent = 0, 0.0
+        from fasthevc_amd import frames
+        luma = frames.hetero_luma(width, height)
+        cu, cv = frames.chroma_planes("hetero", width, height)
+        for (ox, oy) in [c for c in CROPS if c[1] + CROP_H <= height and c[0] + CROP_W <= width][:crops]:
+            buf, org, stride = frames.to_pel_plane(luma[oy:oy + CROP_H, ox:ox + CROP_W].copy(), bit_depth)
+            chroma = tuple((c[oy // 2:(oy + CROP_H) // 2, ox // 2:(ox + CROP_W) // 2].astype(np.int16) << (bit_depth - 8)) for c in (cu, cv))
+            _, st = op.rdo_encode(glib, buf, org, stride, CROP_W, CROP_H, bit_depth, 32, chroma=chroma)
+            done += st["ctus"]
+            spent += st["seconds"]
+        return {"value": done / spent, "unit": "CTUs/s through compressSlice",
+                "sample": f"{done} CTUs, same crops, hm_patch hook -> fhevc_predict_frame_range (margin_split 32000), {spent:.1f} s of 1 thread incl. the GPU calls"}
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def quoted_bd_rate():
+    """the quality half of BASELINE's metric, quoted from the committed evaluations under profiles/ (tests/quality/eval_rd.py,
+    eval_p.py: minutes of CPU each, not re-run here)"""
+    out = {}
+    for tag, name in (("intra", "bdrate_generalization"), ("intra_soft_hook", "bdrate_soft_hook"), ("p_slices", "p_slice_motion_rule")):
+        for rnd in ("r02", "r01"):
+            path = os.path.join(ROOT, "profiles", f"{rnd}_{name}.json")
+            if os.path.exists(path):
+                try:
+                    d = json.load(open(path))
+                    out[tag] = {"source": f"profiles/{rnd}_{name}.json", "summary": d.get("summary", d.get("headline"))}
+                except Exception:
+                    pass
+                break
+    return out or None
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
+        return cpu_worker(sys.argv[2:])
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=64, help="frames per GOP (per rank)")
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--repeats", type=int, default=5, help="how many times the timed region of --steps steps is run (value = median)")
+    ap.add_argument("--frames", type=int, default=None, help="frames per GOP (default 64; 16 with --bands)")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--bit-depth", type=int, default=8)
     ap.add_argument("--sample-bytes", type=int, default=2, help="2 = int16 Pel planes as HM holds them, 1 = uint8")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--bands", action="store_true", help="CTU-row bands of every picture over the ranks (config 3); implies strong scaling")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-stages", action="store_true", help="skip the first-pass / pre-analysis stage report")
+    ap.add_argument("--no-stages", action="store_true", help="skip the first-pass / pre-analysis / motion-search stage report")
+    ap.add_argument("--no-host-path", action="store_true", help="skip the host-to-host (PCIe-inclusive) leg")
+    ap.add_argument("--cpu-procs", type=int, default=None, help="processes of the all-cores CPU baseline (default: host cores, at most 16)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
-
-    import torch
-    import torch.distributed as dist
-    from fasthevc_amd import bands, capi, frames, weights
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    mode = "bands" if args.bands else "frames"
+    scaling = "strong" if args.bands else args.scaling
+    W = args.width or (3840 if args.bands else 1920)
+    H = args.height or (2160 if args.bands else 1080)
+    NF = args.frames or (16 if args.bands else 64)
+    bd = args.bit_depth
+
+    # ---- CPU baseline first: its workers are children of a process that has not touched the GPU yet ----
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle_py as op
+        if op.have_ref():
+            cpu = cpu_baseline_reference(1920, 1080, bd, procs=args.cpu_procs)
+
+    import torch
+    import torch.distributed as dist
+    from fasthevc_amd import capi, frames, gather, weights
+
     if args.one_device:
         assert args.backend != "nccl", "RCCL refuses two ranks on one GPU"
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(args.backend)
+    group, host_group = gather.init_groups(world, rank, dev, args.backend)
 
-    W, H, NF, bd = args.width, args.height, args.frames, args.bit_depth
     trained = os.path.join(ROOT, "fasthevc_amd", "weights", "depthnet_v1.fhw")
     if os.path.exists(trained):
         w, wdesc = weights.load(trained), "trained weights fasthevc_amd/weights/depthnet_v1.fhw"
     else:
         w, wdesc = weights.random_weights(0), "random-init weights"  # same architecture, same arithmetic
-    ctx = capi.Context(W, H, bd, w, device=local, max_frames=NF)
+    total_frames = world * NF if (mode == "frames" and scaling == "weak") else NF
+    ctx = capi.Context(W, H, bd, w, device=local, max_frames=max(1, min(NF, 16)))
     cw, ch, n_ctus = ctx.ctus_x, ctx.ctus_y, ctx.num_ctus
+    fg = gather.FlagGather(mode, world, rank, total_frames, cw, ch, dev, group=group, host_group=host_group)
+    f0, f1 = fg.frames
+    r0, r1 = fg.rows
+    nf_local = f1 - f0
 
-    # synthetic GOP resident in HBM: the pinned "hetero" frame, panned 3 px per frame, per-rank phase
+    # synthetic GOP resident in HBM: the pinned "hetero" frame, panned 3 px per frame; a rank holds the pictures it works on
     base = torch.from_numpy(frames.hetero_luma(W, H).astype(np.int16)).to(dev) << (bd - 8)
     if args.sample_bytes == 2:
         margin = frames.HM_MARGIN
         stride, rows = W + 2 * margin, H + 2 * margin
-        gop = torch.zeros((NF, rows, stride), dtype=torch.int16, device=dev)
-        for f in range(NF):
-            gop[f, margin:margin + H, margin:margin + W] = torch.roll(base, shifts=3 * (f + NF * rank), dims=1)
+        gop = torch.zeros((nf_local, rows, stride), dtype=torch.int16, device=dev)
+        for f in range(nf_local):
+            gop[f, margin:margin + H, margin:margin + W] = torch.roll(base, shifts=3 * (f0 + f), dims=1)
         origin, frame_stride = margin * stride + margin, rows * stride
         luma_ptr = gop.data_ptr() + 2 * origin
     else:
         assert bd == 8
         stride, frame_stride = W, W * H
-        gop = torch.stack([torch.roll(base, shifts=3 * (f + NF * rank), dims=1) for f in range(NF)]).to(torch.uint8).contiguous()
+        gop = torch.stack([torch.roll(base, shifts=3 * (f0 + f), dims=1) for f in range(nf_local)]).to(torch.uint8).contiguous()
         luma_ptr = gop.data_ptr()
 
-    # every rank ends a step with the depth maps of the WHOLE GOP (all ranks' frames) in `gathered`; on the wire the
-    # maps travel as 4-byte split-flag words per CTU (64x less than 256 B) and are expanded on arrival
-    gathered = torch.zeros((world, NF, n_ctus, 256), dtype=torch.uint8, device=dev)
-    # double-buffered so that the all-gather of step i (RCCL's own stream) overlaps the kernels of step i+1
-    flags_all = [bands.alloc_flag_buffers(NF, n_ctus, world, dev) for _ in range(2)]   # receive buffers of the all-gather
-    flags_mine = [torch.zeros((NF, n_ctus), dtype=torch.int32, device=dev) for _ in range(2)]  # this rank's words (send)
-    had = torch.zeros((NF, n_ctus), dtype=torch.int32, device=dev)
-    # A real (non-null) torch stream for everything that follows: the library treats a NULL stream handle as "the context's
-    # own stream", which torch's collectives (ordered against torch's CURRENT stream) would not see.  With it the kernels,
-    # the all-gather's stream dependencies and the expansion are all expressed on one stream.
+    # every rank ends a step with the depth maps of the WHOLE step (all ranks' pictures / bands) in `gathered`
+    gathered = torch.zeros((total_frames, n_ctus, 256), dtype=torch.uint8, device=dev)
+    own = torch.zeros((max(1, fg.local_ctus), 256), dtype=torch.uint8, device=dev)   # this rank's maps, compact
+    had = torch.zeros(max(1, fg.local_ctus), dtype=torch.int32, device=dev)
+    # A real (non-null) torch stream: the collective is ordered against torch's CURRENT stream, so the kernels, the gather's
+    # dependencies and the expansion are all expressed on one stream
     torch.cuda.synchronize()
     tstream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(tstream)
     stream = tstream.cuda_stream
     assert stream != 0
-    inflight = []  # [(work, buffer index)]: at most one collective in flight
+    pending = [False]
 
     def finish_gather():
-        """wait for the collective in flight and expand its words into the depth maps of the whole GOP"""
-        while inflight:
-            work, b = inflight.pop()
-            work.wait()
-            ctx.expand_depth_flags_device(flags_all[b].data_ptr(), world * NF, gathered.data_ptr(), stream=stream)
+        """wait for the collective in flight and expand its words into the depth maps of the whole step"""
+        if pending[0]:
+            words = fg.finish()
+            ctx.expand_depth_flags_device(words.data_ptr(), total_frames, gathered.data_ptr(), stream=stream)
+            pending[0] = False
 
     def step(i):
         b = i & 1
-        ctx.predict_frames_device(luma_ptr, args.sample_bytes, stride, frame_stride, NF, gathered[rank].data_ptr(),
-                                  had.data_ptr(), None, stream=stream, d_flags=flags_mine[b].data_ptr() if world > 1 else None)
+        dst = gathered if world == 1 else own
+        ctx.predict_frames_device(luma_ptr, args.sample_bytes, stride, frame_stride, nf_local, dst.data_ptr(), had.data_ptr(), None,
+                                  rows=(r0, r1), stream=stream, d_flags=fg.local_words(b).data_ptr() if world > 1 else None)
         if world > 1:
-            finish_gather()  # step i-1's gather has had this step's kernels to hide under
-            inflight.append((dist.all_gather_into_tensor(flags_all[b].view(-1), flags_mine[b].view(-1), async_op=True), b))  # the path's only collective
+            finish_gather()   # step i-1's gather has had this step's kernels to hide under
+            fg.start(b)       # the path's only collective
+            pending[0] = True
 
     def fence():
-        finish_gather()  # every step's maps are gathered and expanded before the clock stops
+        finish_gather()       # every step's maps are gathered and expanded before the clock stops
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -211,105 +294,185 @@ def main():
     ctx.enable_kernel_timing(True)
     ctx.kernel_timing(0, reset=True)
     ctx.kernel_timing(1, reset=True)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    regions = []
+    for _ in range(max(1, args.repeats)):
+        fence()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        regions.append(dt)
     cnn_ms, cnn_n = ctx.kernel_timing(0)
     had_ms, had_n = ctx.kernel_timing(1)
 
-    # untimed check of the N > 1 path: what the all-gather + expansion left in `gathered` must be this rank's own maps
-    # in its slot, and the same bytes on every rank
+    # untimed check of the N > 1 path: what gather + expansion left in `gathered` must contain this rank's own maps at their
+    # place, and the same bytes on every rank
     gather_ok = None
     if world > 1:
-        own = torch.empty((NF, n_ctus, 256), dtype=torch.uint8, device=dev)
-        ctx.predict_frames_device(luma_ptr, args.sample_bytes, stride, frame_stride, NF, own.data_ptr(), None, None, stream=stream)
+        check = torch.zeros((max(1, fg.local_ctus), 256), dtype=torch.uint8, device=dev)
+        ctx.predict_frames_device(luma_ptr, args.sample_bytes, stride, frame_stride, nf_local, check.data_ptr(), None, None, rows=(r0, r1), stream=stream)
         torch.cuda.synchronize()
-        chk = torch.tensor([float(torch.equal(own, gathered[rank])), float(gathered.to(torch.int64).sum().item())],
-                           dtype=torch.float64, device=dev)
+        g = gathered.view(total_frames, ch, cw, 256)
+        mine = g[f0:f1, r0:r1].reshape(-1, 256)
+        chk = torch.tensor([float(torch.equal(check, mine)), float(gathered.to(torch.int64).sum().item())], dtype=torch.float64, device=dev)
         lo, hi = chk.clone(), chk.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         gather_ok = bool(lo[0].item() == 1.0 and lo[1].item() == hi[1].item() and len(torch.unique(gathered)) > 1)
 
-    # the path's other stages (SURVEY 8(d) stage 3 and 8(f) N3), measured AFTER the timed region on the same GOP: the
-    # 35-mode SATD first pass over 8 of the frames and the AQ pre-analysis over all of them -- reported, never in `value`
+    # ---- host to host ("depth map delivered to host memory"): the same GOP from pinned host memory through
+    # fhevc_predict_frames (chunks of 16 pictures over two streams), PCIe included; never `value` ----
+    host = None
+    if rank == 0 and world == 1 and not args.no_host_path:
+        host = {}
+        torch.cuda.synchronize()
+        for label, sb in (("uint8_planes", 1), ("int16_pel_planes", 2)):
+            if sb == 1 and bd != 8:
+                continue
+            if sb == 1:
+                src = ctx.alloc_host((NF, H, W), np.uint8)
+                src[:] = torch.stack([torch.roll(base, shifts=3 * f, dims=1) for f in range(NF)]).to(torch.uint8).cpu().numpy()
+                kw = {}
+            else:
+                m = frames.HM_MARGIN
+                src = ctx.alloc_host((NF, H + 2 * m, W + 2 * m), np.int16)
+                src[:] = 0
+                src[:, m:m + H, m:m + W] = torch.stack([torch.roll(base, shifts=3 * f, dims=1) for f in range(NF)]).cpu().numpy()
+                kw = {"origin": m * (W + 2 * m) + m, "stride": W + 2 * m, "frame_stride": (H + 2 * m) * (W + 2 * m)}
+            dout = ctx.alloc_host((NF, n_ctus, 256), np.uint8)
+            hout = ctx.alloc_host((NF, n_ctus), np.int32)
+            ctx.predict_frames(src, qp=32, depth_out=dout, had_out=hout, **kw)   # warm-up (allocates the ring)
+            s0 = ctx.stats()
+            times = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                ctx.predict_frames(src, qp=32, depth_out=dout, had_out=hout, **kw)
+                times.append(time.perf_counter() - t0)
+            s1 = ctx.stats()
+            moved = (s1["bytes_h2d"] - s0["bytes_h2d"] + s1["bytes_d2h"] - s0["bytes_d2h"]) / 5
+            tm = float(np.median(times))
+            same = bool(np.array_equal(dout.reshape(-1), gathered.cpu().numpy().reshape(-1))) if (sb == args.sample_bytes and total_frames == NF) else None
+            host[label] = {"ctu_per_s": NF * n_ctus / tm, "ms_per_gop": tm * 1e3, "min_ms": min(times) * 1e3, "max_ms": max(times) * 1e3,
+                           "pcie_GB_s": moved / tm / 1e9, "pcie_peak_GB_s": PEAK_PCIE_GBS, "pcie_frac": moved / tm / 1e9 / PEAK_PCIE_GBS,
+                           "bytes_per_gop": moved, "equals_device_resident_maps": same}
+            for a in (src, dout, hout):
+                ctx.free_host(a)
+        host["how"] = "fhevc_predict_frames: pinned host GOP -> H2D -> source Hadamard + depth CNN -> D2H of maps + Hadamards, 16-picture chunks on two streams, 5 runs (median)"
+
+    # the path's other stages, measured AFTER the timed region on the same GOP -- reported, never in `value`
     stages = None
     if rank == 0 and not args.no_stages:
-        nb = min(NF, 8)
+        nb = min(nf_local, 8)
         nodes = torch.zeros((nb * n_ctus * 85, 2), dtype=torch.float64, device=dev)
-        act = torch.zeros((NF, ctx.aq_layout(4)[-1]), dtype=torch.float64, device=dev)
+        act = torch.zeros((nf_local, ctx.aq_layout(4)[-1]), dtype=torch.float64, device=dev)
+        mot = torch.zeros((max(1, nf_local - 1) * n_ctus * 85, 4), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
         for timed in (False, True):
-            ctx.kernel_timing(2, reset=True)
-            ctx.kernel_timing(3, reset=True)
+            for k in (2, 3, 4):
+                ctx.kernel_timing(k, reset=True)
             for _ in range(3):
                 ctx.intra_first_pass_device(luma_ptr, args.sample_bytes, stride, frame_stride, nb, nodes.data_ptr(), stream=stream, qp=32)
-                ctx.preanalyze_frames_device(luma_ptr, args.sample_bytes, stride, frame_stride, NF, act.data_ptr(), 4, stream=stream)
+                ctx.preanalyze_frames_device(luma_ptr, args.sample_bytes, stride, frame_stride, nf_local, act.data_ptr(), 4, stream=stream)
+                if nf_local > 1:
+                    ctx.motion_search_device(luma_ptr, args.sample_bytes, stride, frame_stride, nf_local, mot.data_ptr(), stream=stream, qp=38, search_range=4)
             torch.cuda.synchronize()
         fp_ms, _ = ctx.kernel_timing(2)
         pre_ms, _ = ctx.kernel_timing(3)
+        mo_ms, _ = ctx.kernel_timing(4)
         int_ops = nb * n_ctus * 4 * 35 * 64 * (64 + 575)  # per (level, mode, 8x8 tile) 64 predicted samples + ~575 Hadamard ops
-        pre_bytes = NF * (W * H * args.sample_bytes + act.shape[1] * 8)
+        pre_bytes = nf_local * (W * H * args.sample_bytes + act.shape[1] * 8)
+        mo_ops = (nf_local - 1) * n_ctus * 81 * 64 * (64 + 575)  # per (vector, 8x8 tile): 64 differences + ~575 Hadamard ops
         stages = {
             "first_pass": {"kernel": "fhevc_first_pass_kernel", "frames": nb, "avg_launch_ms": fp_ms, "ctu_per_s": nb * n_ctus / (fp_ms * 1e-3),
                            "bound": "int VALU/LDS", "achieved_Tintop_s": int_ops / (fp_ms * 1e-3) / 1e12, "peak_Tintop_s": PEAK_INT32_TOPS,
-                           "frac": int_ops / (fp_ms * 1e-3) / 1e12 / PEAK_INT32_TOPS,
-                           "vs_hadamard_time_per_frame": (fp_ms / nb) / (had_ms / NF) if had_ms else None},
-            "preanalyze": {"kernel": "fhevc_preanalyze_kernel", "frames": NF, "avg_launch_ms": pre_ms, "bound": "hbm",
+                           "frac": int_ops / (fp_ms * 1e-3) / 1e12 / PEAK_INT32_TOPS},
+            "preanalyze": {"kernel": "fhevc_preanalyze_kernel", "frames": nf_local, "avg_launch_ms": pre_ms, "bound": "hbm",
                            "achieved_GB_s": pre_bytes / (pre_ms * 1e-3) / 1e9, "peak_GB_s": PEAK_HBM_GBS,
                            "frac": pre_bytes / (pre_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
         }
+        if nf_local > 1 and mo_ms:
+            stages["motion_search"] = {"kernel": "fhevc_motion_kernel", "picture_pairs": nf_local - 1, "search_range": 4, "avg_launch_ms": mo_ms,
+                                       "ctu_per_s": (nf_local - 1) * n_ctus / (mo_ms * 1e-3), "bound": "int VALU/LDS",
+                                       "achieved_Tintop_s": mo_ops / (mo_ms * 1e-3) / 1e12, "peak_Tintop_s": PEAK_INT32_TOPS,
+                                       "frac": mo_ops / (mo_ms * 1e-3) / 1e12 / PEAK_INT32_TOPS}
     ctx.enable_kernel_timing(False)
 
     def measured_traffic(kernel):
         """HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes,
         FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) -- only for the workload they were taken on."""
-        path = os.path.join(ROOT, "profiles", "r01_pmc_bench_frames64_int16.json")
-        if not (os.path.exists(path) and NF == 64 and args.sample_bytes == 2 and (W, H) == (1920, 1080)):
-            return None
-        d = json.load(open(path))
-        for k, v in d.items():
-            if k.startswith(kernel) and "hbm_read_bytes_corrected" in v and "hbm_write_bytes" in v:
-                return v["hbm_read_bytes_corrected"] + v["hbm_write_bytes"]
-        return None
+        if not (NF == 64 and args.sample_bytes == 2 and (W, H) == (1920, 1080) and mode == "frames"):
+            return None, None
+        for rnd in ("r02", "r01"):
+            path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_bench_frames64_int16.json")
+            if os.path.exists(path):
+                d = json.load(open(path))
+                for k, v in d.items():
+                    if k.startswith(kernel) and "hbm_read_bytes_corrected" in v and "hbm_write_bytes" in v:
+                        return v["hbm_read_bytes_corrected"] + v["hbm_write_bytes"], f"profiles/{rnd}_pmc_bench_frames64_int16.json (commit {d.get('commit', 'of that round')})"
+        return None, None
 
     if rank == 0:
-        ctus_per_step = world * NF * n_ctus
-        value = ctus_per_step * args.steps / dt
-        flop_per_launch = FLOP_PER_CTU * NF * n_ctus
+        ctus_per_step = total_frames * n_ctus
+        thr = sorted(ctus_per_step * args.steps / t for t in regions)
+        value = float(np.median(thr))
+        dt = ctus_per_step * args.steps / value
+        local_ctus = fg.local_ctus
+        flop_per_launch = FLOP_PER_CTU * local_ctus
         sample_b = args.sample_bytes
-        bytes_per_launch_had = NF * (W * H * sample_b + n_ctus * 4)
+        band_px = nf_local * W * min(H, (r1 - r0) * 64)
+        bytes_per_launch_had = band_px * sample_b + local_ctus * 4
+        traffic, traffic_src = measured_traffic("fhevc_cnn_depth_kernel")
         roof = {"bound": "mfma", "kernel": "fhevc_cnn_depth_kernel", "achieved": flop_per_launch / (cnn_ms * 1e-3) / 1e12 if cnn_ms else None,
-                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "traffic": measured_traffic("fhevc_cnn_depth_kernel"),
-                "avg_launch_ms": cnn_ms, "launches": cnn_n, "flop_per_ctu": FLOP_PER_CTU}
+                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "traffic": traffic, "traffic_source": traffic_src,
+                "avg_launch_ms": cnn_ms, "launches": cnn_n, "flop_per_ctu": FLOP_PER_CTU, "ctus_per_launch": local_ctus}
         roof["frac"] = roof["achieved"] / roof["peak"] if roof["achieved"] else None
+        htraffic, htraffic_src = measured_traffic("fhevc_src_hadamard_kernel")
         hbm = {"bound": "hbm", "kernel": "fhevc_src_hadamard_kernel", "achieved": bytes_per_launch_had / (had_ms * 1e-3) / 1e9 if had_ms else None,
-               "peak": PEAK_HBM_GBS, "unit": "GB/s", "traffic": measured_traffic("fhevc_src_hadamard_kernel"), "avg_launch_ms": had_ms, "launches": had_n,
+               "peak": PEAK_HBM_GBS, "unit": "GB/s", "traffic": htraffic, "traffic_source": htraffic_src, "avg_launch_ms": had_ms, "launches": had_n,
                "bytes_per_launch": bytes_per_launch_had}
         hbm["frac"] = hbm["achieved"] / hbm["peak"] if hbm["achieved"] else None
+        geom = "BQTerrace geometry" if (W, H) == (1920, 1080) else "synthetic"
         line = {
-            "metric": "CTU depth decisions/sec at 1080p all-intra", "value": value, "unit": "CTU/s",
+            "metric": "CTU depth decisions/sec at 1080p all-intra + BD-rate delta vs full-RDO HM" if (W, H) == (1920, 1080) else f"CTU depth decisions/sec at {W}x{H} all-intra",
+            "value": value, "unit": "CTU/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "bf16 (conv1) and f16 (conv2, conv3) operands / f32 accumulate (fixed-point valued, exact)", "data": "synthetic",
-            "config": {"workload": f"BQTerrace geometry {W}x{H} all-intra QP32, GOP of {NF} synthetic 'hetero' frames per GPU "
+            "config": {"workload": f"{geom} {W}x{H} all-intra QP32, GOP of {total_frames} synthetic 'hetero' frames "
                                    f"({'int16 Pel planes, HM stride/margins' if sample_b == 2 else 'uint8 planes'}) resident in HBM, "
                                    f"source Hadamard + CTU-batched CNN depth predictor, {wdesc}",
-                       "frames_per_gpu": NF, "ctus_per_frame": n_ctus, "bit_depth": bd,
-                       "sharding": "frames dealt to ranks + one all-gather of the depth maps (as 4-byte split-flag words per CTU, expanded on every rank)" if world > 1 else "single GPU"},
+                       "frames_per_step": total_frames, "frames_per_gpu": nf_local, "ctu_rows_per_gpu": r1 - r0, "ctus_per_frame": n_ctus, "bit_depth": bd,
+                       "sharding": "single GPU" if world == 1 else (
+                           ("CTU-row bands of every picture" if mode == "bands" else "pictures dealt to ranks") +
+                           " + one all-gather of the depth decisions (4-byte split-flag words per CTU, padded equal slices, expanded on every rank)")},
+            "repeats": {"n": len(regions), "region_steps": args.steps, "min": thr[0], "median": value, "max": thr[-1],
+                        "region_ms": [round(t * 1e3, 3) for t in regions]},
             "roofline": roof, "roofline_hbm_kernel": hbm,
         }
+        bdr = quoted_bd_rate()
+        if bdr:
+            line["bd_rate"] = bdr
+        if host:
+            line["host_to_host"] = host
         if stages:
             line["stages"] = stages
-        if gather_ok is not None:
+        if world > 1:
             line["gather_verified"] = gather_ok
+            line["collective"] = fg.status
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(W, H, bd, w)
+            if cpu is None:
+                cpu = cpu_baseline_port(1920, 1080, bd, w)
+            else:
+                hook = gpu_hook_leg(1920, 1080, bd, crops=8)
+                if hook:
+                    hook["speedup"] = hook["value"] / cpu["value"]
+                    cpu["with_gpu_hook"] = hook
+            line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)
     ctx.close()
     if world > 1:

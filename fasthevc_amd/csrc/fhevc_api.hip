@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -32,6 +33,7 @@ struct fhevc_ctx {
   int16_t* d_satd = nullptr; uint32_t* d_satd_out = nullptr;
   hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
   // kernel timing
+  bool fuse_hadamard = true;  // FHEVC_FUSE_HADAMARD=0 keeps the stand-alone Hadamard launch (A/B measurements)
   bool timing = false;
   std::vector<TimedLaunch> pending;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
@@ -297,6 +299,7 @@ int fhevc_create(fhevc_ctx** out, const fhevc_cfg* cfg)
   if (hipSetDevice(c->device) != hipSuccess || hipGetDeviceProperties(&prop, c->device) != hipSuccess) { delete c; return FHEVC_E_NO_DEVICE; }
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) { delete c; return FHEVC_E_NO_DEVICE; }  // code object is gfx950-only
   c->num_cus = prop.multiProcessorCount;
+  if (const char* fz = std::getenv("FHEVC_FUSE_HADAMARD")) c->fuse_hadamard = fz[0] != '0';
   c->ctus_x = (cfg->width + 63) / 64;
   c->ctus_y = (cfg->height + 63) / 64;
   c->num_ctus = c->ctus_x * c->ctus_y;
@@ -398,14 +401,17 @@ int fhevc_predict_frames_device_range(fhevc_ctx* c, const void* d_luma, int samp
   (void)hipSetDevice(c->device);
   hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
   const FhevcFrames fr = frames_of(c, d_luma, sample_bytes, stride_samples, frame_stride_samples, num_frames, ctu_row_begin, ctu_row_end, qp);
-  if (d_hadamard) {
+  // the source Hadamard rides on the depth kernel's own pass over the frame wherever the layout allows the fused form
+  // (aligned planes, widths that are multiples of 16, up to 10 bit); otherwise it is its own HBM-bound launch
+  const bool fuse = d_hadamard && c->fuse_hadamard && fhevc_cnn_can_fuse_hadamard(fr);
+  if (d_hadamard && !fuse) {
     time_begin(c, s, 1);
     HIP_TRY(c, fhevc_launch_src_hadamard(fr, d_hadamard, s));
     time_end(c, s);
     c->stats.kernels_launched++;
   }
   time_begin(c, s, 0);
-  HIP_TRY(c, fhevc_launch_cnn(fr, cnn_weights(c), d_depth_map, d_logits, d_flags, d_depth_max, margin_split, margin_stop, c->num_cus, s));
+  HIP_TRY(c, fhevc_launch_cnn(fr, cnn_weights(c), d_depth_map, fuse ? d_hadamard : nullptr, d_logits, d_flags, d_depth_max, margin_split, margin_stop, c->num_cus, s));
   time_end(c, s);
   c->stats.kernels_launched++;
   c->stats.frames += (uint64_t)num_frames;

@@ -39,7 +39,10 @@ struct FhevcCnnWeights {
 
 hipError_t fhevc_cnn_prepare_device();  // LDS opt-in of the depth kernel on the current device (once per context)
 // d_depth_max / margins: soft decisions (nullptr / 0, 0 = the plain map only)
-hipError_t fhevc_launch_cnn(const FhevcFrames& fr, const FhevcCnnWeights& w, uint8_t* d_depth, int32_t* d_logits,
+// d_had != nullptr: the per-CTU source Hadamard is computed inside the depth kernel from the samples it loads anyway (one
+// pass over the frame); allowed only where fhevc_cnn_can_fuse_hadamard(fr), otherwise use fhevc_launch_src_hadamard
+bool fhevc_cnn_can_fuse_hadamard(const FhevcFrames& fr);
+hipError_t fhevc_launch_cnn(const FhevcFrames& fr, const FhevcCnnWeights& w, uint8_t* d_depth, int32_t* d_had, int32_t* d_logits,
                             uint32_t* d_flags, uint8_t* d_depth_max, int margin_split, int margin_stop, int num_cus, hipStream_t stream);
 hipError_t fhevc_launch_expand_flags(const FhevcFrames& fr, const uint32_t* d_flags, uint8_t* d_depth, hipStream_t stream);
 

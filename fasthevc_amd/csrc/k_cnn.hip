@@ -55,9 +55,10 @@ constexpr int R2_BYTES = 4 * A2_PLANE;            // 21504
 constexpr int IN_PITCH = 68;                      // dwords per input row PAIR (66 used): lo = row 2j, hi = row 2j+1
 constexpr int BIAS_OFF = R2_OFF + R2_BYTES;       // float b1[16] b2[32] b3[64]
 constexpr int LOGIT_OFF = BIAS_OFF + 112 * 4;     // int logits[21][2] (the 64-level pair is formed by the readers) + at [44..51] the
-                                                  // four waves' partial 64-level sums
-constexpr int HEADW_OFF = LOGIT_OFF + 56 * 4;     // int8 head weights: wh64, wh32, wh16 = 18432 B
-constexpr int LDS_BYTES = HEADW_OFF + 18432;      // 79776 -> two workgroups per CU (155.8 of 160 KiB)
+                                                  // four waves' partial 64-level sums; at [56..63] two sets of the four waves' source-
+                                                  // Hadamard sums (the set of the CTU in flight and the set of the next one)
+constexpr int HEADW_OFF = LOGIT_OFF + 64 * 4;     // int8 head weights: wh64, wh32, wh16 = 18432 B
+constexpr int LDS_BYTES = HEADW_OFF + 18432;      // 79808 -> two workgroups per CU (155.9 of 160 KiB)
 static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
 static_assert(A2_PLANE % 256 == 0, "conv3 reads lane group kg of a ds_read_b128 from plane kg");
 static_assert(33 * IN_PITCH * 4 <= R2_BYTES, "input tile must fit the A2 region");
@@ -305,10 +306,12 @@ __device__ __forceinline__ CtuPos advance(CtuPos c, const CtuPos& step, int band
   if (c.ry >= band_rows) { c.ry -= band_rows; c.f++; }
   return c;
 }
+template <bool ZERO>
 __device__ __forceinline__ Prefetched prefetch_ctu(const FhevcFrames& F, bool live, CtuPos c, int ld_row, int ld_seg)
 {
   Prefetched p;
   p.fast = 0;  // a, b stay undefined unless fast (stage_ctu reads them only then): no zero-fill instructions on the way
+  if (ZERO) { p.a = make_uint4(0, 0, 0, 0); p.b = make_uint4(0, 0, 0, 0); }  // the fused source Hadamard reads them either way
   if (!live) return p;
   const int pf = c.f, pcy = F.row_begin + c.ry, pcx = c.cx;
   const int py = pcy * 64 + ld_row, px0 = pcx * 64 + ld_seg * 16;
@@ -329,6 +332,87 @@ __device__ __forceinline__ Prefetched prefetch_ctu(const FhevcFrames& F, bool li
 }
 
 typedef __attribute__((ext_vector_type(2))) short s16x2;
+// ---- source Hadamard fused into the CTU load (TEncCu::updateCtuDataISlice, TEncCu.cpp:1230-1343; the stand-alone twin is
+// k_hadamard.hip) ----------------------------------------------------------------------------------------------------------
+// A thread holds 16 samples of one picture row = one row of two horizontally adjacent 8x8 blocks (registers 0-3: block A,
+// 4-7: block B, two samples per register); the 8 rows of a block sit in the 8 lanes lane ^ {4, 8, 16} of the wave.  The
+// 2-D Walsh-Hadamard transform runs on packed 16-bit VALU (coefficients below 2^15 through five stages up to 10 bit; DC is
+// never formed): horizontal distances 2 and 4 between registers, vertical distances 1, 2, 4 across lanes with a register-
+// PAIR exchange (DPP row shifts under bank masks for lane ^ 4 and lane ^ 8, v_permlane16_swap for lane ^ 16): after the
+// exchange one register of the pair holds the butterfly of P in the lanes of the upper rows and of Q in the lower ones, so
+// every lane does useful work; where a coefficient ends up does not matter for a sum of absolute values.  The last stage
+// (horizontal distance 1, inside a register) is folded into the sum: |a + b| + |a - b| = 2 max(|a|, |b|); the block's DC term
+// |a + b| of that pair is the plain sum of its samples, subtracted at the end (TEncCu.cpp:1319).
+__device__ __forceinline__ unsigned hpk_add(unsigned a, unsigned b) { return __builtin_bit_cast(unsigned, (s16x2)(__builtin_bit_cast(s16x2, a) + __builtin_bit_cast(s16x2, b))); }
+__device__ __forceinline__ unsigned hpk_sub(unsigned a, unsigned b) { return __builtin_bit_cast(unsigned, (s16x2)(__builtin_bit_cast(s16x2, a) - __builtin_bit_cast(s16x2, b))); }
+template <int SHR, int SHL, int BANK_HI, int BANK_LO>
+__device__ __forceinline__ void had_exchange(unsigned& P, unsigned& Q)
+{
+  const unsigned p2 = (unsigned)__builtin_amdgcn_update_dpp((int)P, (int)Q, SHR, 0xF, BANK_HI, false);  // lanes of the upper rows take Q from lane - k
+  const unsigned q2 = (unsigned)__builtin_amdgcn_update_dpp((int)Q, (int)P, SHL, 0xF, BANK_LO, false);  // lanes of the lower rows take P from lane + k
+  P = hpk_add(p2, q2);
+  Q = hpk_sub(p2, q2);
+}
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+// -> the sum over this wave's 16 whole 8x8 blocks of (sum |WHT8x8| - |DC| + 2) >> 2, in every lane.  Threads without samples
+// (rows or columns outside the picture) pass zeros: their blocks then contribute (0 + 2) >> 2 = 0.
+template <int SB>
+__device__ __forceinline__ int wave_src_hadamard(const Prefetched& pre, int lane)
+{
+  unsigned r[8];
+  if (SB == 2) {
+    r[0] = pre.a.x; r[1] = pre.a.y; r[2] = pre.a.z; r[3] = pre.a.w; r[4] = pre.b.x; r[5] = pre.b.y; r[6] = pre.b.z; r[7] = pre.b.w;
+  } else {  // bytes -> 16-bit pairs (selector 0x0C = zero byte)
+    r[0] = __builtin_amdgcn_perm(0u, pre.a.x, 0x0C010C00u); r[1] = __builtin_amdgcn_perm(0u, pre.a.x, 0x0C030C02u);
+    r[2] = __builtin_amdgcn_perm(0u, pre.a.y, 0x0C010C00u); r[3] = __builtin_amdgcn_perm(0u, pre.a.y, 0x0C030C02u);
+    r[4] = __builtin_amdgcn_perm(0u, pre.a.z, 0x0C010C00u); r[5] = __builtin_amdgcn_perm(0u, pre.a.z, 0x0C030C02u);
+    r[6] = __builtin_amdgcn_perm(0u, pre.a.w, 0x0C010C00u); r[7] = __builtin_amdgcn_perm(0u, pre.a.w, 0x0C030C02u);
+  }
+  int t[2];  // per block: 2 * (this lane's share of sum |coefficients| / 2) - (this lane's share of the block's sample sum)
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    unsigned* q = r + 4 * k;
+    const unsigned ss = hpk_add(hpk_add(q[0], q[1]), hpk_add(q[2], q[3]));   // sample sum of the half-row: DC's share
+    const int dc = (int)(ss & 0xFFFFu) + (int)(ss >> 16);
+    // horizontal distance 2 (registers 0|1, 2|3) and 4 (0|2, 1|3)
+    unsigned a = hpk_add(q[0], q[1]), b = hpk_sub(q[0], q[1]), c = hpk_add(q[2], q[3]), d = hpk_sub(q[2], q[3]);
+    q[0] = hpk_add(a, c); q[2] = hpk_sub(a, c); q[1] = hpk_add(b, d); q[3] = hpk_sub(b, d);
+    // vertical distance 1, 2 (lane ^ 4, lane ^ 8: inside a DPP row of 16 lanes), 4 (lane ^ 16: between DPP rows)
+    had_exchange<0x114, 0x104, 0xA, 0x5>(q[0], q[1]);
+    had_exchange<0x114, 0x104, 0xA, 0x5>(q[2], q[3]);
+    had_exchange<0x118, 0x108, 0xC, 0x3>(q[0], q[2]);
+    had_exchange<0x118, 0x108, 0xC, 0x3>(q[1], q[3]);
+#pragma unroll
+    for (int j = 0; j < 4; j += 2) {
+      const u32x2_t sw = __builtin_amdgcn_permlane16_swap(q[j], q[j + 1], false, false);
+      q[j] = hpk_add(sw.x, sw.y);
+      q[j + 1] = hpk_sub(sw.x, sw.y);
+    }
+    unsigned acc = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const s16x2 v = __builtin_bit_cast(s16x2, q[j]);
+      const unsigned m = __builtin_bit_cast(unsigned, __builtin_elementwise_max(v, (s16x2)(-v)));
+      acc += max(m & 0xFFFFu, m >> 16);
+    }
+    t[k] = (int)(2 * acc) - dc;
+  }
+  int hb = 0;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {  // the block's 8 lanes: two row rotations inside the DPP row, one exchange between rows
+    int v = t[k];
+    v += __builtin_amdgcn_update_dpp(0, v, 0x124, 0xF, 0xF, true);   // row_ror:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, true);   // row_ror:8
+    v += __shfl_xor(v, 16);
+    hb += (v + 2) >> 2;                                              // xCalcHADs8x8_ISlice: (sum + 2) >> 2 per block
+  }
+  // one lane per block pair ((lane & 0x1C) == 0): lanes 0-3 and 32-35; sum them
+  int w = ((lane & 0x1C) == 0) ? hb : 0;
+  w += __builtin_amdgcn_update_dpp(0, w, 0xB1, 0xF, 0xF, true);      // quad_perm [1,0,3,2]
+  w += __builtin_amdgcn_update_dpp(0, w, 0x4E, 0xF, 0xF, true);      // quad_perm [2,3,0,1]
+  return __builtin_amdgcn_readlane(w, 0) + __builtin_amdgcn_readlane(w, 32);
+}
+
 // two int16 samples of one dword -> two 8-bit samples (load_sample8 on both halves): max(v, 0) first, so that the
 // rounding shift may be a logical one ((0 + rnd) >> s = 0 like every negative sample), then min(255)
 __device__ __forceinline__ unsigned sample8_pair(unsigned w, int shift, unsigned rnd2)
@@ -455,9 +539,10 @@ __device__ __forceinline__ unsigned long long stamp()
 
 // STAMPS = true is a separate diagnostic instantiation (fhevc_debug_cnn_phase_cycles): wave 0 of every workgroup
 // adds the cycles of each phase (incl. the barrier that ends it) into d_stamps[blockIdx.x * 8 + phase].
-template <bool STAMPS>
+// HAD: also write the per-CTU source Hadamard (d_had), computed from the samples the kernel loads anyway (one pass over the frame)
+template <bool STAMPS, bool HAD>
 __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, FhevcCnnWeights W,
-                                                                  uint8_t* __restrict__ d_depth,
+                                                                  uint8_t* __restrict__ d_depth, int32_t* __restrict__ d_had,
                                                                   int32_t* __restrict__ d_logits,
                                                                   uint32_t* __restrict__ d_flags,
                                                                   unsigned long long* __restrict__ d_stamps,
@@ -528,10 +613,15 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
     pos.f = vb / per_frame; pos.ry = (vb - pos.f * per_frame) / F.ctus_x; pos.cx = (vb - pos.f * per_frame) - pos.ry * F.ctus_x;
     step.f = g / per_frame; step.ry = (g - step.f * per_frame) / F.ctus_x; step.cx = (g - step.f * per_frame) - step.ry * F.ctus_x;
   }
-  Prefetched pre = prefetch_ctu(F, vblock < total, pos, ld_row, ld_seg);
+  Prefetched pre = prefetch_ctu<HAD>(F, vblock < total, pos, ld_row, ld_seg);
+  int had_set = 0;  // which of the two sets of per-wave Hadamard sums belongs to the CTU in flight
   if (vblock < total) {  // prologue: first CTU of this workgroup
     stage_ctu(lds, pre, F, pos, tid, ld_row, ld_seg, shift_in, hc.in);
     zero_a1_halo(lds, tid, hc.a1);
+    if (HAD) {
+      const int hs = F.sample_bytes == 2 ? wave_src_hadamard<2>(pre, lane) : wave_src_hadamard<1>(pre, lane);
+      if (lane == 0) logitL[56 + wave] = hs;
+    }
   }
   __syncthreads();
   FHEVC_STAMP(0)
@@ -640,7 +730,7 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
     FHEVC_STAMP(2)
 
     // ================= P3: conv3 (32 -> 64), K = 9 taps x 32 ch, requant to u8 =================
-    pre = prefetch_ctu(F, work + (int)gridDim.x < total, next, ld_row, ld_seg);  // next CTU's samples travel under conv3 and the heads
+    pre = prefetch_ctu<HAD>(F, work + (int)gridDim.x < total, next, ld_row, ld_seg);  // next CTU's samples travel under conv3 and the heads
     {
       FHEVC_PHASE_IDS
       const int x = lane & 15, kg = lane >> 4;  // B column = position x of the row, K group = activation plane kg; D rows 4 kg ..
@@ -681,6 +771,11 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
       sched_row18();
       conv3_store(q0, q1, a3dst + FHEVC_ROW_OFF(7), tile3, psw);
 #undef FHEVC_ROW_OFF
+    }
+    if (HAD) {  // the next CTU's source Hadamard from its samples in flight: VALU work at the tail of the MFMA-bound phase
+      FHEVC_PHASE_IDS
+      const int hs = F.sample_bytes == 2 ? wave_src_hadamard<2>(pre, lane) : wave_src_hadamard<1>(pre, lane);
+      if (lane == 0) logitL[56 + 4 * (had_set ^ 1) + wave] = hs;
     }
     __syncthreads();
     FHEVC_STAMP(3)
@@ -780,6 +875,10 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
         d_depth_max[o * 256 + tid] = (uint8_t)d;
       }
       if (d_logits != nullptr && tid < 42) d_logits[o * 42 + tid] = tid == 0 ? l64.x : (tid == 1 ? l64.y : logitL[tid]);
+      if (HAD && tid == 64) {  // (a lane of wave 1: wave 0 also assembles the split-flag word)
+        const int4 hp = *reinterpret_cast<const int4*>(logitL + 56 + 4 * had_set);
+        d_had[o] = hp.x + hp.y + hp.z + hp.w;
+      }
       if (d_flags != nullptr && wave == 0) {  // the 21 decisions as one word: lane k < 21 evaluates node k
         const int k = lane;
         const int bi = k - 5, qq = k < 5 ? k - 1 : (bi >> 3) * 2 + ((bi >> 1) & 1);  // own / parent quadrant
@@ -802,6 +901,7 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
       zero_a1_halo(lds, tid, hc.a1);  // R1 held the conv3 output until the P4 barrier; conv1 of the next CTU needs a zero halo
     }
     FHEVC_STAMP(5)
+    had_set ^= 1;
     pos = next;
     // no barrier here: the next P1 reads R2 (staged before the P4 barrier) and writes the A1 interior (R1, last read
     // before the P4 barrier, halo rewritten above by disjoint addresses); the logits are re-initialised in P2.
@@ -854,18 +954,34 @@ hipError_t fhevc_launch_expand_flags(const FhevcFrames& fr, const uint32_t* d_fl
 // > 64 KiB of dynamic LDS needs an opt-in per function AND per device: fhevc_create calls this with its device current
 hipError_t fhevc_cnn_prepare_device()
 {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
 }
 
-hipError_t fhevc_launch_cnn(const FhevcFrames& fr, const FhevcCnnWeights& w, uint8_t* d_depth, int32_t* d_logits,
+// d_had != nullptr: the fused source Hadamard (only where fhevc_cnn_can_fuse_hadamard says so)
+bool fhevc_cnn_can_fuse_hadamard(const FhevcFrames& fr)
+{
+  // every thread's 16 samples must come through the aligned fast path or lie wholly outside the picture, and the packed
+  // 16-bit butterflies need samples below 2^10
+  const size_t sb = (size_t)fr.sample_bytes;
+  return fr.bit_depth <= 10 && (fr.width % 16) == 0 && (reinterpret_cast<uintptr_t>(fr.luma) % 16) == 0 &&
+         ((size_t)fr.stride * sb) % 16 == 0 && ((size_t)fr.frame_stride * sb) % 16 == 0;
+}
+
+hipError_t fhevc_launch_cnn(const FhevcFrames& fr, const FhevcCnnWeights& w, uint8_t* d_depth, int32_t* d_had, int32_t* d_logits,
                             uint32_t* d_flags, uint8_t* d_depth_max, int margin_split, int margin_stop, int num_cus, hipStream_t stream)
 {
   const long long total = (long long)(fr.row_end - fr.row_begin) * fr.ctus_x * fr.num_frames;
   if (total <= 0) return hipSuccess;
   int grid = 2 * num_cus;
   if (total < grid) grid = (int)total;
-  hipLaunchKernelGGL(fhevc_cnn_depth_kernel<false>, dim3(grid), dim3(256), LDS_BYTES, stream, fr, w, d_depth, d_logits,
-                     d_flags, (unsigned long long*)nullptr, d_depth_max, margin_split, margin_stop);
+  if (d_had != nullptr)
+    hipLaunchKernelGGL((fhevc_cnn_depth_kernel<false, true>), dim3(grid), dim3(256), LDS_BYTES, stream, fr, w, d_depth, d_had, d_logits,
+                       d_flags, (unsigned long long*)nullptr, d_depth_max, margin_split, margin_stop);
+  else
+    hipLaunchKernelGGL((fhevc_cnn_depth_kernel<false, false>), dim3(grid), dim3(256), LDS_BYTES, stream, fr, w, d_depth, (int32_t*)nullptr, d_logits,
+                       d_flags, (unsigned long long*)nullptr, d_depth_max, margin_split, margin_stop);
   return hipGetLastError();
 }
 
@@ -880,10 +996,10 @@ hipError_t fhevc_launch_cnn_stamped(const FhevcFrames& fr, const FhevcCnnWeights
   if (total < grid) grid = (int)total;
   *grid_out = grid;
   if (total <= 0) return hipSuccess;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_kernel<true>),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_kernel<true, false>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(fhevc_cnn_depth_kernel<true>, dim3(grid), dim3(256), LDS_BYTES, stream, fr, w, d_depth, (int32_t*)nullptr,
+  hipLaunchKernelGGL((fhevc_cnn_depth_kernel<true, false>), dim3(grid), dim3(256), LDS_BYTES, stream, fr, w, d_depth, (int32_t*)nullptr, (int32_t*)nullptr,
                      (uint32_t*)nullptr, d_stamps, (uint8_t*)nullptr, 0, 0);
   return hipGetLastError();
 }

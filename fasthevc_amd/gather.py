@@ -1,0 +1,144 @@
+"""The path's only exchange step: one all-gather of the depth decisions per step, shared by
+bench.py and the multi-rank tests.
+
+Two partitions of a step's work over the ranks of a node (one process per GPU):
+  * "frames": whole pictures dealt to ranks in contiguous runs (a GOP; weak or strong scaling);
+  * "bands":  contiguous CTU-row bands of every picture, rows [r * rows / R, (r + 1) * rows / R) as fhevc_band (config 3).
+On the wire the depth maps travel as the 21-bit split-flag word per CTU (4 B instead of 256 B, the reference's pre-order
+split-flag serialisation in fixed bit positions, TComSysuCuMDTools.cpp:16-38); every rank's slice is padded to the largest
+slice because all_gather_into_tensor needs equal sizes, and one index_select puts the gathered words into whole-picture CTU
+raster order, ready for fhevc_expand_depth_flags_device.
+
+Collective: torch.distributed "nccl" = RCCL over xGMI.  If RCCL cannot be initialised or a collective raises, the gather
+falls back to a HOST-side gather (D2H of the words, all-gather over a gloo group, H2D) and says so in `status` -- a status,
+never an abort ("acceptable fallback when RCCL init fails").
+"""
+import torch
+import torch.distributed as dist
+
+
+def span(total, rank, world):
+    """contiguous share [begin, end) of `total` items for `rank` of `world`: the arithmetic of fhevc_band"""
+    return (rank * total) // world, ((rank + 1) * total) // world
+
+
+class FlagGather:
+    def __init__(self, mode, world, rank, num_frames, ctus_x, ctus_y, device, group=None, host_group=None):
+        assert mode in ("frames", "bands")
+        self.mode, self.world, self.rank = mode, world, rank
+        self.num_frames, self.ctus_x, self.ctus_y = num_frames, ctus_x, ctus_y
+        self.device = torch.device(device)
+        self.group, self.host_group = group, host_group
+        self.status = "single rank" if world == 1 else "rccl" if self.device.type == "cuda" and group is not False else "host-gather"
+        if group is False:  # the caller could not bring RCCL up
+            self.group = None
+        n = ctus_x * ctus_y
+        if mode == "frames":
+            self.frames = span(num_frames, rank, world)                 # this rank's pictures
+            self.rows = (0, ctus_y)
+            self.slice_words = max(span(num_frames, r, world)[1] - span(num_frames, r, world)[0] for r in range(world)) * n
+        else:
+            self.frames = (0, num_frames)
+            self.rows = span(ctus_y, rank, world)                       # this rank's CTU rows of every picture
+            self.max_rows = max(span(ctus_y, r, world)[1] - span(ctus_y, r, world)[0] for r in range(world))
+            self.slice_words = num_frames * self.max_rows * ctus_x
+        self.local_ctus = (self.frames[1] - self.frames[0]) * (self.rows[1] - self.rows[0]) * ctus_x
+        # position of every (frame, CTU) of the step inside the gathered [world, slice_words] buffer
+        idx = torch.empty(num_frames * n, dtype=torch.int64)
+        for r in range(world):
+            if mode == "frames":
+                fb, fe = span(num_frames, r, world)
+                idx[fb * n:fe * n] = r * self.slice_words + torch.arange((fe - fb) * n)
+            else:
+                rb, re = span(ctus_y, r, world)
+                rows = torch.arange(rb, re)
+                for f in range(num_frames):
+                    dst = (f * ctus_y + rows)[:, None] * ctus_x + torch.arange(ctus_x)[None, :]
+                    src = r * self.slice_words + (f * self.max_rows + (rows - rb))[:, None] * ctus_x + torch.arange(ctus_x)[None, :]
+                    idx[dst.reshape(-1)] = src.reshape(-1)
+        self.index = idx.to(self.device)
+        # double-buffered so that the gather of step i can run under the kernels of step i + 1
+        self.send = [torch.zeros(self.slice_words, dtype=torch.int32, device=self.device) for _ in range(2)]
+        self.recv = [torch.zeros(world * self.slice_words, dtype=torch.int32, device=self.device) for _ in range(2)]
+        self.whole = torch.zeros(num_frames * n, dtype=torch.int32, device=self.device)
+        self._inflight = None
+
+    def local_words(self, b):
+        """where this rank's kernel writes its split-flag words of a step: compact over (its frames) x (its rows) x ctus_x.
+        In "bands" mode with fewer rows than max_rows the per-frame pitch on the wire is max_rows * ctus_x, see pack()."""
+        return self.send[b][: self.local_ctus]
+
+    def pack(self, b):
+        """bands mode: the kernel writes compact [frame][own rows][ctus_x]; the wire layout pads every frame to max_rows"""
+        if self.mode != "bands":
+            return
+        own = self.rows[1] - self.rows[0]
+        if own == self.max_rows:
+            return
+        compact = self.send[b][: self.local_ctus].clone().view(self.num_frames, own * self.ctus_x)
+        padded = self.send[b].view(self.num_frames, self.max_rows * self.ctus_x)
+        padded.zero_()
+        padded[:, : own * self.ctus_x] = compact
+
+    def start(self, b):
+        """issue the all-gather of buffer b (asynchronously where the backend allows); one collective in flight at most"""
+        assert self._inflight is None
+        if self.world == 1:
+            self._inflight = (None, b)
+            return
+        self.pack(b)
+        if self.status == "rccl" or (self.status == "host-gather" and self.device.type == "cpu"):
+            try:
+                src = self.send[b].clone() if self.device.type == "cpu" else self.send[b]
+                work = dist.all_gather_into_tensor(self.recv[b], src, group=self.group if self.device.type == "cuda" else self.host_group,
+                                                   async_op=True)
+                self._inflight = (work, b)
+                return
+            except Exception as e:  # RCCL refused the collective: fall back for the rest of the run
+                self.status = f"host-gather (collective failed: {type(e).__name__})"
+        self._host_gather(b)
+        self._inflight = (None, b)
+
+    def _host_gather(self, b):
+        send = self.send[b].cpu()
+        recv = torch.empty(self.world * self.slice_words, dtype=torch.int32)
+        dist.all_gather_into_tensor(recv, send, group=self.host_group)
+        self.recv[b].copy_(recv)
+
+    def finish(self):
+        """wait for the collective in flight; -> split-flag words of the whole step, [num_frames * numCtus] in CTU raster order"""
+        if self._inflight is None:
+            return None
+        work, b = self._inflight
+        self._inflight = None
+        if self.world == 1:
+            self.whole.copy_(self.send[b][: self.whole.numel()])
+            return self.whole
+        if work is not None:
+            try:
+                work.wait()
+            except Exception as e:
+                self.status = f"host-gather (collective failed: {type(e).__name__})"
+                self._host_gather(b)
+        torch.index_select(self.recv[b], 0, self.index, out=self.whole)
+        return self.whole
+
+
+def init_groups(world, rank, device, backend="nccl"):
+    """(group, host_group): the RCCL group (None = default group; False = RCCL could not be brought up) and a gloo group for
+    the host-side fallback.  world == 1: (None, None)."""
+    if world == 1:
+        return None, None
+    if backend != "nccl":
+        dist.init_process_group(backend, rank=rank, world_size=world)
+        return (False if torch.device(device).type == "cuda" else None), None
+    try:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+        group = None
+    except Exception:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        return False, None
+    host_group = dist.new_group(backend="gloo")  # every rank creates it, in the same order
+    return group, host_group

@@ -51,6 +51,19 @@ class YuvLumaReader:
             return np.ascontiguousarray(y)
         return np.ascontiguousarray(y.astype(np.int16) << shift)
 
+    def read_luma_into(self, out, first=0):
+        """Fill out[f] (uint8 [count, H, W], e.g. pinned memory from Context.alloc_host) with the luma planes of frames
+        first .. first + count - 1 of an 8-bit file whose size needs no padding: one copy file -> destination, chroma is
+        never touched.  This is what feeds fhevc_predict_frames."""
+        assert self.bps == 1 and out.dtype == np.uint8 and out.shape[1:] == (self.height, self.width)
+        assert self.padded_size() == (self.width, self.height), "pad through luma() instead"
+        if first < 0 or first + out.shape[0] > self.num_frames:
+            raise IndexError((first, out.shape[0]))
+        for f in range(out.shape[0]):
+            off = (first + f) * self.frame_bytes
+            out[f].reshape(-1)[:] = self._mm[off:off + self.luma_bytes]
+        return out
+
     def gop_uint8(self, first, count):
         """`count` luma planes of an 8-bit file as one [count, H, W] uint8 array (what a GOP upload hands the device)."""
         assert self.bps == 1
