@@ -859,7 +859,7 @@ void fhevc_p_rule_default(fhevc_p_rule* rule)
   const int32_t ts[3] = FHEVC_P_RULE_T_SPLIT, tp[3] = FHEVC_P_RULE_T_STOP;
   std::memcpy(rule->t_split, ts, sizeof ts);
   std::memcpy(rule->t_stop, tp, sizeof tp);
-  rule->window = 4;  // off
+  rule->window = FHEVC_P_RULE_WINDOW;
 }
 
 int fhevc_p_depth_range(const fhevc_motion_node* nodes, const uint8_t* prev_depth, int valid_w, int valid_h, int qp, const fhevc_p_rule* rule,

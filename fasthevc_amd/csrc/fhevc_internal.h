@@ -71,8 +71,12 @@ hipError_t fhevc_launch_motion(const FhevcFrames& fr, int range, const FhevcMvCo
 #define FHEVC_P_RULE_WEIGHTS { { 3101, 188, -94, 80, 1149, 1149, 3174, -138, 15748, -351620 }, \
                                { 594, 101, 375, -8, 1078, 1078, -197, 436, 3462, 256745 },      \
                                { 317, -3, 366, -216, 745, 745, 0, 1344, 2780, -18423 } }
-#define FHEVC_P_RULE_T_SPLIT { 524288, 524288, 1048576 }
-#define FHEVC_P_RULE_T_STOP  { 524288, 524288, 262144 }
+// thresholds (Q18) picked on the 1080p pan clip (tests/quality/eval_p.py, profiles/r02_p_slice_motion_rule.json): no split is
+// ever FORCED (a wrongly forced split costs several percent of rate on P pictures), splits are FORBIDDEN below scores of
+// -3 / -1 / -0.5, and the range stays within +-1 of the co-located depth
+#define FHEVC_P_RULE_T_SPLIT { 25952256, 25952256, 25952256 }
+#define FHEVC_P_RULE_T_STOP  { 786432, 262144, 131072 }
+#define FHEVC_P_RULE_WINDOW  1
 
 // ---- adaptive-QP pre-analysis (k_preanalyze.hip) -----------------------------------------------------------
 // d_activity: per frame parts_per_frame doubles, layers concatenated (layer d: ceil(H/P) x ceil(W/P), P = 64 >> d)

@@ -53,7 +53,7 @@ void TEncFastDepth::readKnobs()
     if (std::sscanf(pt, "%lf,%lf,%lf,%lf,%lf,%lf", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5]) == 6)
       for (int l = 0; l < 3; l++) { P_RULE->t_split[l] = (int)(v[l] * 262144.0); P_RULE->t_stop[l] = (int)(v[3 + l] * 262144.0); }
   }
-  if (pm != NULL && std::strcmp(pm, "motion") == 0 && pw != NULL) P_RULE->window = m_pWindow;
+  if (pm != NULL && std::strcmp(pm, "motion") == 0 && pw != NULL) P_RULE->window = m_pWindow;   // overrides the rule's own +-1 clip (4 = off)
 #endif
 }
 

@@ -236,6 +236,8 @@ def rdo_encode(lib, plane, origin, stride, width, height, bit_depth, qp, forced_
         raise RuntimeError(f"href_rdo_encode_frame failed: {rc}")
     mse = stats[4] / (width * height)
     peak = (1 << bit_depth) - 1
-    return depth.reshape(n, 256), {"bits": stats[0], "dist": stats[1], "rdcost": stats[2], "seconds": stats[3],
-                                   "psnr_y": 10 * np.log10(peak * peak / mse) if mse > 0 else 99.0, "ctus": int(stats[5]),
-                                   "coded_bits": stats[6]}
+    out = {"bits": stats[0], "dist": stats[1], "rdcost": stats[2], "seconds": stats[3],
+           "psnr_y": 10 * np.log10(peak * peak / mse) if mse > 0 else 99.0, "ctus": int(stats[5]), "coded_bits": stats[6]}
+    if stats[7] > 0:  # FHREF_DEBLOCK=1: luma PSNR after the reference's own deblocking filter
+        out["psnr_y_deblocked"] = 10 * np.log10(peak * peak / (stats[7] / (width * height)))
+    return depth.reshape(n, 256), out

@@ -41,6 +41,7 @@
 #include "TLibCommon/TComTU.h"
 #include "TLibCommon/TComPattern.h"
 #include "TLibCommon/TComPrediction.h"
+#include "TLibCommon/TComLoopFilter.h"
 #include "TLibCommon/TComRdCost.h"
 #include "TLibEncoder/TEncCfg.h"
 #include "TLibEncoder/TEncCu.h"
@@ -297,7 +298,8 @@ extern "C" {
 // forced_depth (only in hook builds): numCtus*256 raster depth map fed to the xCompressCU hook, or NULL.
 // depth_out: numCtus*256, raster per CTU = getDepth(g_auiRasterToZscan[r]).  stats: [0] bits (RD-SBAC estimate summed
 // over CTUs), [1] distortion (SSE, chroma weighted as in TComRdCost), [2] RD cost, [3] seconds in compressSlice,
-// [4] luma SSE of the reconstruction vs the original, [5] number of CTUs.
+// [4] luma SSE of the reconstruction vs the original, [5] number of CTUs, [6] bits counted by encodeCtu, [7] luma SSE after the
+// reference's own deblocking filter when FHREF_DEBLOCK=1 (else -1).
 int href_rdo_encode_frame_yuv(const int16_t* luma, int stride, const int16_t* cb, const int16_t* cr, int width, int height,
                               int bit_depth, int qp, const uint8_t* forced_depth, uint8_t* depth_out, double* stats);
 
@@ -358,6 +360,21 @@ int href_rdo_encode_frame_yuv(const int16_t* luma, int stride, const int16_t* cb
       for (int x = 0; x < width; x++) { const double d = (double)o[y * so + x] - (double)r[y * sr + x]; sse += d * d; }
     stats[4] = sse;
     stats[5] = n;
+    stats[7] = -1.0;
+    if (env_int("FHREF_DEBLOCK", 0)) {
+      // the reference's own in-loop deblocking filter on the reconstruction (TComLoopFilter::loopFilterPic, called by TEncGOP.cpp:1607-1619
+      // with the slice's default parameters: filter enabled, beta / tc offsets 0), then the luma SSE again: distortion as a decoder
+      // sees it before SAO.  Modifies PicYuvRec in place (only used for I pictures that no P picture follows).
+      TComLoopFilter lf;
+      lf.create(4);
+      lf.setCfg(true);
+      lf.loopFilterPic(e->pic);
+      lf.destroy();
+      double sse2 = 0;
+      for (int y = 0; y < height; y++)
+        for (int x = 0; x < width; x++) { const double d = (double)o[y * so + x] - (double)r[y * sr + x]; sse2 += d * d; }
+      stats[7] = sse2;
+    }
   }
   e->last = e->pic;  // reference of a following P picture (href_rdo_encode_next_p, P-variant builds)
   return 0;

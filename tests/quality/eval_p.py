@@ -114,53 +114,67 @@ def encode_seq(lib, ys, qp, window=None, cnn=None, motion=None):
     return out
 
 
+def _run_qp(job):
+    """one slice QP: the anchor (unrestricted search) and every variant; runs in its own process (HM is single-threaded)"""
+    qp, variants, (W, H), nframes = job
+    from oracle import oracle_py as op
+    from fasthevc_amd import capi
+    lib, oracle = load_p(), op.load_oracle()
+    ys = pan_clip(W, H, nframes)
+    tail = lambda seq: (sum(s["bits"] for _, s in seq[2:]), float(np.mean([s["psnr_y"] for _, s in seq[2:]])), sum(s["seconds"] for _, s in seq[2:]))
+    anchor = encode_seq(lib, ys, qp)
+    out = {"anchor": tail(anchor), "pictures": [dict(s, depth_hist=np.bincount(d.reshape(-1), minlength=4).tolist()) for d, s in anchor]}
+    for name, v in variants.items():
+        if v["kind"] == "window":
+            seq = encode_seq(lib, ys, qp, window=tuple(v["window"]))
+        else:  # the shipped rule (fhevc_p_rule_default) with optional overrides of its thresholds / window
+            rule = op.PRule.from_buffer_copy(bytes(capi.p_rule_default()))
+            for l in range(3):
+                if "t_split" in v:
+                    rule.t_split[l] = int(v["t_split"][l] * (1 << 18))
+                if "t_stop" in v:
+                    rule.t_stop[l] = int(v["t_stop"][l] * (1 << 18))
+            rule.window = v.get("window", rule.window)
+            seq = encode_seq(lib, ys, qp, motion=(oracle, rule))
+        out[name] = tail(seq)
+        out[name + ":agreement"] = [float((seq[f][0] == anchor[f][0]).mean()) for f in range(2, nframes)]
+    return qp, out
+
+
+DEFAULT_VARIANTS = {
+    "same_depth": {"kind": "window", "window": [0, 0]},
+    "window_pm1": {"kind": "window", "window": [1, 1]},
+    "motion_rule": {"kind": "rule"},   # what TEncFastDepth runs with FHEVC_P_MODE=motion: fhevc_p_rule_default()
+}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--size", default="1920x1080")
     ap.add_argument("--frames", type=int, default=4)
     ap.add_argument("--json", default=None)
-    ap.add_argument("--weights-p", default=None, help="FHW1 blob trained on P-picture labels (make_labels_p.py): adds classifier variants")
+    ap.add_argument("--variants", default=None, help="JSON: {name: {kind: window|rule, window: ..., t_split: [3], t_stop: [3]}}")
+    ap.add_argument("--workers", type=int, default=4)
     args = ap.parse_args()
+    from multiprocessing import Pool
     W, H = (int(v) for v in args.size.split("x"))
-    lib = load_p()
-    ys = pan_clip(W, H, args.frames)
-    windows = {"same_depth": (0, 0), "window_pm1": (1, 1), "at_most_plus1": (3, 1), "at_least_minus1": (1, 3)}
-    cnn_variants = {}
-    if args.weights_p:
-        from oracle import oracle_py as op
-        from fasthevc_amd import weights
-        oracle, ws = op.load_oracle(), op.weights_from_arrays(weights.load(args.weights_p))
-        cnn_variants = {"cnn_p_hard": (oracle, ws, 0, 0), "cnn_p_split32000": (oracle, ws, 32000, 0), "cnn_p_soft8000": (oracle, ws, 8000, 8000)}
-        windows = {"window_pm1": (1, 1)}
-    rows = {"anchor": []}
-    rows.update({k: [] for k in windows})
-    rows.update({k: [] for k in cnn_variants})
-    report = {"clip": f"{W}x{H} pan clip, {args.frames} frames (I P P ...), restricted pictures: POC >= 2", "qp": [], "pictures": []}
-    for qp in (22, 27, 32, 37):
-        anchor = encode_seq(lib, ys, qp)
-        tail = lambda seq: (sum(s["bits"] for _, s in seq[2:]), float(np.mean([s["psnr_y"] for _, s in seq[2:]])), sum(s["seconds"] for _, s in seq[2:]))
-        rows["anchor"].append(tail(anchor))
-        report["qp"].append(qp)
-        report["pictures"].append([dict(s, depth_hist=np.bincount(d.reshape(-1), minlength=4).tolist()) for d, s in anchor])
-        same = [float((anchor[f][0] == anchor[f - 1][0]).mean()) for f in range(2, len(ys))]
-        pm1 = [float((np.abs(anchor[f][0].astype(int) - anchor[f - 1][0].astype(int)) <= 1).mean()) for f in range(2, len(ys))]
-        print(f"qp {qp}: " + " | ".join(f"POC{f} {s['bits']:.0f} b {s['psnr_y']:.2f} dB {s['seconds']:.1f} s skip {100 * s['skip_share']:.0f} %" for f, (_, s) in enumerate(anchor))
-              + f" | P->P depth equal {100 * np.mean(same):.0f} %, within 1 {100 * np.mean(pm1):.0f} %", flush=True)
-        for k, win in windows.items():
-            t = tail(encode_seq(lib, ys, qp, win))
-            rows[k].append(t)
-            print(f"   {k}: POC2.. {t[0]:.0f} b {t[1]:.2f} dB {t[2]:.1f} s", flush=True)
-        for k, cv in cnn_variants.items():
-            t = tail(encode_seq(lib, ys, qp, cnn=cv))
-            rows[k].append(t)
-            print(f"   {k}: POC2.. {t[0]:.0f} b {t[1]:.2f} dB {t[2]:.1f} s", flush=True)
-    ra, pa = [r[0] for r in rows["anchor"]], [r[1] for r in rows["anchor"]]
-    report["anchor"] = rows["anchor"]
-    for k in list(windows) + list(cnn_variants):
-        v = rows[k]
-        report[k] = {"points": v, "bd_rate_percent": bd_rate(ra, pa, [r[0] for r in v], [r[1] for r in v]),
-                     "time_ratio": float(np.sum([r[2] for r in rows["anchor"]]) / np.sum([r[2] for r in v]))}
-        print(f"{k}: BD-rate of the restricted P pictures {report[k]['bd_rate_percent']:+.2f} %  decision time {report[k]['time_ratio']:.2f}x faster")
+    variants = json.loads(args.variants) if args.variants else DEFAULT_VARIANTS
+    qps = (22, 27, 32, 37)
+    with Pool(args.workers) as pool:
+        res = dict(pool.map(_run_qp, [(qp, variants, (W, H), args.frames) for qp in qps]))
+    ra, pa = [res[q]["anchor"][0] for q in qps], [res[q]["anchor"][1] for q in qps]
+    ta = sum(res[q]["anchor"][2] for q in qps)
+    report = {"clip": f"{W}x{H} pan clip (frames.pan_clip), {args.frames} frames I P P ..., P pictures at QP + 6; restricted pictures: POC >= 2 "
+                      "(their reference picture is a P picture); decision stage: bits counted by encodeCtu, luma PSNR before the in-loop filters",
+              "qp": list(qps), "anchor": [res[q]["anchor"] for q in qps], "pictures": [res[q]["pictures"] for q in qps], "variants": {}, "summary": {}}
+    for name, v in variants.items():
+        pts = [res[q][name] for q in qps]
+        bd = bd_rate(ra, pa, [p[0] for p in pts], [p[1] for p in pts])
+        tr = ta / sum(p[2] for p in pts)
+        report["variants"][name] = {"definition": v, "points": pts, "bd_rate_percent": bd, "time_ratio": tr,
+                                    "depth_agreement_with_full_rdo": [float(np.mean(res[q][name + ":agreement"])) for q in qps]}
+        report["summary"][name] = f"BD-rate {bd:+.2f} % at {tr:.2f}x less time in compressSlice"
+        print(f"{name:24s} BD-rate of the restricted P pictures {bd:+6.2f} %   decision time {tr:5.2f}x faster", flush=True)
     if args.json:
         with open(args.json, "w") as f:
             json.dump(report, f, indent=1)
