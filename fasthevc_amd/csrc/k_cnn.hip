@@ -217,7 +217,14 @@ __device__ __forceinline__ void conv3_store(const f32x4& acc0, const f32x4& acc1
 // Each v_mfma needs one ds_read_b128 (its im2col fragment).  hipcc places the read right in front of its MFMA and
 // waits for it, exposing the LDS latency 18 times per chain; instead the reads run RING steps ahead of their MFMA
 // and sched_group_barrier pins the (MFMA, DS read, a few VALU of the previous unit's epilogue) interleave.
-constexpr int RING = 4;
+#ifndef FHEVC_RING2
+#define FHEVC_RING2 4
+#endif
+#ifndef FHEVC_RING3
+#define FHEVC_RING3 4
+#endif
+constexpr int RING = FHEVC_RING2;    // conv2's ring (the register-tightest phase)
+constexpr int RING3 = FHEVC_RING3;   // conv3's ring
 static_assert(12 % RING == 0, "conv2 hands its ring slots from unit to unit unchanged");
 template <int VALU_PER_MFMA>
 __device__ __forceinline__ void sched_chain18()
@@ -267,22 +274,22 @@ __device__ __forceinline__ constexpr int conv3_frag_off(int g)
   return ((4 * (k >> 1) + (k & 1) + t / 3) * A2_PITCH + t % 3) * 16;
 }
 template <int K>
-__device__ __forceinline__ void conv3_row(const unsigned char* base, const bf16x8 (&wA3)[18], bf16x8 (&ring)[RING],
+__device__ __forceinline__ void conv3_row(const unsigned char* base, const bf16x8 (&wA3)[18], bf16x8 (&ring)[RING3],
                                           const f32x4& b0, const f32x4& b1, f32x4& acc0, f32x4& acc1)
 {
   acc0 = b0;  // C operand of the first MFMA of each accumulator: the bias costs nothing
   acc1 = b1;
   if (K == 0) {
 #pragma unroll
-    for (int g = 0; g < RING; ++g) ring[g] = lds_frag(base + conv3_frag_off(g));
+    for (int g = 0; g < RING3; ++g) ring[g] = lds_frag(base + conv3_frag_off(g));
   }
 #pragma unroll
   for (int t = 0; t < 9; ++t) {
     const int g = 9 * K + t;
-    const bf16x8 b = ring[g % RING];
+    const bf16x8 b = ring[g % RING3];
     acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wA3[t]), __builtin_bit_cast(f16x8, b), acc0, 0, 0, 0);
     acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wA3[9 + t]), __builtin_bit_cast(f16x8, b), acc1, 0, 0, 0);
-    if (g + RING < 72) ring[g % RING] = lds_frag(base + conv3_frag_off(g + RING));
+    if (g + RING3 < 72) ring[g % RING3] = lds_frag(base + conv3_frag_off(g + RING3));
   }
 }
 __device__ __forceinline__ void sched_row18()
@@ -742,11 +749,11 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
       unsigned char* a3dst = lds + A3_OFF + (y0 * 16 + x) * 64 + 4 * kg;
       const f32x4 b30 = *reinterpret_cast<const f32x4*>(biasL + 48 + 32 * tile3 + 4 * kg);       // M tile 0: channels 32 t + 4 kg + i
       const f32x4 b31 = *reinterpret_cast<const f32x4*>(biasL + 48 + 32 * tile3 + 16 + 4 * kg);  // M tile 1
-      bf16x8 ring[RING];
+      bf16x8 ring[RING3];
       f32x4 p0, p1, q0, q1;
 #define FHEVC_ROW_OFF(k) ((4 * ((k) >> 1) + ((k) & 1)) * 1024)
       conv3_row<0>(a2, wA3, ring, b30, b31, p0, p1);
-      __builtin_amdgcn_sched_group_barrier(0x100, RING + 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, RING3 + 2, 0);
       sched_row18();
       conv3_row<1>(a2, wA3, ring, b30, b31, q0, q1);
       conv3_store(p0, p1, a3dst + FHEVC_ROW_OFF(0), tile3, psw);

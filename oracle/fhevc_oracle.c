@@ -747,10 +747,10 @@ static inline int is_split(const int32_t l[2]) { return l[1] > l[0]; }
 /* split when the logit difference exceeds thr (thr = 0: the plain decision) */
 static inline int is_split_thr(const int32_t l[2], int thr) { return l[1] - l[0] > thr; }
 
-static void depth_from_logits_thr(const int32_t logits[21][2], int vw, int vh, int thr, uint8_t depth[256])
+static void depth_from_logits_thr3(const int32_t logits[21][2], int vw, int vh, const int thr3[3], uint8_t depth[256])
 {
   memset(depth, 0, 256);
-  const int s64 = (vw < 64 || vh < 64) ? 1 : is_split_thr(logits[0], thr);
+  const int s64 = (vw < 64 || vh < 64) ? 1 : is_split_thr(logits[0], thr3[0]);
   for (int q = 0; q < 4; q++) {
     const int qx = (q & 1) * 32, qy = (q >> 1) * 32;
     if (qx >= vw || qy >= vh) continue; /* quadrant entirely outside the picture */
@@ -758,7 +758,7 @@ static void depth_from_logits_thr(const int32_t logits[21][2], int vw, int vh, i
     if (!s64) d32 = 0;
     else {
       const int cross = (qx + 32 > vw) || (qy + 32 > vh);
-      d32 = (cross || is_split_thr(logits[1 + q], thr)) ? 2 : 1;
+      d32 = (cross || is_split_thr(logits[1 + q], thr3[1])) ? 2 : 1;
     }
     for (int b = 0; b < 4; b++) {
       const int bx = qx + (b & 1) * 16, by = qy + (b >> 1) * 16;
@@ -767,7 +767,7 @@ static void depth_from_logits_thr(const int32_t logits[21][2], int vw, int vh, i
       if (d32 == 2) {
         const int cross = (bx + 16 > vw) || (by + 16 > vh);
         const int bi = (by / 16) * 4 + bx / 16;
-        d = (cross || is_split_thr(logits[5 + bi], thr)) ? 3 : 2;
+        d = (cross || is_split_thr(logits[5 + bi], thr3[2])) ? 3 : 2;
       }
       for (int uy = 0; uy < 4; uy++)
         for (int ux = 0; ux < 4; ux++) {
@@ -776,6 +776,12 @@ static void depth_from_logits_thr(const int32_t logits[21][2], int vw, int vh, i
         }
     }
   }
+}
+
+static void depth_from_logits_thr(const int32_t logits[21][2], int vw, int vh, int thr, uint8_t depth[256])
+{
+  const int t3[3] = { thr, thr, thr };
+  depth_from_logits_thr3(logits, vw, vh, t3, depth);
 }
 
 void fho_depth_from_logits(const int32_t logits[21][2], int vw, int vh, uint8_t depth[256])
@@ -791,6 +797,16 @@ void fho_depth_range_from_logits(const int32_t logits[21][2], int vw, int vh, in
 {
   depth_from_logits_thr(logits, vw, vh, margin_split, depth_min);
   depth_from_logits_thr(logits, vw, vh, -margin_stop, depth_max);
+}
+
+/* the same with one margin pair per level (64-, 32-, 16-level split): fhevc_set_level_margins */
+void fho_depth_range_from_logits_levels(const int32_t logits[21][2], int vw, int vh, const int32_t margin_split[3],
+                                        const int32_t margin_stop[3], uint8_t depth_min[256], uint8_t depth_max[256])
+{
+  const int lo[3] = { margin_split[0], margin_split[1], margin_split[2] };
+  const int hi[3] = { -margin_stop[0], -margin_stop[1], -margin_stop[2] };
+  depth_from_logits_thr3(logits, vw, vh, lo, depth_min);
+  depth_from_logits_thr3(logits, vw, vh, hi, depth_max);
 }
 
 uint32_t fho_flags_from_logits(const int32_t logits[21][2], int vw, int vh)

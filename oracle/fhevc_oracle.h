@@ -159,6 +159,9 @@ void fho_depth_from_logits(const int32_t logits[21][2], int valid_w, int valid_h
  * -margin_stop -> depth_max */
 void fho_depth_range_from_logits(const int32_t logits[21][2], int valid_w, int valid_h, int margin_split, int margin_stop,
                                  uint8_t depth_min[256], uint8_t depth_max[256]);
+/* one margin pair per split level (64, 32, 16): the calibration of DESIGN.md section 4 */
+void fho_depth_range_from_logits_levels(const int32_t logits[21][2], int valid_w, int valid_h, const int32_t margin_split[3],
+                                        const int32_t margin_stop[3], uint8_t depth_min[256], uint8_t depth_max[256]);
 /* The same decisions as one 21-bit word per CTU: bit 0 = 64x64 split, bits 1..4 = 32x32 quadrants (raster),
  * bits 5..20 = 16x16 blocks (raster); a bit is set only under split parents and inside the picture (forced
  * splits at the picture edge included).  This is the reference's pre-order split-flag serialisation

@@ -102,6 +102,7 @@ def load_oracle():
     lib.fho_cnn_ctu_debug.argtypes = [C.POINTER(Weights), _i8p, C.c_int, _u8p, _u8p, _u8p, _i32p]
     lib.fho_depth_from_logits.argtypes = [_i32p, C.c_int, C.c_int, _u8p]
     lib.fho_depth_range_from_logits.argtypes = [_i32p, C.c_int, C.c_int, C.c_int, C.c_int, _u8p, _u8p]
+    lib.fho_depth_range_from_logits_levels.argtypes = [_i32p, C.c_int, C.c_int, _i32p, _i32p, _u8p, _u8p]
     lib.fho_flags_from_logits.argtypes = [_i32p, C.c_int, C.c_int]
     lib.fho_flags_from_logits.restype = C.c_uint32
     lib.fho_depth_from_flags.argtypes = [C.c_uint32, C.c_int, C.c_int, _u8p]

@@ -9,7 +9,8 @@ Per family: BD-rate over the four QPs with bits and PSNR summed / averaged over 
 ratio in compressSlice, and the share of 4x4 units left to HM's own search.  Decision-stage figures (bits counted by encodeCtu,
 luma PSNR before the in-loop filters) plus the same BD-rate on the PSNR after the reference's own deblocking filter.
 
-usage: python tests/quality/eval_families.py --pictures 5 --size 1024x576 --margins 0:0,32000:0,64000:16000 --json profiles/r02_bdrate_generalization.json
+Margins: "split:stop", each side one number for all levels or "m64/m32/m16" per split level, "inf" = never.
+usage: python tests/quality/eval_families.py --pictures 5 --size 1024x576 --margins 0:0,32000:0,inf:16000/8000/8000 --json profiles/r02_bdrate_generalization.json
 """
 import argparse
 import ctypes as C
@@ -55,13 +56,13 @@ def work(job):
         pred = np.zeros(n * 256, np.uint8)
         logits = np.zeros(n * 42, np.int32)
         oracle.fho_predict_frame(ws, op.ptr(buf.reshape(-1), org), stride, W, H, 8, qp, pred, C.c_void_p(logits.ctypes.data))
-        for (ms, mt) in margins:
+        for (name, ms, mt) in margins:
             dmin, dmax = np.zeros((n, 256), np.uint8), np.zeros((n, 256), np.uint8)
             for c in range(n):
                 vw, vh = min(64, W - (c % cw) * 64), min(64, H - (c // cw) * 64)
-                oracle.fho_depth_range_from_logits(np.ascontiguousarray(logits[c * 42:(c + 1) * 42]), vw, vh, ms, mt, dmin[c], dmax[c])
+                oracle.fho_depth_range_from_logits_levels(np.ascontiguousarray(logits[c * 42:(c + 1) * 42]), vw, vh, ms, mt, dmin[c], dmax[c])
             _, sv = op.rdo_encode(hook, buf, org, stride, W, H, 8, qp, forced_depth=dmin, forced_depth_max=dmax, chroma=(u, u))
-            out[(f"{ms}:{mt}", qp)] = (sv["coded_bits"], sv["psnr_y"], sv["seconds"], float((dmin != dmax).mean()), sv.get("psnr_y_deblocked", sv["psnr_y"]))
+            out[(name, qp)] = (sv["coded_bits"], sv["psnr_y"], sv["seconds"], float((dmin != dmax).mean()), sv.get("psnr_y_deblocked", sv["psnr_y"]))
         for c in range(4):  # trivial floors
             _, sc = op.rdo_encode(hook, buf, org, stride, W, H, 8, qp, forced_depth=np.full((n, 256), c, np.uint8), chroma=(u, u))
             out[(f"const{c}", qp)] = (sc["coded_bits"], sc["psnr_y"], sc["seconds"], 0.0, sc.get("psnr_y_deblocked", sc["psnr_y"]))
@@ -80,7 +81,10 @@ def main():
     args = ap.parse_args()
     from eval_rd import bd_rate
     W, H = (int(v) for v in args.size.split("x"))
-    margins = [tuple(int(x) for x in m.split(":")) for m in args.margins.split(",")]
+    def side(t):  # "m" (all levels) or "m64/m32/m16"; "inf" = never (2^30)
+        v = [(1 << 30) if x == "inf" else int(x) for x in t.split("/")]
+        return np.array(v * 3 if len(v) == 1 else v, np.int32)
+    margins = [(m, side(m.split(":")[0]), side(m.split(":")[1])) for m in args.margins.split(",")]
     fams = args.families.split(",")
     jobs = [(f, k, (W, H), margins, args.weights) for f in fams for k in range(args.pictures)]
     res = {}
@@ -88,7 +92,7 @@ def main():
         for i, (family, k, out) in enumerate(pool.imap_unordered(work, jobs)):
             res[(family, k)] = out
             print(f"{i + 1}/{len(jobs)} {family} #{k}", flush=True)
-    variants = [f"{a}:{b}" for a, b in margins] + [f"const{c}" for c in range(4)]
+    variants = [m[0] for m in margins] + [f"const{c}" for c in range(4)]
     report = {"what": f"{args.pictures} unseen {W}x{H} pictures per family, QP {list(QPS)}, shipped blob {os.path.basename(args.weights)}; per family ONE RD curve "
                       "(bits summed, PSNR averaged over its pictures); decision-stage BD-rate vs the reference's full RDO", "families": {}, "summary": {}}
     for f in fams:

@@ -18,6 +18,10 @@ dev = torch.device("cuda:0")
 torch.cuda.init()
 ctx = capi.Context(W, H, 8, weights.random_weights(0), max_frames=NF)
 ctx.enable_kernel_timing(True)
+os.environ["FHEVC_FUSE_HADAMARD"] = "0"   # a second context that keeps the stand-alone source-Hadamard launch (the fused form is the default)
+ctx_unfused = capi.Context(W, H, 8, weights.random_weights(0), max_frames=NF)
+ctx_unfused.enable_kernel_timing(True)
+del os.environ["FHEVC_FUSE_HADAMARD"]
 base = frames.hetero_luma(W, H)
 planes = np.stack([frames.to_pel_plane(np.roll(base, 3 * f, axis=1), 8)[0] for f in range(NF)])
 _, org, stride = frames.to_pel_plane(base, 8)
@@ -42,22 +46,26 @@ for layout, ptr, sb, st, fstride in (("int16 HM planes", d16.data_ptr() + 2 * or
     out[f"preanalyze[{layout}]"] = {"ms": ms, "launches": n, "algorithmic_bytes": alg, "GB/s": alg / ms / 1e6,
                                     "frac_of_8TB/s": alg / ms / 1e6 / 8000}
 
-# --- source Hadamard alone (no CNN): d_depth is required by the entry point, so time through kernel_timing(1)
+# --- source Hadamard as its own launch (context without the fusion) and the depth kernel with / without the fused Hadamard
 depth = torch.zeros((NF, ctx.num_ctus, 256), dtype=torch.uint8, device=dev)
 had = torch.zeros((NF, ctx.num_ctus), dtype=torch.int32, device=dev)
 for layout, ptr, sb, st, fstride in (("int16 HM planes", d16.data_ptr() + 2 * org, 2, stride, fs), ("uint8 packed", d8.data_ptr(), 1, W, W * H)):
-    for _ in range(2):
-        ctx.predict_frames_device(ptr, sb, st, fstride, NF, depth.data_ptr(), had.data_ptr())
-    torch.cuda.synchronize()
-    ctx.kernel_timing(0, reset=True); ctx.kernel_timing(1, reset=True)
-    for _ in range(REPS):
-        ctx.predict_frames_device(ptr, sb, st, fstride, NF, depth.data_ptr(), had.data_ptr())
-    torch.cuda.synchronize()
-    ms_c, _ = ctx.kernel_timing(0, reset=True)
-    ms_h, n = ctx.kernel_timing(1, reset=True)
-    alg = NF * (W * H * sb + ctx.num_ctus * 4)
-    out[f"src_hadamard[{layout}]"] = {"ms": ms_h, "launches": n, "algorithmic_bytes": alg, "GB/s": alg / ms_h / 1e6}
-    out[f"depth_cnn[{layout}]"] = {"ms": ms_c, "Mctu/s": NF * ctx.num_ctus / ms_c / 1e3}
+    for cx in (ctx_unfused, ctx):
+        for _ in range(2):
+            cx.predict_frames_device(ptr, sb, st, fstride, NF, depth.data_ptr(), had.data_ptr())
+        torch.cuda.synchronize()
+        cx.kernel_timing(0, reset=True); cx.kernel_timing(1, reset=True)
+        for _ in range(REPS):
+            cx.predict_frames_device(ptr, sb, st, fstride, NF, depth.data_ptr(), had.data_ptr())
+        torch.cuda.synchronize()
+        ms_c, _ = cx.kernel_timing(0, reset=True)
+        ms_h, n = cx.kernel_timing(1, reset=True)
+        alg = NF * (W * H * sb + ctx.num_ctus * 4)
+        if cx is ctx_unfused:
+            out[f"src_hadamard[{layout}]"] = {"ms": ms_h, "launches": n, "algorithmic_bytes": alg, "GB/s": alg / ms_h / 1e6}
+            out[f"depth_cnn[{layout}]"] = {"ms": ms_c, "Mctu/s": NF * ctx.num_ctus / ms_c / 1e3}
+        else:
+            out[f"depth_cnn+fused_hadamard[{layout}]"] = {"ms": ms_c, "Mctu/s": NF * ctx.num_ctus / ms_c / 1e3, "stand_alone_hadamard_launches": n}
 
 # --- 35-mode first pass, one picture per call (host-buffer entry point; the kernel time excludes the copies)
 for _ in range(2):
@@ -83,5 +91,20 @@ torch.cuda.synchronize()
 ms, n = ctx.kernel_timing(2, reset=True)
 out[f"first_pass[{NB} pictures, device batch]"] = {"ms": ms, "launches": n, "ctu/s": NB * ctx.num_ctus / ms * 1e3,
                                                   "Tint-op/s": NB * ops / ms / 1e9}
+# --- config 4: source-only motion search per CU node, 16 pictures (15 pairs), search range 4 and 8
+mot = torch.zeros((15 * ctx.num_ctus * 85, 4), dtype=torch.int32, device=dev)
+for rng_ in (4, 8):
+    for _ in range(2):
+        ctx.motion_search_device(d16.data_ptr() + 2 * org, 2, stride, fs, 16, mot.data_ptr(), qp=38, search_range=rng_)
+    torch.cuda.synchronize()
+    ctx.kernel_timing(4, reset=True)
+    for _ in range(5):
+        ctx.motion_search_device(d16.data_ptr() + 2 * org, 2, stride, fs, 16, mot.data_ptr(), qp=38, search_range=rng_)
+    torch.cuda.synchronize()
+    ms, n = ctx.kernel_timing(4, reset=True)
+    mops = 15 * ctx.num_ctus * (2 * rng_ + 1) ** 2 * 64 * (64 + 575)  # per (vector, 8x8 tile): 64 differences + ~575 Hadamard ops
+    out[f"motion_search[15 pairs, range {rng_}]"] = {"ms": ms, "launches": n, "ctu/s": 15 * ctx.num_ctus / ms * 1e3, "approx_int_ops": mops,
+                                                     "Tint-op/s": mops / ms / 1e9}
 print(json.dumps(out, indent=1))
 ctx.close()
+ctx_unfused.close()

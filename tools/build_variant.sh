@@ -11,7 +11,7 @@ else for f in $(git -C "$ROOT" ls-tree --name-only "$REV" fasthevc_amd/csrc/ inc
 sed -i 's|#include "../../include/fasthevc.h"|#include "../include/fasthevc.h"|' "$T"/csrc/* 2>/dev/null || true
 cd "$T/csrc"
 for s in $(cd "$T/csrc" && ls *.hip | sed "s/.hip//"); do
-  X=""; [ $s = k_cnn ] && X="-ffinite-math-only -fno-signed-zeros"
+  X=""; [ $s = k_cnn ] && X="-ffinite-math-only -fno-signed-zeros ${CNN_FLAGS:-}"
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -w $X -I"$T/include" -c $s.hip -o $s.o &
 done
 wait
