@@ -11,7 +11,8 @@
  *   FHEVC_DEVICE=<ordinal>    HIP device (default 0)
  *   FHEVC_MARGIN=<int>        soft decisions: logit margin inside which a split decision is left to HM's RDO;
  *   FHEVC_MARGIN_SPLIT / FHEVC_MARGIN_STOP set the two sides separately (not forcing unsure splits is almost free,
- *                             not forbidding unsure ones costs the recursion it allows).  Defaults: split 32000, stop 0;
+ *                             not forbidding unsure ones costs the recursion it allows).  Defaults: split 100000, stop 48000 (every content
+ *                             family measured stays within 1 % BD-rate); split 32000, stop 0 for content like the training set;
  *                             FHEVC_MARGIN=0 gives hard decisions
  *   FHEVC_P_MODE=window|motion  P/B pictures whose first reference picture was inter coded (default: off = stock RDO):
  *                             window = co-located depth of that picture +- FHEVC_P_WINDOW levels (host logic only, independent of
