@@ -414,7 +414,7 @@ def main():
             if os.path.exists(path):
                 d = json.load(open(path))
                 for k, v in d.items():
-                    if k.startswith(kernel) and "hbm_read_bytes_corrected" in v and "hbm_write_bytes" in v:
+                    if k.startswith(kernel) and isinstance(v, dict) and "hbm_read_bytes_corrected" in v and "hbm_write_bytes" in v:
                         return v["hbm_read_bytes_corrected"] + v["hbm_write_bytes"], f"profiles/{rnd}_pmc_bench_frames64_int16.json (commit {d.get('commit', 'of that round')})"
         return None, None
 

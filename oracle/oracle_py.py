@@ -212,7 +212,7 @@ def rdo_encode(lib, plane, origin, stride, width, height, bit_depth, qp, forced_
     [H/2, W/2] at the internal bit depth (default: flat mid-grey)."""
     n = ((width + 63) // 64) * ((height + 63) // 64)
     depth = np.zeros(n * 256, np.uint8)
-    stats = np.zeros(8, np.float64)
+    stats = np.zeros(10, np.float64)
     fd = None
     if forced_depth is not None:
         fd = np.ascontiguousarray(forced_depth, np.uint8).reshape(-1)
@@ -239,6 +239,8 @@ def rdo_encode(lib, plane, origin, stride, width, height, bit_depth, qp, forced_
     peak = (1 << bit_depth) - 1
     out = {"bits": stats[0], "dist": stats[1], "rdcost": stats[2], "seconds": stats[3],
            "psnr_y": 10 * np.log10(peak * peak / mse) if mse > 0 else 99.0, "ctus": int(stats[5]), "coded_bits": stats[6]}
+    if stats[8] > 0:  # FHREF_ENCODE_SLICE=1: slice-data bits of the reference's own encodeSlice (real arithmetic coder)
+        out["slice_data_bits"] = stats[8]
     if stats[7] > 0:  # FHREF_DEBLOCK=1: luma PSNR after the reference's own deblocking filter
         out["psnr_y_deblocked"] = 10 * np.log10(peak * peak / (stats[7] / (width * height)))
     return depth.reshape(n, 256), out

@@ -42,6 +42,7 @@
 #include "TLibCommon/TComPattern.h"
 #include "TLibCommon/TComPrediction.h"
 #include "TLibCommon/TComLoopFilter.h"
+#include "TLibCommon/TComBitStream.h"
 #include "TLibCommon/TComRdCost.h"
 #include "TLibEncoder/TEncCfg.h"
 #include "TLibEncoder/TEncCu.h"
@@ -299,7 +300,8 @@ extern "C" {
 // depth_out: numCtus*256, raster per CTU = getDepth(g_auiRasterToZscan[r]).  stats: [0] bits (RD-SBAC estimate summed
 // over CTUs), [1] distortion (SSE, chroma weighted as in TComRdCost), [2] RD cost, [3] seconds in compressSlice,
 // [4] luma SSE of the reconstruction vs the original, [5] number of CTUs, [6] bits counted by encodeCtu, [7] luma SSE after the
-// reference's own deblocking filter when FHREF_DEBLOCK=1 (else -1).
+// reference's own deblocking filter when FHREF_DEBLOCK=1 (else -1), [8] slice-data bits written by the reference's own encodeSlice
+// (real CABAC) when FHREF_ENCODE_SLICE=1 (else -1).
 int href_rdo_encode_frame_yuv(const int16_t* luma, int stride, const int16_t* cb, const int16_t* cr, int width, int height,
                               int bit_depth, int qp, const uint8_t* forced_depth, uint8_t* depth_out, double* stats);
 
@@ -361,6 +363,15 @@ int href_rdo_encode_frame_yuv(const int16_t* luma, int stride, const int16_t* cb
     stats[4] = sse;
     stats[5] = n;
     stats[7] = -1.0;
+    stats[8] = -1.0;
+    if (env_int("FHREF_ENCODE_SLICE", 0)) {
+      // the reference's own TEncSlice::encodeSlice (TEncSlice.cpp:985-1160: the real arithmetic coder, TEncBinCABAC) over the picture the
+      // decision path has just filled in: slice-data bits as they would stand in the bitstream (no slice header, no SAO syntax: SAO is not run)
+      TComOutputBitstream substream;
+      UInt bins = 0;
+      e->slice.encodeSlice(e->pic, &substream, bins);
+      stats[8] = (double)substream.getNumberOfWrittenBits();
+    }
     if (env_int("FHREF_DEBLOCK", 0)) {
       // the reference's own in-loop deblocking filter on the reconstruction (TComLoopFilter::loopFilterPic, called by TEncGOP.cpp:1607-1619
       // with the slice's default parameters: filter enabled, beta / tc offsets 0), then the luma SSE again: distortion as a decoder

@@ -168,3 +168,24 @@ def test_trained_weights_follow_the_reference_decisions(oracle):
     const_agree = max(float((ref == c).mean()) for c in range(4))
     const_err = min(float(np.abs(ref.astype(int) - c).mean()) for c in range(4))
     assert agree > const_agree + 0.10 and mean_err < const_err - 0.20, (agree, const_agree, mean_err, const_err)
+
+
+@need_ref
+def test_true_rate_and_post_filter_distortion_from_the_references_own_code(monkeypatch):
+    """The quality figures rest on bits counted by encodeCtu during compressSlice (RD-SBAC estimate) and on the PSNR before the
+    in-loop filters.  The harness can also run the reference's own TEncSlice::encodeSlice (the real arithmetic coder) and
+    TComLoopFilter::loopFilterPic on the same picture: the counted bits agree with the written slice data to a fraction of a
+    percent, and deblocking moves the PSNR by hundredths of a dB -- for the full-RDO picture and for a hook-driven one alike."""
+    monkeypatch.setenv("FHREF_ENCODE_SLICE", "1")
+    monkeypatch.setenv("FHREF_DEBLOCK", "1")
+    luma = frames.hetero_luma(1920, 1080)[:256, :384].copy()
+    buf, org, stride = frames.to_pel_plane(luma, 8)
+    hook = op.bind_rdo(op.load_ref(hook=True))
+    for qp in (22, 37):
+        d, s = op.rdo_encode(hook, buf, org, stride, 384, 256, 8, qp)
+        assert abs(s["slice_data_bits"] - s["coded_bits"]) <= 0.005 * s["coded_bits"] + 16
+        assert abs(s["psnr_y_deblocked"] - s["psnr_y"]) < 0.3
+        forced = np.clip(d.astype(int) - 1, 0, 3).astype(np.uint8)   # a deliberately worse map through the hook
+        _, t = op.rdo_encode(hook, buf, org, stride, 384, 256, 8, qp, forced_depth=forced)
+        assert abs(t["slice_data_bits"] - t["coded_bits"]) <= 0.005 * t["coded_bits"] + 16
+        assert t["slice_data_bits"] != s["slice_data_bits"] and abs(t["psnr_y_deblocked"] - t["psnr_y"]) < 0.3

@@ -17,6 +17,16 @@ pairs = {
 }
 for a, b in pairs.items():
     shutil.copyfile(os.path.join(src, a), os.path.join(dst, b))
+# stamp the PMC summaries with the commit they were taken at (the GPU box has no .git): bench.py quotes it in roofline.traffic_source
+import json
+import subprocess
+commit = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+dirty = bool(subprocess.run(["git", "-C", root, "status", "--porcelain", "--", "fasthevc_amd/csrc", "bench.py"], capture_output=True, text=True).stdout.strip())
+for b in (pairs["pmc_bench.json"], pairs["pmc_kernels.json"]):
+    path = os.path.join(dst, b)
+    d = json.load(open(path))
+    d["commit"] = commit + (" + uncommitted kernel changes" if dirty else "")
+    json.dump(d, open(path, "w"), indent=1, sort_keys=True)
 stats = sorted(glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
 assert stats, "no kernel stats"
 shutil.copyfile(stats[-1], os.path.join(dst, f"{tag}_kernel_stats_bench_default.csv"))  # gpurun merges runs: newest wins
