@@ -48,7 +48,8 @@ def test_reference_encoder_driven_by_the_gpu_library(oracle):
         # TEncFastDepth reads its knobs when the harness constructs the encoder of a geometry: one geometry per setting
         for (W, H), env, margins in (((768, 512), {"FHEVC_ENABLE": "1", "FHEVC_WEIGHTS": BLOB, "FHEVC_MARGIN": "0"}, (0, 0)),
                                     ((832, 448), {"FHEVC_ENABLE": "1", "FHEVC_WEIGHTS": BLOB}, (100000, 48000)),   # the hook's defaults
-                                    ((704, 512), {"FHEVC_ENABLE": "1", "FHEVC_WEIGHTS": BLOB, "FHEVC_MARGIN_SPLIT": "32000"}, (32000, 0)),
+                                    ((704, 512), {"FHEVC_ENABLE": "1", "FHEVC_WEIGHTS": BLOB, "FHEVC_MARGIN_SPLIT": "32000"}, (32000, 48000)),   # the other side keeps its default
+                                    ((576, 512), {"FHEVC_ENABLE": "1", "FHEVC_WEIGHTS": BLOB, "FHEVC_MARGIN_SPLIT": "32000", "FHEVC_MARGIN_STOP": "0"}, (32000, 0)),
                                     ((640, 448), {"FHEVC_ENABLE": "1", "FHEVC_WEIGHTS": BLOB, "FHEVC_MARGIN": "8000"}, (8000, 8000))):
             buf, org, stride, chroma = _picture(W, H)
             dmin, dmax = _oracle_maps(oracle, buf, org, stride, W, H, *margins)
@@ -62,7 +63,7 @@ def test_reference_encoder_driven_by_the_gpu_library(oracle):
             assert s_gpu["bits"] == s_ref["bits"] and s_gpu["dist"] == s_ref["dist"], (W, H)
             assert not np.array_equal(d_gpu, d_full) and s_gpu["seconds"] < (0.95 if margins[1] >= 48000 else 0.8) * s_full["seconds"], (W, H)
         # library switched off (FHEVC_ENABLE unset) / weights missing: stock full RDO, never an abort
-        for (W, H), env in (((576, 448), {}), ((512, 448), {"FHEVC_ENABLE": "1", "FHEVC_WEIGHTS": "/nonexistent.fhw"})):
+        for (W, H), env in (((576, 448), {}), ((512, 448), {"FHEVC_ENABLE": "1", "FHEVC_WEIGHTS": "/nonexistent.fhw"})):  # (geometries not used above)
             buf, org, stride, chroma = _picture(W, H)
             d_full, s_full = op.rdo_encode(hook, buf, org, stride, W, H, 8, QP, chroma=chroma)
             for k in KNOBS:
