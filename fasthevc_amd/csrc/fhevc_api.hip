@@ -27,6 +27,9 @@ struct fhevc_ctx {
   // weight image
   bool have_weights = false;
   uint4* d_frag = nullptr; float* d_bias = nullptr; uint8_t* d_whead = nullptr; int32_t* d_bhead = nullptr;
+  uint4* d_frag_i8 = nullptr; int32_t* d_bias_i8 = nullptr;  // the i8 variant of conv2 / conv3 (k_cnn.hip)
+  int shift[3] = { 0, 0, 0 };
+  bool cnn_i8 = false;                                        // FHEVC_CNN_ARITH=i8 at fhevc_create
   float scale[3] = { 1, 1, 1 };
   // staging for the host-buffer entry points
   int16_t* d_luma = nullptr; uint8_t* d_depth = nullptr; int32_t* d_had = nullptr; FhevcNodeCost* d_nodes = nullptr;
@@ -122,6 +125,7 @@ int build_weight_image(fhevc_ctx* c, const BlobView& b)
     const int s = rd32(b.shift, l);
     if (s < 0 || s > 14) return fail(c, FHEVC_E_WEIGHTS, "shift out of range (0..14)");
     c->scale[l] = std::ldexp(1.0f, -s);
+    c->shift[l] = s;
   }
   std::vector<uint16_t> frag((size_t)FHEVC_FRAG_TOTAL * 8, 0);
   // all conv weights carry their layer's 2^-shift: w * 2^-s is still exact in bf16 (a power-of-two scaling of an 8-bit integer)
@@ -170,6 +174,37 @@ int build_weight_image(fhevc_ctx* c, const BlobView& b)
           put_scaled(2, FHEVC_FRAG_CONV3 + (t * 18 + s) * 64, lane, j, b.w3[(oc * 32 + ic) * 9 + tap]);
         }
   }
+  // the i8 variant (v_mfma_i32_32x32x32_i8: a lane holds 16 signed bytes of K; lanes 0-31 K 0-15, lanes 32-63 K 16-31):
+  //   conv2 fragment (q, kx): row = output channel lane & 31, K byte j of lane half h = input channel j at tap (ky = 2 q + h, kx)
+  //                           (ky = 3: the phantom row, zero);
+  //   conv3 fragment (tile, tap): row = output channel 32 tile + (lane & 31), K byte j of lane half h = input channel 16 h + j
+  std::vector<int8_t> frag8((size_t)FHEVC_FRAGI8_TOTAL * 16, 0);
+  for (int lane = 0; lane < 64; ++lane) {
+    const int r = lane & 31, h = lane >> 5;
+    for (int j = 0; j < 16; ++j) {
+      for (int q = 0; q < 2; ++q)
+        for (int kx = 0; kx < 3; ++kx) {
+          const int ky = 2 * q + h;
+          if (ky <= 2) frag8[((size_t)FHEVC_FRAGI8_CONV2 + (q * 3 + kx) * 64 + lane) * 16 + j] = b.w2[(r * 16 + j) * 9 + ky * 3 + kx];
+        }
+      for (int t = 0; t < 2; ++t)
+        for (int tap = 0; tap < 9; ++tap)
+          frag8[((size_t)FHEVC_FRAGI8_CONV3 + (t * 9 + tap) * 64 + lane) * 16 + j] = b.w3[((32 * t + r) * 32 + 16 * h + j) * 9 + tap];
+    }
+  }
+  // its biases: the activations travel as a - 128, so sum w a = sum w (a - 128) + 128 sum w (over ALL taps: the halo holds
+  // a - 128 = -128, "activation 0", and meets the same correction)
+  std::vector<int32_t> bias8(112, 0);
+  for (int oc = 0; oc < 32; ++oc) {
+    int sw = 0;
+    for (int i = 0; i < 16 * 9; ++i) sw += b.w2[oc * 144 + i];
+    bias8[16 + oc] = rd32(b.b2, oc) + 128 * sw;
+  }
+  for (int oc = 0; oc < 64; ++oc) {
+    int sw = 0;
+    for (int i = 0; i < 32 * 9; ++i) sw += b.w3[oc * 288 + i];
+    bias8[48 + oc] = rd32(b.b3, oc) + 128 * sw;
+  }
   std::vector<float> bias(112);
   for (int i = 0; i < 16; ++i) {  // the kernel feeds conv1 the samples x, not x - 128: sum w (x - 128) + b = sum w x + (b - 128 sum w)
     int sw = 0;
@@ -202,7 +237,11 @@ int build_weight_image(fhevc_ctx* c, const BlobView& b)
     HIP_TRY(c, hipMalloc(&c->d_bias, bias.size() * 4));
     HIP_TRY(c, hipMalloc(&c->d_whead, whead.size()));
     HIP_TRY(c, hipMalloc(&c->d_bhead, sizeof bhead));
+    HIP_TRY(c, hipMalloc(&c->d_frag_i8, frag8.size()));
+    HIP_TRY(c, hipMalloc(&c->d_bias_i8, bias8.size() * 4));
   }
+  HIP_TRY(c, hipMemcpy(c->d_frag_i8, frag8.data(), frag8.size(), hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(c->d_bias_i8, bias8.data(), bias8.size() * 4, hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(c->d_frag, frag.data(), frag.size() * 2, hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(c->d_bias, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(c->d_whead, whead.data(), whead.size(), hipMemcpyHostToDevice));
@@ -216,6 +255,9 @@ FhevcCnnWeights cnn_weights(const fhevc_ctx* c)
   FhevcCnnWeights w;
   w.frag = c->d_frag; w.bias = c->d_bias; w.whead = c->d_whead; w.bhead = c->d_bhead;
   w.scale[0] = c->scale[0]; w.scale[1] = c->scale[1]; w.scale[2] = c->scale[2];
+  w.frag_i8 = c->d_frag_i8; w.bias_i8 = c->d_bias_i8;
+  w.shift[0] = c->shift[0]; w.shift[1] = c->shift[1]; w.shift[2] = c->shift[2];
+  w.i8 = c->cnn_i8 ? 1 : 0;
   return w;
 }
 
@@ -300,6 +342,8 @@ int fhevc_create(fhevc_ctx** out, const fhevc_cfg* cfg)
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) { delete c; return FHEVC_E_NO_DEVICE; }  // code object is gfx950-only
   c->num_cus = prop.multiProcessorCount;
   if (const char* fz = std::getenv("FHEVC_FUSE_HADAMARD")) c->fuse_hadamard = fz[0] != '0';
+  // arithmetic of conv2 / conv3 in the depth kernel: "f16" (16-bit MFMAs) or "i8" (v_mfma_i32_32x32x32_i8); both are exact
+  if (const char* ar = std::getenv("FHEVC_CNN_ARITH")) c->cnn_i8 = std::strcmp(ar, "i8") == 0;
   c->ctus_x = (cfg->width + 63) / 64;
   c->ctus_y = (cfg->height + 63) / 64;
   c->num_ctus = c->ctus_x * c->ctus_y;
@@ -341,6 +385,7 @@ void fhevc_destroy(fhevc_ctx* c)
   for (auto& p : c->pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   (void)hipFree(c->d_frag); (void)hipFree(c->d_bias); (void)hipFree(c->d_whead); (void)hipFree(c->d_bhead);
+  (void)hipFree(c->d_frag_i8); (void)hipFree(c->d_bias_i8);
   (void)hipFree(c->d_luma); (void)hipFree(c->d_depth); (void)hipFree(c->d_had); (void)hipFree(c->d_nodes); (void)hipFree(c->d_satd); (void)hipFree(c->d_satd_out); (void)hipFree(c->d_act); (void)hipFree(c->d_depth_max); (void)hipFree(c->d_pair); (void)hipFree(c->d_motion);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;

@@ -16,6 +16,10 @@
 #define FHEVC_FRAG_CONV2 128
 #define FHEVC_FRAG_CONV3 (128 + 9 * 64)
 #define FHEVC_FRAG_TOTAL (128 + 9 * 64 + 2 * 18 * 64)
+// the i8 variant's fragments (one uint4 = 16 signed bytes per lane): conv2 [2 row pairs][3 columns of taps][64], conv3 [2 tiles][9 taps][64]
+#define FHEVC_FRAGI8_CONV2 0
+#define FHEVC_FRAGI8_CONV3 (6 * 64)
+#define FHEVC_FRAGI8_TOTAL (6 * 64 + 2 * 9 * 64)
 
 struct FhevcFrames {
   const void* luma;          // device pointer to sample (0,0) of frame 0
@@ -35,6 +39,12 @@ struct FhevcCnnWeights {
   const uint8_t* whead;
   const int32_t* bhead;      // bh64[2], bh32[2], bh16[2], then qp_bias[3][52]
   float scale[3];            // 2^-shift per conv layer (folded into the fragments; the kernel pre-scales the biases with it)
+  // the i8 variant of conv2 / conv3 (v_mfma_i32_32x32x32_i8 on activations a - 128): unscaled int8 fragments, int32 biases
+  // (+ 128 * the sum of the filter's weights; entries 16.. of bias_i8, laid out like bias) and the requant shifts
+  const uint4* frag_i8;
+  const int32_t* bias_i8;
+  int shift[3];
+  int i8;                    // 1: run that variant
 };
 
 hipError_t fhevc_cnn_prepare_device();  // LDS opt-in of the depth kernel on the current device (once per context)

@@ -36,34 +36,49 @@ typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
 namespace {
 
 // ---- LDS map (bytes) ---------------------------------------------------------------------------------------
-// conv1 output: 32x32 + 1 halo each side = 34 x 34 positions per 8-channel plane
+// conv1 output: 32x32 + 1 halo each side = 34 x 34 positions, 16 B per position and plane
 constexpr int A1_ROW = 36 * 16;                   // bytes per row of a plane; inside a row the columns are split by parity: odd x
 constexpr int A1_EVEN = 19 * 16;                  // at slot x >> 1, even x at slot 19 + (x >> 1), so that the stride-2 column runs
                                                   // conv2 reads (one pooled column per lane) are contiguous; 19 = 3 mod 8 keeps the
                                                   // two 64-byte halves of conv1's 8-lane store groups on disjoint banks
-constexpr int A1_PLANE = 34 * A1_ROW;             // one 8-channel plane: 16 B per position
-constexpr int R1_OFF = 0;                         // R1: A1 (2 planes); later A3 u8 [256][64] + pooled [64][64]
-constexpr int R1_BYTES = 2 * A1_PLANE;            // 39168
+constexpr int R1_OFF = 0;                         // R1: A1; later A3 u8 [256][64]
 constexpr int A3_OFF = R1_OFF;
-constexpr int P3_OFF = R1_OFF + 16384;            // maxpool2x2(a3): [8*8][64] u8
 constexpr int A2_PITCH = 18;                      // conv2 output 16x16 + halo
 constexpr int A2_PLANE = 18 * 18 * 16 + 192;      // 5376 = 21 * 256: conv3's B operand takes lane group kg of a ds_read_b128 from plane kg,
                                                   // and {positions 0-3, 12-15 of plane 0} + {4-11 of plane 1} only tile a 256-byte bank row
                                                   // when the planes are a multiple of 256 B apart
-constexpr int R2_OFF = R1_OFF + R1_BYTES;         // R2: input CTU bf16 [66][68]; later A2 (4 planes)
-constexpr int R2_BYTES = 4 * A2_PLANE;            // 21504
 constexpr int IN_PITCH = 68;                      // dwords per input row PAIR (66 used): lo = row 2j, hi = row 2j+1
-constexpr int BIAS_OFF = R2_OFF + R2_BYTES;       // float b1[16] b2[32] b3[64]
-constexpr int LOGIT_OFF = BIAS_OFF + 112 * 4;     // int logits[21][2] (the 64-level pair is formed by the readers) + at [44..51] the
-                                                  // four waves' partial 64-level sums; at [56..63] two sets of the four waves' source-
-                                                  // Hadamard sums (the set of the CTU in flight and the set of the next one)
-constexpr int HEADW_OFF = LOGIT_OFF + 64 * 4;     // int8 head weights: wh64, wh32, wh16 = 18432 B
-constexpr int LDS_BYTES = HEADW_OFF + 18432;      // 79808 -> two workgroups per CU (155.9 of 160 KiB)
-static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
-static_assert(A2_PLANE % 256 == 0, "conv3 reads lane group kg of a ds_read_b128 from plane kg");
-static_assert(33 * IN_PITCH * 4 <= R2_BYTES, "input tile must fit the A2 region");
-static_assert(HEADW_OFF % 16 == 0, "head weights are read with ds_read_b128");
-static_assert(P3_OFF + 4096 <= R1_OFF + R1_BYTES, "pooled map must fit R1");
+// The two arithmetic variants of the kernel differ in the activations between the convs:
+//   I8 = false: f16 (16-bit MFMAs): A1 = 2 planes of 8 channels, A2 = 4 planes of 8 channels;
+//   I8 = true : signed bytes a - 128 (v_mfma_i32_32x32x32_i8 in conv2 and conv3): A1 = 1 plane of 16 channels (+ one phantom row that
+//               only zero weights meet), A2 = 2 planes of 16 channels -- half the LDS, which is what lets three workgroups share a CU
+#ifndef FHEVC_I8_WG_PER_CU
+#define FHEVC_I8_WG_PER_CU 3
+#endif
+template <bool I8>
+struct Lds {
+  static constexpr int A1_PLANE = (I8 ? 35 : 34) * A1_ROW;
+  static constexpr int A1_PLANES = I8 ? 1 : 2, A2_PLANES = I8 ? 2 : 4;
+  static constexpr int R1_BYTES = A1_PLANES * A1_PLANE;     // 39168 / 20160
+  static constexpr int R2_OFF = R1_OFF + R1_BYTES;          // R2: input CTU bf16 [66][68]; later A2
+  static constexpr int R2_BYTES = A2_PLANES * A2_PLANE;     // 21504 / 10752
+  static constexpr int BIAS_OFF = R2_OFF + R2_BYTES;        // b1[16] (float) b2[32] b3[64] (float, or int32 in the i8 variant)
+  static constexpr int LOGIT_OFF = BIAS_OFF + 112 * 4;      // int logits[21][2] (the 64-level pair is formed by the readers) + at [44..51] the
+                                                            // four waves' partial 64-level sums; at [56..63] two sets of the four waves' source-
+                                                            // Hadamard sums (the set of the CTU in flight and the set of the next one)
+  static constexpr int HEADW_OFF = LOGIT_OFF + 64 * 4;      // int8 head weights: wh64, wh32, wh16 = 18432 B
+  static constexpr int LDS_BYTES = HEADW_OFF + 18432;       // 79808 -> two workgroups per CU (155.9 of 160 KiB) / 50048 -> three
+  static constexpr unsigned HALO_FILL = I8 ? 0x80808080u : 0u;  // "activation 0" in the halos of A1 and A2
+  static_assert(A2_PLANE % 256 == 0, "conv3 reads lane groups of a ds_read_b128 from different planes");
+  static_assert(33 * IN_PITCH * 4 + 4 * IN_PITCH * 4 <= R2_BYTES, "input tile (and conv1's one fragment read past it) must fit the A2 region");
+  static_assert(HEADW_OFF % 16 == 0, "head weights are read with ds_read_b128");
+  static_assert(A3_OFF + 16384 <= R1_OFF + R1_BYTES, "conv3's output must fit R1");
+  static_assert(R2_OFF + R2_BYTES <= 65536, "halo offsets are packed into 16 bits");
+};
+static_assert(2 * Lds<false>::LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+static_assert(3 * Lds<true>::LDS_BYTES <= 160 * 1024, "three workgroups per CU");
+// the 16-bit variant's names, as its epilogues and chains use them
+constexpr int A1_PLANE = Lds<false>::A1_PLANE;
 
 constexpr int HEAD64_OFF = 0, HEAD32_OFF = 2 * 4096, HEAD16_OFF = 4 * 4096;  // into whead (int8)
 
@@ -213,6 +228,66 @@ __device__ __forceinline__ void conv3_store(const f32x4& acc0, const f32x4& acc1
   *reinterpret_cast<unsigned*>(dst + (((2 * tile + 1) ^ psw) << 4)) = d1 ^ 0x80808080u;
 }
 
+// ---- the i8 variant's epilogues: int32 accumulators (bias + 128 * sum of weights as the C operand: the activations travel as
+// a - 128), requant = arithmetic shift, clamp to 0..255, back to a - 128.  Four values -> one dword in 9 instructions:
+// 4 v_ashrrev_i32, 2 v_cvt_pk_i16_i32 (saturating), 2 v_sat_pk_u8_i16 (SDWA: low / high word of the result), 1 v_xor
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(16))) int i32x16;
+typedef __attribute__((ext_vector_type(2))) short s16x2_t;
+__device__ __forceinline__ unsigned requant4_i8(int a, int b, int c, int d, int shift)
+{
+  const s16x2_t p0 = __builtin_amdgcn_cvt_pk_i16(a >> shift, b >> shift), p1 = __builtin_amdgcn_cvt_pk_i16(c >> shift, d >> shift);
+  unsigned r;
+  asm("v_sat_pk_u8_i16_sdwa %0, %1 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD" : "=v"(r) : "v"(p0));
+  asm("v_sat_pk_u8_i16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(r) : "v"(p1));
+  return r ^ 0x80808080u;
+}
+// conv1 (still on the bf16 MFMA: K = 16 gains nothing from the i8 shape): pool, floor + clamp, a - 128; the lane's 8 channels
+// (8h .. 8h+7) are 8 bytes of the position's 16
+__device__ __forceinline__ void conv1_store_i8(const f32x16& acc0, const f32x16& acc1, unsigned char* dst)
+{
+  float m[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) m[k] = fmaxf(fmaxf(acc0[k], acc0[k + 8]), fmaxf(acc1[k], acc1[k + 8]));
+  *reinterpret_cast<uint2*>(dst) = make_uint2(u8x4_floor_clamp(m[0], m[1], m[2], m[3]) ^ 0x80808080u, u8x4_floor_clamp(m[4], m[5], m[6], m[7]) ^ 0x80808080u);
+}
+__device__ __forceinline__ i32x16 bias_tile_i8(const int* b32, int h)  // the integer twin of bias_tile
+{
+  i32x16 acc;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int4 v = *reinterpret_cast<const int4*>(b32 + 8 * g + 4 * h);
+    acc[4 * g + 0] = v.x; acc[4 * g + 1] = v.y; acc[4 * g + 2] = v.z; acc[4 * g + 3] = v.w;
+  }
+  return acc;
+}
+__device__ __forceinline__ void pool_h_i8(i32x16& acc0, const i32x16& acc1)
+{
+#pragma unroll
+  for (int k = 0; k < 16; ++k) acc0[k] = max(acc0[k], acc1[k]);
+}
+__device__ __forceinline__ void pool_v_i8(i32x16& top, const i32x16& acc0, const i32x16& acc1)
+{
+#pragma unroll
+  for (int k = 0; k < 16; ++k) top[k] = max(max(top[k], acc0[k]), acc1[k]);
+}
+// reg i -> channel (i & 3) + 8 g + 4 h, g = i >> 2: plane g >> 1, bytes 8 (g & 1) + 4 h ..; dst = the lane's position in plane 0 + 4 h
+__device__ __forceinline__ void conv2_requant_store_i8(const i32x16& m, unsigned char* dst, int shift)
+{
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    *reinterpret_cast<unsigned*>(dst + (g >> 1) * A2_PLANE + 8 * (g & 1)) = requant4_i8(m[4 * g], m[4 * g + 1], m[4 * g + 2], m[4 * g + 3], shift);
+}
+// conv3: channel 32 tile + 8 g + 4 h + (i & 3) of a position lives in logical 16-B chunk 2 tile + (g >> 1), bytes 8 (g & 1) + 4 h ..;
+// dst = the position's 64-byte row + 4 h; psw = chunk swizzle of the position
+__device__ __forceinline__ void conv3_store_i8(const i32x16& acc, unsigned char* dst, int tile, int psw, int shift)
+{
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    *reinterpret_cast<unsigned*>(dst + (((2 * tile + (g >> 1)) ^ psw) << 4) + 8 * (g & 1)) =
+        requant4_i8(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3], shift);
+}
+
 // ---- MFMA chains with a register ring of B fragments ---------------------------------------------------------
 // Each v_mfma needs one ds_read_b128 (its im2col fragment).  hipcc places the read right in front of its MFMA and
 // waits for it, exposing the LDS latency 18 times per chain; instead the reads run RING steps ahead of their MFMA
@@ -298,6 +373,90 @@ __device__ __forceinline__ void sched_row18()
   for (int i = 0; i < 9; ++i) {
     __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // 2 MFMAs (the two M tiles of a fragment)
     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+  }
+}
+// ---- the i8 variant's chains (v_mfma_i32_32x32x32_i8: K = 32 bytes, lanes 0-31 hold K 0-15, lanes 32-63 K 16-31) ----------
+__device__ __forceinline__ i32x16 mfma_i8(const bf16x8& a, const bf16x8& b, const i32x16& c)
+{
+  return __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, a), __builtin_bit_cast(i32x4, b), c, 0, 0, 0);
+}
+// conv2: K = one column of taps over TWO input rows (ky = 2 q + lane half) x 16 channels: q = 0 -> taps (0, kx), (1, kx);
+// q = 1 -> (2, kx) and a phantom row whose weights are zero.  The lane halves read rows one A1_ROW apart (the lane's base
+// pointer carries it), so fragment (q, column c) is ONE ds_read_b128 at a compile-time offset: 8 fragments, 12 MFMAs per
+// half-chain (c = 1, 2 feed both accumulators) where the 16-bit form needs 12 and 18
+__device__ __forceinline__ const unsigned char* conv2_frag_i8(const unsigned char* base, int f)
+{
+  return base + 2 * (f / 4) * A1_ROW + (((f % 4) & 1) ? 0 : A1_EVEN) + ((f % 4) >> 1) * 16;
+}
+template <bool FIRST, bool LAST>
+__device__ __forceinline__ void conv2_half_i8(const unsigned char* base, const unsigned char* next, const bf16x8 (&wA2)[9], bf16x8 (&ring)[RING],
+                                              const int* bias, int h, i32x16& acc0, i32x16& acc1)
+{
+  const i32x16 binit = bias_tile_i8(bias, h);  // read per half-chain, not held across the phase (168 registers)
+  acc0 = binit;
+  acc1 = binit;
+  if (FIRST) {
+#pragma unroll
+    for (int f = 0; f < RING; ++f) ring[f] = lds_frag(conv2_frag_i8(base, f));
+  }
+#pragma unroll
+  for (int f = 0; f < 8; ++f) {
+    const int q = f / 4, c = f % 4;
+    const bf16x8 b = ring[f % RING];
+    if (c < 3) acc0 = mfma_i8(wA2[q * 3 + c], b, acc0);
+    if (c > 0) acc1 = mfma_i8(wA2[q * 3 + c - 1], b, acc1);
+    if (f + RING < 8) ring[f % RING] = lds_frag(conv2_frag_i8(base, f + RING));
+    else if (!LAST) ring[f % RING] = lds_frag(conv2_frag_i8(next, f + RING - 8));
+  }
+}
+static_assert(8 % RING == 0, "the i8 conv2 hands its ring slots from half-chain to half-chain unchanged");
+template <int VALU_PER_GROUP>
+__device__ __forceinline__ void sched_chain12_i8()
+{
+#define FHEVC_G(NM)                                                                          \
+  __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);                                        \
+  __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                         \
+  if (VALU_PER_GROUP > 0) __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_GROUP, 0);
+  FHEVC_G(1) FHEVC_G(2) FHEVC_G(2) FHEVC_G(1) FHEVC_G(1) FHEVC_G(2) FHEVC_G(2) FHEVC_G(1)  // fragments c = 0 .. 3 of q = 0, 1
+#undef FHEVC_G
+}
+// conv3: one MFMA = one tap x all 32 input channels (lane half = activation plane) x the wave's 32 output channels x TWO output
+// rows (B column n: row n >> 4, x = n & 15): 9 MFMAs and 9 ds_read_b128 per row pair, 4 row pairs per wave.  Two row pairs run
+// interleaved (two independent accumulators: a lone chain of 9 would wait for each MFMA's result): super-chain S = row pairs
+// 2S, 2S+1, fragment g = 18 S + 2 tap + (pair & 1)
+__device__ __forceinline__ constexpr int conv3_frag_off_i8(int g)
+{
+  const int k = 2 * (g / 18) + (g & 1), t = (g % 18) / 2;
+  return ((4 * k + t / 3) * A2_PITCH + t % 3) * 16;
+}
+template <int S>
+__device__ __forceinline__ void conv3_pairs_i8(const unsigned char* base, const bf16x8 (&wA3)[18], bf16x8 (&ring)[RING3], const int* bias, int h,
+                                               i32x16& acc0, i32x16& acc1)
+{
+  const i32x16 binit = bias_tile_i8(bias, h);  // read per super-chain, not held across the phase (168 registers)
+  acc0 = binit;
+  acc1 = binit;
+  if (S == 0) {
+#pragma unroll
+    for (int g = 0; g < RING3; ++g) ring[g] = lds_frag(base + conv3_frag_off_i8(g));
+  }
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int g = 18 * S + 2 * t;
+    acc0 = mfma_i8(wA3[t], ring[g % RING3], acc0);
+    if (g + RING3 < 36) ring[g % RING3] = lds_frag(base + conv3_frag_off_i8(g + RING3));
+    acc1 = mfma_i8(wA3[t], ring[(g + 1) % RING3], acc1);
+    if (g + 1 + RING3 < 36) ring[(g + 1) % RING3] = lds_frag(base + conv3_frag_off_i8(g + 1 + RING3));
+  }
+}
+template <int VALU_PER_GROUP>
+__device__ __forceinline__ void sched_pairs18_i8()
+{
+#pragma unroll
+  for (int i = 0; i < 18; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    if (VALU_PER_GROUP > 0) __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_GROUP, 0);
   }
 }
 // One thread's 16 samples of a CTU (picture row ld_row, columns 16*ld_seg..) fetched ahead of use.  fast = 0:
@@ -434,10 +593,10 @@ __device__ __forceinline__ unsigned sample8_pair(unsigned w, int shift, unsigned
 
 // Stage one CTU into LDS (region R2): 8-bit samples as bf16, two picture rows per dword, halo = 128 (the centre).
 // halo coordinates: hy = row + 1, hx = col + 1; dword (hy >> 1) * IN_PITCH + hx, half (hy & 1)
-__device__ __forceinline__ void stage_ctu(unsigned char* lds, const Prefetched& pre, const FhevcFrames& F, CtuPos c,
+__device__ __forceinline__ void stage_ctu(unsigned char* lds, int r2_off, const Prefetched& pre, const FhevcFrames& F, CtuPos c,
                                           int tid, int ld_row, int ld_seg, int shift_in, unsigned in_cells)
 {
-  unsigned short* inh = reinterpret_cast<unsigned short*>(lds + R2_OFF);
+  unsigned short* inh = reinterpret_cast<unsigned short*>(lds + r2_off);
   const int hy = ld_row + 1;
   unsigned short* dst = inh + 2 * ((hy >> 1) * IN_PITCH + ld_seg * 16 + 1) + (hy & 1);
   if (pre.fast) {
@@ -480,6 +639,7 @@ __device__ __forceinline__ void stage_ctu(unsigned char* lds, const Prefetched& 
 // LDS byte offsets of the halo cells a thread zeroes (computed once per kernel: the index arithmetic with its three-way
 // divergence cost ~700 cycles per CTU when it ran inside the phases).  Cell e of: the conv1 output halo (264 x 16 B),
 // the conv2 output halo (272 x 16 B), the input tile halo (260 x 2 B).
+template <bool I8>
 __device__ __forceinline__ int a1_halo_off(int e)
 {
   const int pl = e / 132, k0 = e - pl * 132;
@@ -487,8 +647,9 @@ __device__ __forceinline__ int a1_halo_off(int e)
   if (k0 < 34) { y = 0; x = k0; }
   else if (k0 < 68) { y = 33; x = k0 - 34; }
   else { const int k = k0 - 68; y = 1 + (k >> 1); x = (k & 1) ? 33 : 0; }
-  return R1_OFF + pl * A1_PLANE + y * A1_ROW + ((x & 1) ? 0 : A1_EVEN) + (x >> 1) * 16;
+  return R1_OFF + pl * Lds<I8>::A1_PLANE + y * A1_ROW + ((x & 1) ? 0 : A1_EVEN) + (x >> 1) * 16;
 }
+template <bool I8>
 __device__ __forceinline__ int a2_halo_off(int e)
 {
   const int pl = e / 68, k0 = e - pl * 68;
@@ -496,32 +657,37 @@ __device__ __forceinline__ int a2_halo_off(int e)
   if (k0 < 18) { y = 0; x = k0; }
   else if (k0 < 36) { y = 17; x = k0 - 18; }
   else { const int k = k0 - 36; y = 1 + (k >> 1); x = (k & 1) ? 17 : 0; }
-  return R2_OFF + pl * A2_PLANE + (y * A2_PITCH + x) * 16;
+  return Lds<I8>::R2_OFF + pl * A2_PLANE + (y * A2_PITCH + x) * 16;
 }
+template <bool I8>
 __device__ __forceinline__ int in_halo_off(int e)
 {
   int y, x;
   if (e < 66) { y = 0; x = e; }
   else if (e < 132) { y = 65; x = e - 66; }
   else { const int k = e - 132; y = 1 + (k >> 1); x = (k & 1) ? 65 : 0; }
-  return R2_OFF + 2 * (2 * ((y >> 1) * IN_PITCH + x) + (y & 1));
+  return Lds<I8>::R2_OFF + 2 * (2 * ((y >> 1) * IN_PITCH + x) + (y & 1));
 }
-// a thread's two cells of each halo, packed as (first | second << 16); all offsets are below 64 KiB
+// a thread's two cells of each halo, packed as (first | second << 16); all offsets are below 64 KiB.  The A1 and A2 halos have
+// 132 and 68 cells per plane: with fewer cells than threads (the i8 variant) the surplus threads rewrite the last cell
 struct HaloCells { unsigned a1, a2, in; };
+template <bool I8>
 __device__ __forceinline__ HaloCells halo_cells(int tid)
 {
+  constexpr int N1 = 132 * Lds<I8>::A1_PLANES, N2 = 68 * Lds<I8>::A2_PLANES;
   HaloCells hc;
-  hc.a1 = (unsigned)a1_halo_off(tid) | ((unsigned)a1_halo_off(min(tid + 256, 263)) << 16);
-  hc.a2 = (unsigned)a2_halo_off(tid) | ((unsigned)a2_halo_off(min(tid + 256, 271)) << 16);
-  hc.in = (unsigned)in_halo_off(tid) | ((unsigned)in_halo_off(min(tid + 256, 259)) << 16);
+  hc.a1 = (unsigned)a1_halo_off<I8>(min(tid, N1 - 1)) | ((unsigned)a1_halo_off<I8>(min(tid + 256, N1 - 1)) << 16);
+  hc.a2 = (unsigned)a2_halo_off<I8>(min(tid, N2 - 1)) | ((unsigned)a2_halo_off<I8>(min(tid + 256, N2 - 1)) << 16);
+  hc.in = (unsigned)in_halo_off<I8>(tid) | ((unsigned)in_halo_off<I8>(min(tid + 256, 259)) << 16);
   return hc;
 }
-static_assert(R2_OFF + R2_BYTES <= 65536, "halo offsets are packed into 16 bits");
-// zero the halo of the conv1 output planes (region R1, shared with the conv3 output): 132 positions x 2 planes
+// "activation 0" into the halo of the conv1 output (region R1, shared with the conv3 output): 132 positions per plane
+template <bool I8>
 __device__ __forceinline__ void zero_a1_halo(unsigned char* lds, int tid, unsigned cells)
 {
-  *reinterpret_cast<uint4*>(lds + (cells & 0xFFFF)) = make_uint4(0, 0, 0, 0);
-  if (tid < 264 - 256) *reinterpret_cast<uint4*>(lds + (cells >> 16)) = make_uint4(0, 0, 0, 0);
+  constexpr unsigned Z = Lds<I8>::HALO_FILL;
+  *reinterpret_cast<uint4*>(lds + (cells & 0xFFFF)) = make_uint4(Z, Z, Z, Z);
+  if (tid < 132 * Lds<I8>::A1_PLANES - 256) *reinterpret_cast<uint4*>(lds + (cells >> 16)) = make_uint4(Z, Z, Z, Z);
 }
 
 // in-kernel stamp (diagnostic build only): s_memtime with its own lgkmcnt wait, fenced against reordering
@@ -547,8 +713,9 @@ __device__ __forceinline__ unsigned long long stamp()
 // STAMPS = true is a separate diagnostic instantiation (fhevc_debug_cnn_phase_cycles): wave 0 of every workgroup
 // adds the cycles of each phase (incl. the barrier that ends it) into d_stamps[blockIdx.x * 8 + phase].
 // HAD: also write the per-CTU source Hadamard (d_had), computed from the samples the kernel loads anyway (one pass over the frame)
-template <bool STAMPS, bool HAD>
-__global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, FhevcCnnWeights W,
+// I8: conv2 and conv3 on v_mfma_i32_32x32x32_i8 with the activations as signed bytes (see Lds); the same integers come out
+template <bool STAMPS, bool HAD, bool I8>
+__global__ __launch_bounds__(256, I8 ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn_depth_kernel(FhevcFrames F, FhevcCnnWeights W,
                                                                   uint8_t* __restrict__ d_depth, int32_t* __restrict__ d_had,
                                                                   int32_t* __restrict__ d_logits,
                                                                   uint32_t* __restrict__ d_flags,
@@ -561,7 +728,8 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
   __builtin_amdgcn_s_setreg((1 << 11) | 1, 2);
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const HaloCells hc = halo_cells(tid);  // three registers for the life of the kernel
+  using L = Lds<I8>;
+  const HaloCells hc = halo_cells<I8>(tid);  // three registers for the life of the kernel
   // head bias + QP prior on "split" (class 1): uniform, lives in scalar registers
   const int hb64a = W.bhead[0], hb64b = W.bhead[1] + W.bhead[6 + 0 * 52 + F.qp];
   const int hb32a = W.bhead[2], hb32b = W.bhead[3] + W.bhead[6 + 1 * 52 + F.qp];
@@ -572,27 +740,40 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
   const uint4* frag1p = W.frag + FHEVC_FRAG_CONV1 + lane;
   bf16x8 wA1a = __builtin_bit_cast(bf16x8, frag1p[0]);
   bf16x8 wA1b = __builtin_bit_cast(bf16x8, frag1p[64]);
-  bf16x8 wA2[9];
-#pragma unroll
-  for (int s = 0; s < 9; ++s) wA2[s] = __builtin_bit_cast(bf16x8, W.frag[FHEVC_FRAG_CONV2 + s * 64 + lane]);
-  bf16x8 wA3[18];
+  bf16x8 wA2[9];   // the i8 variant uses 6 of them (2 row pairs x 3 columns of taps) ...
+  bf16x8 wA3[18];  // ... and 9 of these (one per tap): 60 weight registers instead of 108
   const int tile3 = wave & 1;
+  if (I8) {
 #pragma unroll
-  for (int s = 0; s < 18; ++s) wA3[s] = __builtin_bit_cast(bf16x8, W.frag[FHEVC_FRAG_CONV3 + (tile3 * 18 + s) * 64 + lane]);
+    for (int s = 0; s < 6; ++s) wA2[s] = __builtin_bit_cast(bf16x8, W.frag_i8[FHEVC_FRAGI8_CONV2 + s * 64 + lane]);
+#pragma unroll
+    for (int s = 0; s < 9; ++s) wA3[s] = __builtin_bit_cast(bf16x8, W.frag_i8[FHEVC_FRAGI8_CONV3 + (tile3 * 9 + s) * 64 + lane]);
+  } else {
+#pragma unroll
+    for (int s = 0; s < 9; ++s) wA2[s] = __builtin_bit_cast(bf16x8, W.frag[FHEVC_FRAG_CONV2 + s * 64 + lane]);
+#pragma unroll
+    for (int s = 0; s < 18; ++s) wA3[s] = __builtin_bit_cast(bf16x8, W.frag[FHEVC_FRAG_CONV3 + (tile3 * 18 + s) * 64 + lane]);
+  }
+  const int shift2 = W.shift[1], shift3 = W.shift[2];  // (the i8 variant's requant shifts: scalar registers)
+  (void)shift2; (void)shift3;
 
-  float* biasL = reinterpret_cast<float*>(lds + BIAS_OFF);
-  int* logitL = reinterpret_cast<int*>(lds + LOGIT_OFF);
+  float* biasL = reinterpret_cast<float*>(lds + L::BIAS_OFF);
+  int* logitL = reinterpret_cast<int*>(lds + L::LOGIT_OFF);
   if (tid < 112) {  // all pre-scaled (exact: integer * 2^-s); b1 is the accumulator init of conv1, whose weights carry 2^-s1
-    float b = W.bias[tid];
-    b *= (tid < 16 ? W.scale[0] : (tid < 48 ? W.scale[1] : W.scale[2]));
-    biasL[tid] = b;
+    if (I8 && tid >= 16) {  // conv2 / conv3 biases of the i8 variant: int32, + 128 * (sum of the filter's weights)
+      reinterpret_cast<int*>(biasL)[tid] = W.bias_i8[tid];
+    } else {
+      float b = W.bias[tid];
+      b *= (tid < 16 ? W.scale[0] : (tid < 48 ? W.scale[1] : W.scale[2]));
+      biasL[tid] = b;
+    }
   }
   // head weights stay in LDS for the life of the workgroup; the four 16-B chunks of a 64-B row are XOR-swizzled by
   // the row so that the 16 lanes of a ds_read_b128 group (a 4x4 block of positions) hit 16 distinct slots
   for (int i = tid; i < 18432 / 16; i += 256) {
     const int row = i >> 2, c = i & 3;
     const int sw = (i < 2 * 4096 * 2 / 16) ? ((row >> 3) & 3) : ((row >> 2) & 3);  // wh64, wh32: rows of 8; wh16: rows of 4
-    *reinterpret_cast<uint4*>(lds + HEADW_OFF + row * 64 + ((c ^ sw) << 4)) = reinterpret_cast<const uint4*>(W.whead)[i];
+    *reinterpret_cast<uint4*>(lds + L::HEADW_OFF + row * 64 + ((c ^ sw) << 4)) = reinterpret_cast<const uint4*>(W.whead)[i];
   }
 
   const int band_rows = F.row_end - F.row_begin;
@@ -623,8 +804,8 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
   Prefetched pre = prefetch_ctu<HAD>(F, vblock < total, pos, ld_row, ld_seg);
   int had_set = 0;  // which of the two sets of per-wave Hadamard sums belongs to the CTU in flight
   if (vblock < total) {  // prologue: first CTU of this workgroup
-    stage_ctu(lds, pre, F, pos, tid, ld_row, ld_seg, shift_in, hc.in);
-    zero_a1_halo(lds, tid, hc.a1);
+    stage_ctu(lds, L::R2_OFF, pre, F, pos, tid, ld_row, ld_seg, shift_in, hc.in);
+    zero_a1_halo<I8>(lds, tid, hc.a1);
     if (HAD) {
       const int hs = F.sample_bytes == 2 ? wave_src_hadamard<2>(pre, lane) : wave_src_hadamard<1>(pre, lane);
       if (lane == 0) logitL[56 + wave] = hs;
@@ -641,7 +822,7 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
     FHEVC_PHASE_IDS                                                                                      \
     early_b0 = *reinterpret_cast<const float4*>(biasL + 8 * h);                                          \
     early_b1 = *reinterpret_cast<const float4*>(biasL + 8 * h + 4);                                      \
-    const unsigned char* p = lds + R2_OFF + (2 * r + 2 * h) * 4 + wave * (IN_PITCH * 4);                 \
+    const unsigned char* p = lds + L::R2_OFF + (2 * r + 2 * h) * 4 + wave * (IN_PITCH * 4);              \
     const uint2 lo = *reinterpret_cast<const uint2*>(p);                                                 \
     const uint2 hi = *reinterpret_cast<const uint2*>(p + IN_PITCH * 4);                                  \
     early_bq = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));                           \
@@ -662,7 +843,7 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
       // unit = one pooled row of 32 positions (picture rows 2yp, 2yp+1, all 64 columns); lane (n, h): pooled column n,
       // K slots = the 4x4 input window of the 2x2 pre-pool outputs: lanes h=0 hold window columns 0-1, h=1 columns 2-3,
       // each column as two row-pair dwords -> the fragment is two ds_read_b64, all 16 K slots carry data
-      const unsigned char* inb = lds + R2_OFF + (2 * r + 2 * h) * 4;
+      const unsigned char* inb = lds + L::R2_OFF + (2 * r + 2 * h) * 4;
       f32x16 bias1;  // reg i -> channel (i&3) + 4*((i>>2)&1) + 8h, the same for both pre-pool rows and both MFMAs
       {
         const float4 b0 = early_b0, b1 = early_b1;  // read from LDS before the previous CTU's depth phase (or by the prologue)
@@ -678,7 +859,7 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
       };
       // this wave's units: pooled rows wave, wave + 4, ...: both addresses advance by constants (no per-unit index arithmetic)
       const unsigned char* fp = inb + wave * (IN_PITCH * 4);
-      unsigned char* dp = lds + R1_OFF + h * A1_PLANE + (wave + 1) * A1_ROW + (((r + 1) & 1) ? 0 : A1_EVEN) + ((r + 1) >> 1) * 16;  // column r (halo +1)
+      unsigned char* dp = lds + R1_OFF + (I8 ? 8 * h : h * A1_PLANE) + (wave + 1) * A1_ROW + (((r + 1) & 1) ? 0 : A1_EVEN) + ((r + 1) >> 1) * 16;  // column r (halo +1)
       bf16x8 bq = early_bq;  // = frag1(fp), in flight since before the previous CTU's depth phase
 #pragma unroll 2
       for (int i = 0; i < 8; ++i) {
@@ -686,7 +867,8 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
         const f32x16 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA1b, bq, bias1, 0, 0, 0);
         fp += 4 * IN_PITCH * 4;
         bq = frag1(fp);  // next unit's fragment travels during the epilogue (the last one is redundant: it reads past the tile, inside R2)
-        conv1_store(acc0, acc1, dp);
+        if (I8) conv1_store_i8(acc0, acc1, dp);
+        else conv1_store(acc0, acc1, dp);
         dp += 4 * A1_ROW;
       }
     }
@@ -694,7 +876,40 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
     FHEVC_STAMP(1)
 
     // ================= P2: conv2 (16 -> 32), K = 9 taps x 16 ch, fused maxpool + requant =================
-    {
+    if constexpr (I8) {
+      FHEVC_PHASE_IDS
+      constexpr unsigned Z = L::HALO_FILL;  // the input tile is dead: "activation 0" into the A2 halo (68 positions x 2 planes)
+      *reinterpret_cast<uint4*>(lds + (hc.a2 & 0xFFFF)) = make_uint4(Z, Z, Z, Z);
+      // lane -> pooled position as in the 16-bit form below; the lane half picks the input row of a tap pair (ky = 2 q + h)
+      const int q = r >> 2;
+      const int pr = (q ^ (q >> 1) ^ (q >> 2)) & 1, pc = ((r >> 3) << 2) | (r & 3);
+      const unsigned char* a1p = lds + R1_OFF + (2 * pr + h) * A1_ROW + pc * 16;
+      unsigned char* a2dst = lds + L::R2_OFF + ((pr + 1) * A2_PITCH + pc + 1) * 16 + 4 * h;  // pooled row pr of unit 0, plane 0, bytes 4h ..
+      const int u0 = wave, u1 = wave + 4;
+      const unsigned char* h00 = a1p + (4 * u0) * A1_ROW;  // half-chains: (u0, dy 0), (u0, dy 1), (u1, dy 0), (u1, dy 1)
+      const unsigned char* h10 = a1p + (4 * u1) * A1_ROW;
+      const int* b2t = reinterpret_cast<const int*>(biasL) + 16;
+      i32x16 t0, t1, a0, a1;
+      bf16x8 ring[RING];
+      conv2_half_i8<true, false>(h00, h00 + A1_ROW, wA2, ring, b2t, h, t0, t1);
+      __builtin_amdgcn_sched_group_barrier(0x100, RING + 4, 0);  // bias tile + the ring's first fragments go out together
+      sched_chain12_i8<0>();
+      conv2_half_i8<false, false>(h00 + A1_ROW, h10, wA2, ring, b2t, h, a0, a1);
+      pool_h_i8(t0, t1);
+      sched_chain12_i8<2>();
+      __builtin_amdgcn_sched_barrier(0);
+      pool_v_i8(t0, a0, a1);
+      __builtin_amdgcn_sched_barrier(0);
+      conv2_half_i8<false, false>(h10, h10 + A1_ROW, wA2, ring, b2t, h, t1, a0);
+      conv2_requant_store_i8(t0, a2dst + (2 * u0) * A2_PITCH * 16, shift2);
+      sched_chain12_i8<5>();
+      conv2_half_i8<false, true>(h10 + A1_ROW, h10 + A1_ROW, wA2, ring, b2t, h, a1, t0);
+      pool_h_i8(t1, a0);
+      sched_chain12_i8<2>();
+      __builtin_amdgcn_sched_barrier(0);
+      pool_v_i8(t1, a1, t0);
+      conv2_requant_store_i8(t1, a2dst + (2 * u1) * A2_PITCH * 16, shift2);
+    } else {
       FHEVC_PHASE_IDS
       // the input tile is dead: zero the A2 halo (68 positions x 4 planes) while conv2 fills the interior
       *reinterpret_cast<uint4*>(lds + (hc.a2 & 0xFFFF)) = make_uint4(0, 0, 0, 0);
@@ -707,7 +922,7 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
       const int pr = (q ^ (q >> 1) ^ (q >> 2)) & 1, pc = ((r >> 3) << 2) | (r & 3);
       // unit u = pooled rows 2u, 2u+1 = pre-pool rows 4u .. 4u+3 (input halo rows 4u .. 4u+5); this lane: input row 4u + 2pr + dy + ky
       const unsigned char* a1p = lds + R1_OFF + h * A1_PLANE + (2 * pr) * A1_ROW + pc * 16;
-      unsigned char* a2dst = lds + R2_OFF + ((pr + 1) * A2_PITCH + pc + 1) * 16 + 8 * h;  // pooled row pr of unit 0, plane 0
+      unsigned char* a2dst = lds + L::R2_OFF + ((pr + 1) * A2_PITCH + pc + 1) * 16 + 8 * h;  // pooled row pr of unit 0, plane 0
       const int u0 = wave, u1 = wave + 4;
       const unsigned char* h00 = a1p + (4 * u0) * A1_ROW;  // half-chains: (u0, dy 0), (u0, dy 1), (u1, dy 0), (u1, dy 1)
       const unsigned char* h10 = a1p + (4 * u1) * A1_ROW;
@@ -738,11 +953,31 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
 
     // ================= P3: conv3 (32 -> 64), K = 9 taps x 32 ch, requant to u8 =================
     pre = prefetch_ctu<HAD>(F, work + (int)gridDim.x < total, next, ld_row, ld_seg);  // next CTU's samples travel under conv3 and the heads
-    {
+    if constexpr (I8) {
+      FHEVC_PHASE_IDS
+      const int x = lane & 15, rs = (lane >> 4) & 1;  // B column n = lane & 31: row rs of the pair, position x; lane half h = activation plane
+      const int y0 = 2 * (wave >> 1);                 // this wave's row pairs: y0 + 4 k + {0, 1}
+      const unsigned char* a2 = lds + L::R2_OFF + h * A2_PLANE + ((y0 + rs) * A2_PITCH + x) * 16;
+      const int psw = (x >> 2) & 3;                   // chunk swizzle of the a3 rows (see the 16-bit form below)
+      unsigned char* a3dst = lds + A3_OFF + ((y0 + rs) * 16 + x) * 64 + 4 * h;
+      const int* b3p = reinterpret_cast<const int*>(biasL) + 48 + 32 * tile3;
+      bf16x8 ring[RING3];
+      i32x16 p0, p1, q0, q1;
+      conv3_pairs_i8<0>(a2, wA3, ring, b3p, h, p0, p1);
+      __builtin_amdgcn_sched_group_barrier(0x100, RING3 + 4, 0);
+      sched_pairs18_i8<0>();
+      conv3_pairs_i8<1>(a2, wA3, ring, b3p, h, q0, q1);
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      conv3_store_i8(p0, a3dst + 0 * 4096, tile3, psw, shift3);
+      conv3_store_i8(p1, a3dst + 1 * 4096, tile3, psw, shift3);
+      sched_pairs18_i8<4>();
+      conv3_store_i8(q0, a3dst + 2 * 4096, tile3, psw, shift3);
+      conv3_store_i8(q1, a3dst + 3 * 4096, tile3, psw, shift3);
+    } else {
       FHEVC_PHASE_IDS
       const int x = lane & 15, kg = lane >> 4;  // B column = position x of the row, K group = activation plane kg; D rows 4 kg ..
       const int y0 = 2 * (wave >> 1);           // this wave's rows: y0 + {0, 1, 4, 5, 8, 9, 12, 13} (+ {2, 3, ...} for the next wave pair)
-      const unsigned char* a2 = lds + R2_OFF + kg * A2_PLANE + (y0 * A2_PITCH + x) * 16;
+      const unsigned char* a2 = lds + L::R2_OFF + kg * A2_PLANE + (y0 * A2_PITCH + x) * 16;
       // a3 row of a position p = 64 B = four 16-B chunks; chunk c is stored at c ^ ((p >> 2) & 3) so that the 16
       // lanes of a ds_read_b128 group in the heads (consecutive positions, same logical chunk) hit 16 distinct slots
       const int psw = (x >> 2) & 3;
@@ -794,6 +1029,12 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
       asm volatile("" : "+v"(fp));  // opaque address: keeps the re-fetch inside the loop
       wA1a = __builtin_bit_cast(bf16x8, fp[0]);
       wA1b = __builtin_bit_cast(bf16x8, fp[64]);
+      if (I8) {  // the i8 variant runs three workgroups per CU on 168 registers: conv2's fragments are dead during conv3 and come back here too
+        const uint4* f2 = W.frag_i8 + FHEVC_FRAGI8_CONV2 + lane;
+        asm volatile("" : "+v"(f2));
+#pragma unroll
+        for (int s = 0; s < 6; ++s) wA2[s] = __builtin_bit_cast(bf16x8, f2[s * 64]);
+      }
     }
     {
       FHEVC_PHASE_IDS
@@ -803,9 +1044,9 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
       const int x = (q & 1) * 8 + (blk & 1) * 4 + (lane & 3);
       const unsigned char* arow = lds + A3_OFF + (y * 16 + x) * 64;
       const int psw = (x >> 2) & 3;  // chunk swizzle of this position (see P3)
-      const unsigned char* w16 = lds + HEADW_OFF + HEAD16_OFF + ((y & 3) * 4 + (x & 3)) * 64;
-      const unsigned char* w32 = lds + HEADW_OFF + HEAD32_OFF + ((y & 7) * 8 + (x & 7)) * 64;
-      const unsigned char* w64 = lds + HEADW_OFF + HEAD64_OFF + ((y >> 1) * 8 + (x >> 1)) * 64;  // 2x2 sum pool
+      const unsigned char* w16 = lds + L::HEADW_OFF + HEAD16_OFF + ((y & 3) * 4 + (x & 3)) * 64;
+      const unsigned char* w32 = lds + L::HEADW_OFF + HEAD32_OFF + ((y & 7) * 8 + (x & 7)) * 64;
+      const unsigned char* w64 = lds + L::HEADW_OFF + HEAD64_OFF + ((y >> 1) * 8 + (x >> 1)) * 64;  // 2x2 sum pool
       const int sw16 = y & 3, sw32 = y & 3, sw64 = (y >> 1) & 3;  // (row >> 2) & 3, (row >> 3) & 3 of the weight rows (both classes)
       int s16a = 0, s16b = 0, s32a = 0, s32b = 0, s64a = 0, s64b = 0;
 #pragma unroll
@@ -845,7 +1086,7 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
     }
     // the A2/input region (R2) is free since the P3 barrier: stage the next CTU now, its P1 needs no extra barrier
     FHEVC_STAMP(6)  // heads only
-    if (work + (int)gridDim.x < total) stage_ctu(lds, pre, F, next, tid, ld_row, ld_seg, shift_in, hc.in);
+    if (work + (int)gridDim.x < total) stage_ctu(lds, L::R2_OFF, pre, F, next, tid, ld_row, ld_seg, shift_in, hc.in);
     FHEVC_STAMP(7)  // staging of the next CTU; slot 4 below is then the wait at the barrier
     __syncthreads();
     FHEVC_STAMP(4)
@@ -905,7 +1146,7 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_kernel(FhevcFrames F, 
         const unsigned long long m = __ballot(bit && k < 21);
         if (lane == 0) d_flags[o] = (uint32_t)(m & 0x1FFFFFu);
       }
-      zero_a1_halo(lds, tid, hc.a1);  // R1 held the conv3 output until the P4 barrier; conv1 of the next CTU needs a zero halo
+      zero_a1_halo<I8>(lds, tid, hc.a1);  // R1 held the conv3 output until the P4 barrier; conv1 of the next CTU needs a zero halo
     }
     FHEVC_STAMP(5)
     had_set ^= 1;
@@ -961,9 +1202,11 @@ hipError_t fhevc_launch_expand_flags(const FhevcFrames& fr, const uint32_t* d_fl
 // > 64 KiB of dynamic LDS needs an opt-in per function AND per device: fhevc_create calls this with its device current
 hipError_t fhevc_cnn_prepare_device()
 {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-  if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_kernel<false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, Lds<false>::LDS_BYTES);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_kernel<false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, Lds<false>::LDS_BYTES);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_kernel<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, Lds<true>::LDS_BYTES);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_kernel<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, Lds<true>::LDS_BYTES);
+  return e;
 }
 
 // d_had != nullptr: the fused source Hadamard (only where fhevc_cnn_can_fuse_hadamard says so)
@@ -976,19 +1219,39 @@ bool fhevc_cnn_can_fuse_hadamard(const FhevcFrames& fr)
          ((size_t)fr.stride * sb) % 16 == 0 && ((size_t)fr.frame_stride * sb) % 16 == 0;
 }
 
+namespace {
+template <bool STAMPS, bool HAD, bool I8>
+void launch_depth_kernel(int grid, hipStream_t stream, const FhevcFrames& fr, const FhevcCnnWeights& w, uint8_t* d_depth, int32_t* d_had, int32_t* d_logits,
+                         uint32_t* d_flags, unsigned long long* d_stamps, uint8_t* d_depth_max, int margin_split, int margin_stop)
+{
+  hipLaunchKernelGGL((fhevc_cnn_depth_kernel<STAMPS, HAD, I8>), dim3(grid), dim3(256), Lds<I8>::LDS_BYTES, stream, fr, w, d_depth, d_had, d_logits,
+                     d_flags, d_stamps, d_depth_max, margin_split, margin_stop);
+}
+}  // namespace
+
+// workgroups per CU of the persistent grid (FHEVC_CNN_WG_PER_CU overrides: a tuning knob)
+static int cnn_wg_per_cu(const FhevcCnnWeights& w)
+{
+  const char* e = getenv("FHEVC_CNN_WG_PER_CU");
+  if (e && e[0] >= '1' && e[0] <= '4') return e[0] - '0';
+  (void)w;
+  return 2;
+}
+
 hipError_t fhevc_launch_cnn(const FhevcFrames& fr, const FhevcCnnWeights& w, uint8_t* d_depth, int32_t* d_had, int32_t* d_logits,
                             uint32_t* d_flags, uint8_t* d_depth_max, int margin_split, int margin_stop, int num_cus, hipStream_t stream)
 {
   const long long total = (long long)(fr.row_end - fr.row_begin) * fr.ctus_x * fr.num_frames;
   if (total <= 0) return hipSuccess;
-  int grid = 2 * num_cus;
+  int grid = cnn_wg_per_cu(w) * num_cus;
   if (total < grid) grid = (int)total;
-  if (d_had != nullptr)
-    hipLaunchKernelGGL((fhevc_cnn_depth_kernel<false, true>), dim3(grid), dim3(256), LDS_BYTES, stream, fr, w, d_depth, d_had, d_logits,
-                       d_flags, (unsigned long long*)nullptr, d_depth_max, margin_split, margin_stop);
-  else
-    hipLaunchKernelGGL((fhevc_cnn_depth_kernel<false, false>), dim3(grid), dim3(256), LDS_BYTES, stream, fr, w, d_depth, (int32_t*)nullptr, d_logits,
-                       d_flags, (unsigned long long*)nullptr, d_depth_max, margin_split, margin_stop);
+  if (w.i8) {
+    if (d_had != nullptr) launch_depth_kernel<false, true, true>(grid, stream, fr, w, d_depth, d_had, d_logits, d_flags, nullptr, d_depth_max, margin_split, margin_stop);
+    else launch_depth_kernel<false, false, true>(grid, stream, fr, w, d_depth, nullptr, d_logits, d_flags, nullptr, d_depth_max, margin_split, margin_stop);
+  } else {
+    if (d_had != nullptr) launch_depth_kernel<false, true, false>(grid, stream, fr, w, d_depth, d_had, d_logits, d_flags, nullptr, d_depth_max, margin_split, margin_stop);
+    else launch_depth_kernel<false, false, false>(grid, stream, fr, w, d_depth, nullptr, d_logits, d_flags, nullptr, d_depth_max, margin_split, margin_stop);
+  }
   return hipGetLastError();
 }
 
@@ -999,14 +1262,14 @@ hipError_t fhevc_launch_cnn_stamped(const FhevcFrames& fr, const FhevcCnnWeights
   const long long total = (long long)(fr.row_end - fr.row_begin) * fr.ctus_x * fr.num_frames;
   // FHEVC_DEBUG_WG_PER_CU=1: one workgroup per CU, i.e. the phase times without a second workgroup on the same SIMDs
   const char* per_cu = getenv("FHEVC_DEBUG_WG_PER_CU");
-  int grid = ((per_cu && per_cu[0] == '1') ? 1 : 2) * num_cus;
+  int grid = ((per_cu && per_cu[0] >= '1' && per_cu[0] <= '4') ? per_cu[0] - '0' : cnn_wg_per_cu(w)) * num_cus;
   if (total < grid) grid = (int)total;
   *grid_out = grid;
   if (total <= 0) return hipSuccess;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_kernel<true, false>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  hipError_t e = w.i8 ? hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_kernel<true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, Lds<true>::LDS_BYTES)
+                      : hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_kernel<true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, Lds<false>::LDS_BYTES);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((fhevc_cnn_depth_kernel<true, false>), dim3(grid), dim3(256), LDS_BYTES, stream, fr, w, d_depth, (int32_t*)nullptr, (int32_t*)nullptr,
-                     (uint32_t*)nullptr, d_stamps, (uint8_t*)nullptr, 0, 0);
+  if (w.i8) launch_depth_kernel<true, false, true>(grid, stream, fr, w, d_depth, nullptr, nullptr, nullptr, d_stamps, nullptr, 0, 0);
+  else launch_depth_kernel<true, false, false>(grid, stream, fr, w, d_depth, nullptr, nullptr, nullptr, d_stamps, nullptr, 0, 0);
   return hipGetLastError();
 }
