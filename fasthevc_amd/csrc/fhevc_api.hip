@@ -29,6 +29,7 @@ struct fhevc_ctx {
   uint4* d_frag = nullptr; float* d_bias = nullptr; uint8_t* d_whead = nullptr; int32_t* d_bhead = nullptr;
   uint4* d_frag_i8 = nullptr; int32_t* d_bias_i8 = nullptr;  // the i8 variant of conv2 / conv3 (k_cnn.hip)
   int shift[3] = { 0, 0, 0 };
+  int requant_mode[3] = { 0, 0, 0 };
   bool cnn_i8 = false;                                        // FHEVC_CNN_ARITH=i8 at fhevc_create
   float scale[3] = { 1, 1, 1 };
   // staging for the host-buffer entry points
@@ -195,15 +196,24 @@ int build_weight_image(fhevc_ctx* c, const BlobView& b)
   // its biases: the activations travel as a - 128, so sum w a = sum w (a - 128) + 128 sum w (over ALL taps: the halo holds
   // a - 128 = -128, "activation 0", and meets the same correction)
   std::vector<int32_t> bias8(112, 0);
+  long long bound[3] = { 0, 0, 0 };  // largest |accumulator| any input can produce: |b'| + 128 * sum |w|
   for (int oc = 0; oc < 32; ++oc) {
-    int sw = 0;
-    for (int i = 0; i < 16 * 9; ++i) sw += b.w2[oc * 144 + i];
+    int sw = 0, sa = 0;
+    for (int i = 0; i < 16 * 9; ++i) { sw += b.w2[oc * 144 + i]; sa += std::abs((int)b.w2[oc * 144 + i]); }
     bias8[16 + oc] = rd32(b.b2, oc) + 128 * sw;
+    bound[1] = std::max(bound[1], (long long)std::abs(bias8[16 + oc]) + 128LL * sa);
   }
   for (int oc = 0; oc < 64; ++oc) {
-    int sw = 0;
-    for (int i = 0; i < 32 * 9; ++i) sw += b.w3[oc * 288 + i];
+    int sw = 0, sa = 0;
+    for (int i = 0; i < 32 * 9; ++i) { sw += b.w3[oc * 288 + i]; sa += std::abs((int)b.w3[oc * 288 + i]); }
     bias8[48 + oc] = rd32(b.b3, oc) + 128 * sw;
+    bound[2] = std::max(bound[2], (long long)std::abs(bias8[48 + oc]) + 128LL * sa);
+  }
+  // the requant's form per layer (k_cnn.hip: requant4_i8); FHEVC_CNN_REQUANT=general keeps the general one (A/B, tests)
+  const char* rq = std::getenv("FHEVC_CNN_REQUANT");
+  for (int l = 1; l < 3; ++l) {
+    const int sh = rd32(b.shift, l);
+    c->requant_mode[l] = (rq && std::strcmp(rq, "general") == 0) ? 0 : (sh == 8 && bound[l] < (1LL << 23)) ? 2 : (sh <= 7 ? 1 : 0);
   }
   std::vector<float> bias(112);
   for (int i = 0; i < 16; ++i) {  // the kernel feeds conv1 the samples x, not x - 128: sum w (x - 128) + b = sum w x + (b - 128 sum w)
@@ -257,6 +267,7 @@ FhevcCnnWeights cnn_weights(const fhevc_ctx* c)
   w.scale[0] = c->scale[0]; w.scale[1] = c->scale[1]; w.scale[2] = c->scale[2];
   w.frag_i8 = c->d_frag_i8; w.bias_i8 = c->d_bias_i8;
   w.shift[0] = c->shift[0]; w.shift[1] = c->shift[1]; w.shift[2] = c->shift[2];
+  w.requant_mode[0] = 0; w.requant_mode[1] = c->requant_mode[1]; w.requant_mode[2] = c->requant_mode[2];
   w.i8 = c->cnn_i8 ? 1 : 0;
   return w;
 }

@@ -44,6 +44,7 @@ struct FhevcCnnWeights {
   const uint4* frag_i8;
   const int32_t* bias_i8;
   int shift[3];
+  int requant_mode[3];       // per layer: 0 general, 1 shift <= 7 (packed 16-bit shift), 2 shift == 8 and |accumulator| < 2^23 (byte gather)
   int i8;                    // 1: run that variant
 };
 

@@ -234,9 +234,25 @@ __device__ __forceinline__ void conv3_store(const f32x4& acc0, const f32x4& acc1
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 typedef __attribute__((ext_vector_type(16))) int i32x16;
 typedef __attribute__((ext_vector_type(2))) short s16x2_t;
-__device__ __forceinline__ unsigned requant4_i8(int a, int b, int c, int d, int shift)
+// Two shorter forms where the numbers allow (mode, uniform per layer, chosen by the host: build_weight_image):
+//   mode 1 (shift <= 7): saturate to int16 FIRST, then one packed 16-bit shift per pair (sat16(x) >> s and x >> s clamp to the same
+//           byte: 32767 >> 7 = 255) -- 7 instructions;
+//   mode 2 (shift == 8 and every accumulator provably inside 24 bits): bytes 1, 2 of x ARE x >> 8 as an int16, one v_perm_b32 per
+//           pair -- 5 instructions
+__device__ __forceinline__ unsigned requant4_i8(int a, int b, int c, int d, int shift, int mode)
 {
-  const s16x2_t p0 = __builtin_amdgcn_cvt_pk_i16(a >> shift, b >> shift), p1 = __builtin_amdgcn_cvt_pk_i16(c >> shift, d >> shift);
+  s16x2_t p0, p1;
+  if (mode == 2) {
+    p0 = __builtin_bit_cast(s16x2_t, __builtin_amdgcn_perm((unsigned)b, (unsigned)a, 0x06050201u));
+    p1 = __builtin_bit_cast(s16x2_t, __builtin_amdgcn_perm((unsigned)d, (unsigned)c, 0x06050201u));
+  } else if (mode == 1) {
+    const s16x2_t sh = { (short)shift, (short)shift };
+    p0 = __builtin_amdgcn_cvt_pk_i16(a, b) >> sh;
+    p1 = __builtin_amdgcn_cvt_pk_i16(c, d) >> sh;
+  } else {
+    p0 = __builtin_amdgcn_cvt_pk_i16(a >> shift, b >> shift);
+    p1 = __builtin_amdgcn_cvt_pk_i16(c >> shift, d >> shift);
+  }
   unsigned r;
   asm("v_sat_pk_u8_i16_sdwa %0, %1 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD" : "=v"(r) : "v"(p0));
   asm("v_sat_pk_u8_i16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(r) : "v"(p1));
@@ -272,20 +288,22 @@ __device__ __forceinline__ void pool_v_i8(i32x16& top, const i32x16& acc0, const
   for (int k = 0; k < 16; ++k) top[k] = max(max(top[k], acc0[k]), acc1[k]);
 }
 // reg i -> channel (i & 3) + 8 g + 4 h, g = i >> 2: plane g >> 1, bytes 8 (g & 1) + 4 h ..; dst = the lane's position in plane 0 + 4 h
-__device__ __forceinline__ void conv2_requant_store_i8(const i32x16& m, unsigned char* dst, int shift)
+template <int MODE>
+__device__ __forceinline__ void conv2_requant_store_i8m(const i32x16& m, unsigned char* dst, int shift)
 {
 #pragma unroll
   for (int g = 0; g < 4; ++g)
-    *reinterpret_cast<unsigned*>(dst + (g >> 1) * A2_PLANE + 8 * (g & 1)) = requant4_i8(m[4 * g], m[4 * g + 1], m[4 * g + 2], m[4 * g + 3], shift);
+    *reinterpret_cast<unsigned*>(dst + (g >> 1) * A2_PLANE + 8 * (g & 1)) = requant4_i8(m[4 * g], m[4 * g + 1], m[4 * g + 2], m[4 * g + 3], shift, MODE);
 }
 // conv3: channel 32 tile + 8 g + 4 h + (i & 3) of a position lives in logical 16-B chunk 2 tile + (g >> 1), bytes 8 (g & 1) + 4 h ..;
 // dst = the position's 64-byte row + 4 h; psw = chunk swizzle of the position
-__device__ __forceinline__ void conv3_store_i8(const i32x16& acc, unsigned char* dst, int tile, int psw, int shift)
+template <int MODE>
+__device__ __forceinline__ void conv3_store_i8m(const i32x16& acc, unsigned char* dst, int tile, int psw, int shift)
 {
 #pragma unroll
   for (int g = 0; g < 4; ++g)
     *reinterpret_cast<unsigned*>(dst + (((2 * tile + (g >> 1)) ^ psw) << 4) + 8 * (g & 1)) =
-        requant4_i8(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3], shift);
+        requant4_i8(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3], shift, MODE);
 }
 
 // ---- MFMA chains with a register ring of B fragments ---------------------------------------------------------
@@ -421,13 +439,15 @@ __device__ __forceinline__ void sched_chain12_i8()
 #undef FHEVC_G
 }
 // conv3: one MFMA = one tap x all 32 input channels (lane half = activation plane) x the wave's 32 output channels x TWO output
-// rows (B column n: row n >> 4, x = n & 15): 9 MFMAs and 9 ds_read_b128 per row pair, 4 row pairs per wave.  Two row pairs run
-// interleaved (two independent accumulators: a lone chain of 9 would wait for each MFMA's result): super-chain S = row pairs
-// 2S, 2S+1, fragment g = 18 S + 2 tap + (pair & 1)
+// rows (B column n: x = n & 15 of row y + 8 (n >> 4): rows EIGHT apart are 8 * 288 B = 9 * 256 B apart, so the 16-lane groups of
+// a ds_read_b128 -- {0-3, 12-15 of one row} + {4-11 of the other} -- tile a 256-byte bank row): 9 MFMAs and 9 ds_read_b128 per
+// row pair, 4 row pairs per wave (rows y0 + {0, 1, 4, 5} + {0, 8}).  Two row pairs run interleaved (two independent accumulators: a
+// lone chain of 9 would wait for each MFMA's result): super-chain S = row pairs 2S, 2S+1, fragment g = 18 S + 2 tap + (pair & 1)
+__device__ __forceinline__ constexpr int conv3_pair_row_i8(int k) { return 4 * (k >> 1) + (k & 1); }
 __device__ __forceinline__ constexpr int conv3_frag_off_i8(int g)
 {
   const int k = 2 * (g / 18) + (g & 1), t = (g % 18) / 2;
-  return ((4 * k + t / 3) * A2_PITCH + t % 3) * 16;
+  return ((conv3_pair_row_i8(k) + t / 3) * A2_PITCH + t % 3) * 16;
 }
 template <int S>
 __device__ __forceinline__ void conv3_pairs_i8(const unsigned char* base, const bf16x8 (&wA3)[18], bf16x8 (&ring)[RING3], const int* bias, int h,
@@ -713,9 +733,10 @@ __device__ __forceinline__ unsigned long long stamp()
 // STAMPS = true is a separate diagnostic instantiation (fhevc_debug_cnn_phase_cycles): wave 0 of every workgroup
 // adds the cycles of each phase (incl. the barrier that ends it) into d_stamps[blockIdx.x * 8 + phase].
 // HAD: also write the per-CTU source Hadamard (d_had), computed from the samples the kernel loads anyway (one pass over the frame)
-// I8: conv2 and conv3 on v_mfma_i32_32x32x32_i8 with the activations as signed bytes (see Lds); the same integers come out
-template <bool STAMPS, bool HAD, bool I8>
-__global__ __launch_bounds__(256, I8 ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn_depth_kernel(FhevcFrames F, FhevcCnnWeights W,
+// I8: conv2 and conv3 on v_mfma_i32_32x32x32_i8 with the activations as signed bytes (see Lds); the same integers come out.
+// I8 = 2: the same with the short requant forms (requant4_i8: conv2 mode 1, conv3 mode 2), where the host found them valid
+template <bool STAMPS, bool HAD, int ARITH>
+__global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn_depth_kernel(FhevcFrames F, FhevcCnnWeights W,
                                                                   uint8_t* __restrict__ d_depth, int32_t* __restrict__ d_had,
                                                                   int32_t* __restrict__ d_logits,
                                                                   uint32_t* __restrict__ d_flags,
@@ -728,6 +749,8 @@ __global__ __launch_bounds__(256, I8 ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn_de
   __builtin_amdgcn_s_setreg((1 << 11) | 1, 2);
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
+  constexpr bool I8 = ARITH != 0, FASTRQ = ARITH == 2;
+  (void)FASTRQ;
   using L = Lds<I8>;
   const HaloCells hc = halo_cells<I8>(tid);  // three registers for the life of the kernel
   // head bias + QP prior on "split" (class 1): uniform, lives in scalar registers
@@ -754,7 +777,7 @@ __global__ __launch_bounds__(256, I8 ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn_de
 #pragma unroll
     for (int s = 0; s < 18; ++s) wA3[s] = __builtin_bit_cast(bf16x8, W.frag[FHEVC_FRAG_CONV3 + (tile3 * 18 + s) * 64 + lane]);
   }
-  const int shift2 = W.shift[1], shift3 = W.shift[2];  // (the i8 variant's requant shifts: scalar registers)
+  const int shift2 = W.shift[1], shift3 = W.shift[2];  // (the i8 variant's requant shifts and forms: scalar registers)
   (void)shift2; (void)shift3;
 
   float* biasL = reinterpret_cast<float*>(lds + L::BIAS_OFF);
@@ -901,14 +924,14 @@ __global__ __launch_bounds__(256, I8 ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn_de
       pool_v_i8(t0, a0, a1);
       __builtin_amdgcn_sched_barrier(0);
       conv2_half_i8<false, false>(h10, h10 + A1_ROW, wA2, ring, b2t, h, t1, a0);
-      conv2_requant_store_i8(t0, a2dst + (2 * u0) * A2_PITCH * 16, shift2);
+      conv2_requant_store_i8m<FASTRQ ? 1 : 0>(t0, a2dst + (2 * u0) * A2_PITCH * 16, shift2);
       sched_chain12_i8<5>();
       conv2_half_i8<false, true>(h10 + A1_ROW, h10 + A1_ROW, wA2, ring, b2t, h, a1, t0);
       pool_h_i8(t1, a0);
       sched_chain12_i8<2>();
       __builtin_amdgcn_sched_barrier(0);
       pool_v_i8(t1, a1, t0);
-      conv2_requant_store_i8(t1, a2dst + (2 * u1) * A2_PITCH * 16, shift2);
+      conv2_requant_store_i8m<FASTRQ ? 1 : 0>(t1, a2dst + (2 * u1) * A2_PITCH * 16, shift2);
     } else {
       FHEVC_PHASE_IDS
       // the input tile is dead: zero the A2 halo (68 positions x 4 planes) while conv2 fills the interior
@@ -955,11 +978,11 @@ __global__ __launch_bounds__(256, I8 ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn_de
     pre = prefetch_ctu<HAD>(F, work + (int)gridDim.x < total, next, ld_row, ld_seg);  // next CTU's samples travel under conv3 and the heads
     if constexpr (I8) {
       FHEVC_PHASE_IDS
-      const int x = lane & 15, rs = (lane >> 4) & 1;  // B column n = lane & 31: row rs of the pair, position x; lane half h = activation plane
-      const int y0 = 2 * (wave >> 1);                 // this wave's row pairs: y0 + 4 k + {0, 1}
-      const unsigned char* a2 = lds + L::R2_OFF + h * A2_PLANE + ((y0 + rs) * A2_PITCH + x) * 16;
+      const int x = lane & 15, rs = (lane >> 4) & 1;  // B column n = lane & 31: row 8 rs of the pair, position x; lane half h = activation plane
+      const int y0 = 2 * (wave >> 1);                 // this wave's row pairs: y0 + {0, 1, 4, 5} + {0, 8}
+      const unsigned char* a2 = lds + L::R2_OFF + h * A2_PLANE + ((y0 + 8 * rs) * A2_PITCH + x) * 16;
       const int psw = (x >> 2) & 3;                   // chunk swizzle of the a3 rows (see the 16-bit form below)
-      unsigned char* a3dst = lds + A3_OFF + ((y0 + rs) * 16 + x) * 64 + 4 * h;
+      unsigned char* a3dst = lds + A3_OFF + ((y0 + 8 * rs) * 16 + x) * 64 + 4 * h;
       const int* b3p = reinterpret_cast<const int*>(biasL) + 48 + 32 * tile3;
       bf16x8 ring[RING3];
       i32x16 p0, p1, q0, q1;
@@ -968,11 +991,11 @@ __global__ __launch_bounds__(256, I8 ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn_de
       sched_pairs18_i8<0>();
       conv3_pairs_i8<1>(a2, wA3, ring, b3p, h, q0, q1);
       __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-      conv3_store_i8(p0, a3dst + 0 * 4096, tile3, psw, shift3);
-      conv3_store_i8(p1, a3dst + 1 * 4096, tile3, psw, shift3);
+      conv3_store_i8m<FASTRQ ? 2 : 0>(p0, a3dst + conv3_pair_row_i8(0) * 1024, tile3, psw, shift3);
+      conv3_store_i8m<FASTRQ ? 2 : 0>(p1, a3dst + conv3_pair_row_i8(1) * 1024, tile3, psw, shift3);
       sched_pairs18_i8<4>();
-      conv3_store_i8(q0, a3dst + 2 * 4096, tile3, psw, shift3);
-      conv3_store_i8(q1, a3dst + 3 * 4096, tile3, psw, shift3);
+      conv3_store_i8m<FASTRQ ? 2 : 0>(q0, a3dst + conv3_pair_row_i8(2) * 1024, tile3, psw, shift3);
+      conv3_store_i8m<FASTRQ ? 2 : 0>(q1, a3dst + conv3_pair_row_i8(3) * 1024, tile3, psw, shift3);
     } else {
       FHEVC_PHASE_IDS
       const int x = lane & 15, kg = lane >> 4;  // B column = position x of the row, K group = activation plane kg; D rows 4 kg ..
@@ -1202,11 +1225,9 @@ hipError_t fhevc_launch_expand_flags(const FhevcFrames& fr, const uint32_t* d_fl
 // > 64 KiB of dynamic LDS needs an opt-in per function AND per device: fhevc_create calls this with its device current
 hipError_t fhevc_cnn_prepare_device()
 {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_kernel<false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, Lds<false>::LDS_BYTES);
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_kernel<false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, Lds<false>::LDS_BYTES);
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_kernel<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, Lds<true>::LDS_BYTES);
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_kernel<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, Lds<true>::LDS_BYTES);
-  return e;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_kernel<false, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, Lds<false>::LDS_BYTES);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_kernel<false, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, Lds<false>::LDS_BYTES);
+  return e;  // (the i8 variant's 50 048 B need no opt-in)
 }
 
 // d_had != nullptr: the fused source Hadamard (only where fhevc_cnn_can_fuse_hadamard says so)
@@ -1220,13 +1241,15 @@ bool fhevc_cnn_can_fuse_hadamard(const FhevcFrames& fr)
 }
 
 namespace {
-template <bool STAMPS, bool HAD, bool I8>
+template <bool STAMPS, bool HAD, int ARITH>
 void launch_depth_kernel(int grid, hipStream_t stream, const FhevcFrames& fr, const FhevcCnnWeights& w, uint8_t* d_depth, int32_t* d_had, int32_t* d_logits,
                          uint32_t* d_flags, unsigned long long* d_stamps, uint8_t* d_depth_max, int margin_split, int margin_stop)
 {
-  hipLaunchKernelGGL((fhevc_cnn_depth_kernel<STAMPS, HAD, I8>), dim3(grid), dim3(256), Lds<I8>::LDS_BYTES, stream, fr, w, d_depth, d_had, d_logits,
+  hipLaunchKernelGGL((fhevc_cnn_depth_kernel<STAMPS, HAD, ARITH>), dim3(grid), dim3(256), Lds<ARITH != 0>::LDS_BYTES, stream, fr, w, d_depth, d_had, d_logits,
                      d_flags, d_stamps, d_depth_max, margin_split, margin_stop);
 }
+// 0: 16-bit MFMAs; 1: i8, general requant; 2: i8 with the short requant forms
+int cnn_arith(const FhevcCnnWeights& w) { return !w.i8 ? 0 : (w.requant_mode[1] == 1 && w.requant_mode[2] == 2) ? 2 : 1; }
 }  // namespace
 
 // workgroups per CU of the persistent grid (FHEVC_CNN_WG_PER_CU overrides: a tuning knob)
@@ -1234,8 +1257,7 @@ static int cnn_wg_per_cu(const FhevcCnnWeights& w)
 {
   const char* e = getenv("FHEVC_CNN_WG_PER_CU");
   if (e && e[0] >= '1' && e[0] <= '4') return e[0] - '0';
-  (void)w;
-  return 2;
+  return w.i8 ? FHEVC_I8_WG_PER_CU : 2;  // what the variants' LDS and register budgets are sized for
 }
 
 hipError_t fhevc_launch_cnn(const FhevcFrames& fr, const FhevcCnnWeights& w, uint8_t* d_depth, int32_t* d_had, int32_t* d_logits,
@@ -1245,13 +1267,14 @@ hipError_t fhevc_launch_cnn(const FhevcFrames& fr, const FhevcCnnWeights& w, uin
   if (total <= 0) return hipSuccess;
   int grid = cnn_wg_per_cu(w) * num_cus;
   if (total < grid) grid = (int)total;
-  if (w.i8) {
-    if (d_had != nullptr) launch_depth_kernel<false, true, true>(grid, stream, fr, w, d_depth, d_had, d_logits, d_flags, nullptr, d_depth_max, margin_split, margin_stop);
-    else launch_depth_kernel<false, false, true>(grid, stream, fr, w, d_depth, nullptr, d_logits, d_flags, nullptr, d_depth_max, margin_split, margin_stop);
-  } else {
-    if (d_had != nullptr) launch_depth_kernel<false, true, false>(grid, stream, fr, w, d_depth, d_had, d_logits, d_flags, nullptr, d_depth_max, margin_split, margin_stop);
-    else launch_depth_kernel<false, false, false>(grid, stream, fr, w, d_depth, nullptr, d_logits, d_flags, nullptr, d_depth_max, margin_split, margin_stop);
+#define FHEVC_LAUNCH(HAD, ARITH) launch_depth_kernel<false, HAD, ARITH>(grid, stream, fr, w, d_depth, d_had, d_logits, d_flags, nullptr, d_depth_max, margin_split, margin_stop)
+  const bool had = d_had != nullptr;
+  switch (cnn_arith(w)) {
+    case 2: if (had) FHEVC_LAUNCH(true, 2); else FHEVC_LAUNCH(false, 2); break;
+    case 1: if (had) FHEVC_LAUNCH(true, 1); else FHEVC_LAUNCH(false, 1); break;
+    default: if (had) FHEVC_LAUNCH(true, 0); else FHEVC_LAUNCH(false, 0); break;
   }
+#undef FHEVC_LAUNCH
   return hipGetLastError();
 }
 
@@ -1266,10 +1289,12 @@ hipError_t fhevc_launch_cnn_stamped(const FhevcFrames& fr, const FhevcCnnWeights
   if (total < grid) grid = (int)total;
   *grid_out = grid;
   if (total <= 0) return hipSuccess;
-  hipError_t e = w.i8 ? hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_kernel<true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, Lds<true>::LDS_BYTES)
-                      : hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_kernel<true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, Lds<false>::LDS_BYTES);
-  if (e != hipSuccess) return e;
-  if (w.i8) launch_depth_kernel<true, false, true>(grid, stream, fr, w, d_depth, nullptr, nullptr, nullptr, d_stamps, nullptr, 0, 0);
-  else launch_depth_kernel<true, false, false>(grid, stream, fr, w, d_depth, nullptr, nullptr, nullptr, d_stamps, nullptr, 0, 0);
+  const int arith = cnn_arith(w);
+  if (arith == 0) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_kernel<true, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, Lds<false>::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    launch_depth_kernel<true, false, 0>(grid, stream, fr, w, d_depth, nullptr, nullptr, nullptr, d_stamps, nullptr, 0, 0);
+  } else if (arith == 1) launch_depth_kernel<true, false, 1>(grid, stream, fr, w, d_depth, nullptr, nullptr, nullptr, d_stamps, nullptr, 0, 0);
+  else launch_depth_kernel<true, false, 2>(grid, stream, fr, w, d_depth, nullptr, nullptr, nullptr, d_stamps, nullptr, 0, 0);
   return hipGetLastError();
 }
