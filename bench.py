@@ -26,6 +26,13 @@ sys.path.insert(0, ROOT)
 MAC_PER_CTU = 4096 * 9 * 16 + 1024 * 144 * 32 + 256 * 288 * 64 + (4096 + 4 * 4096 + 16 * 1024) * 2
 FLOP_PER_CTU = 2 * MAC_PER_CTU
 PEAK_BF16_TFLOPS = 2500.0   # dense 16-bit (bf16 = f16) MFMA, MI355X_MICROARCH.md
+PEAK_I8_TOPS = 5000.0       # dense i8 MFMA: "2x BF16 per clock" (same table)
+ARITH_DTYPE = {
+    "i8": "int8 operands / int32 accumulate on v_mfma_i32_32x32x32_i8 (conv2, conv3: 93 % of the MACs); conv1 bf16 operands / f32 accumulate "
+          "(fixed-point valued); every result exact",
+    "f16": "bf16 (conv1) and f16 (conv2, conv3) operands / f32 accumulate (fixed-point valued, exact)",
+}
+ARITH_PEAK = {"i8": PEAK_I8_TOPS, "f16": PEAK_BF16_TFLOPS}
 PEAK_HBM_GBS = 8000.0
 PEAK_PCIE_GBS = 63.0        # PCIe Gen5 x16 (spec), MI355X_MICROARCH.md
 PEAK_INT32_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12  # 256 CUs x 4 SIMD x 16 lanes x 2.4 GHz: one 32-bit integer op per lane-cycle (39.3)
@@ -190,6 +197,10 @@ def main():
     ap.add_argument("--no-stages", action="store_true", help="skip the first-pass / pre-analysis / motion-search stage report")
     ap.add_argument("--no-host-path", action="store_true", help="skip the host-to-host (PCIe-inclusive) leg")
     ap.add_argument("--cpu-procs", type=int, default=None, help="processes of the all-cores CPU baseline (default: host cores, at most 16)")
+    ap.add_argument("--arith", choices=("i8", "f16"), default=None,
+                    help="arithmetic of the classifier's conv2 / conv3 for the headline (default: the library's, i8); the other form is timed "
+                         "beside it (\"variants\") unless --no-variants")
+    ap.add_argument("--no-variants", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
@@ -230,7 +241,8 @@ def main():
     else:
         w, wdesc = weights.random_weights(0), "random-init weights"  # same architecture, same arithmetic
     total_frames = world * NF if (mode == "frames" and scaling == "weak") else NF
-    ctx = capi.Context(W, H, bd, w, device=local, max_frames=max(1, min(NF, 16)))
+    ctx = capi.Context(W, H, bd, w, device=local, max_frames=max(1, min(NF, 16)), arith=args.arith)
+    arith = ctx.cnn_arith
     cw, ch, n_ctus = ctx.ctus_x, ctx.ctus_y, ctx.num_ctus
     fg = gather.FlagGather(mode, world, rank, total_frames, cw, ch, dev, group=group, host_group=host_group)
     f0, f1 = fg.frames
@@ -310,6 +322,28 @@ def main():
         regions.append(dt)
     cnn_ms, cnn_n = ctx.kernel_timing(0)
     had_ms, had_n = ctx.kernel_timing(1)
+
+    # ---- the other arithmetic form of the classifier, the same steps on the same box (one timed region): a second line, never `value` ----
+    variants = None
+    if not args.no_variants:
+        other = "f16" if arith == "i8" else "i8"
+        ctx.set_cnn_arith(other)
+        for i in range(args.warmup):
+            step(i)
+        fence()
+        ctx.kernel_timing(0, reset=True)
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        fence()
+        dto = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dto], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dto = float(t.item())
+        o_ms, o_n = ctx.kernel_timing(0, reset=True)
+        ctx.set_cnn_arith(arith)
+        variants = {other: {"seconds": dto, "cnn_ms": o_ms, "launches": o_n}}
 
     # untimed check of the N > 1 path: what gather + expansion left in `gathered` must contain this rank's own maps at their
     # place, and the same bytes on every rank
@@ -429,10 +463,19 @@ def main():
         band_px = nf_local * W * min(H, (r1 - r0) * 64)
         bytes_per_launch_had = band_px * sample_b + local_ctus * 4
         traffic, traffic_src = measured_traffic("fhevc_cnn_depth_kernel")
-        roof = {"bound": "mfma", "kernel": "fhevc_cnn_depth_kernel", "achieved": flop_per_launch / (cnn_ms * 1e-3) / 1e12 if cnn_ms else None,
-                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "traffic": traffic, "traffic_source": traffic_src,
-                "avg_launch_ms": cnn_ms, "launches": cnn_n, "flop_per_ctu": FLOP_PER_CTU, "ctus_per_launch": local_ctus}
+        roof = {"bound": "mfma", "kernel": f"fhevc_cnn_depth_kernel ({arith} form)", "achieved": flop_per_launch / (cnn_ms * 1e-3) / 1e12 if cnn_ms else None,
+                "peak": ARITH_PEAK[arith], "unit": "TFLOP/s" if arith == "f16" else "TOP/s (2 per MAC)", "traffic": traffic, "traffic_source": traffic_src,
+                "avg_launch_ms": cnn_ms, "launches": cnn_n, "flop_per_ctu": FLOP_PER_CTU, "ctus_per_launch": local_ctus,
+                "peak_note": "dense 16-bit MFMA" if arith == "f16" else "dense i8 MFMA; conv1 (6 % of the MACs) runs on the 16-bit MFMA at half that rate"}
         roof["frac"] = roof["achieved"] / roof["peak"] if roof["achieved"] else None
+        if variants:
+            for name, v in variants.items():
+                ach = flop_per_launch / (v["cnn_ms"] * 1e-3) / 1e12 if v["cnn_ms"] else None
+                variants[name] = {"value": ctus_per_step * args.steps / v["seconds"], "unit": "CTU/s", "ms_per_step": v["seconds"] / args.steps * 1e3,
+                                  "dtype": ARITH_DTYPE[name], "regions": 1,
+                                  "roofline": {"bound": "mfma", "kernel": f"fhevc_cnn_depth_kernel ({name} form)", "achieved": ach, "peak": ARITH_PEAK[name],
+                                               "unit": "TFLOP/s" if name == "f16" else "TOP/s (2 per MAC)", "frac": ach / ARITH_PEAK[name] if ach else None,
+                                               "avg_launch_ms": v["cnn_ms"], "launches": v["launches"]}}
         htraffic, htraffic_src = measured_traffic("fhevc_src_hadamard_kernel")
         hbm = {"bound": "hbm", "kernel": "fhevc_src_hadamard_kernel", "achieved": bytes_per_launch_had / (had_ms * 1e-3) / 1e9 if had_ms else None,
                "peak": PEAK_HBM_GBS, "unit": "GB/s", "traffic": htraffic, "traffic_source": htraffic_src, "avg_launch_ms": had_ms, "launches": had_n,
@@ -444,7 +487,7 @@ def main():
             "value": value, "unit": "CTU/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
-            "dtype": "bf16 (conv1) and f16 (conv2, conv3) operands / f32 accumulate (fixed-point valued, exact)", "data": "synthetic",
+            "dtype": ARITH_DTYPE[arith], "data": "synthetic",
             "config": {"workload": f"{geom} {W}x{H} all-intra QP32, GOP of {total_frames} synthetic 'hetero' frames "
                                    f"({'int16 Pel planes, HM stride/margins' if sample_b == 2 else 'uint8 planes'}) resident in HBM, "
                                    f"source Hadamard + CTU-batched CNN depth predictor, {wdesc}",
@@ -463,6 +506,8 @@ def main():
             line["host_to_host"] = host
         if stages:
             line["stages"] = stages
+        if variants:
+            line["variants"] = variants
         if world > 1:
             line["gather_verified"] = gather_ok
             line["collective"] = fg.status

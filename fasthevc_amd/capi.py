@@ -25,8 +25,9 @@ SYMBOLS = [
     "fhevc_expand_depth_flags_device", "fhevc_aq_parts", "fhevc_preanalyze", "fhevc_preanalyze_frames_device", "fhevc_aq_qp", "fhevc_intra_first_pass_device",
     "fhevc_predict_frame_range", "fhevc_predict_frames_device_range",
     "fhevc_motion_search", "fhevc_motion_search_device", "fhevc_intra_first_pass_all", "fhevc_p_rule_default", "fhevc_p_depth_range",
-    "fhevc_predict_frames", "fhevc_alloc_host", "fhevc_free_host",
+    "fhevc_predict_frames", "fhevc_alloc_host", "fhevc_free_host", "fhevc_set_cnn_arith", "fhevc_get_cnn_arith",
 ]
+CNN_ARITH = {"i8": 8, "f16": 16}
 
 
 class Cfg(C.Structure):
@@ -115,6 +116,8 @@ def load_library():
     lib.fhevc_aq_qp.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     lib.fhevc_preanalyze_frames_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_int,
                                                    C.c_int, vp, vp]
+    lib.fhevc_set_cnn_arith.argtypes = [vp, C.c_int]
+    lib.fhevc_get_cnn_arith.argtypes = [vp]
     lib.fhevc_motion_search.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]
     lib.fhevc_motion_search_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
     lib.fhevc_p_rule_default.argtypes = [C.POINTER(PRule)]
@@ -170,7 +173,7 @@ def band(ctu_rows, rank, world):
 class Context:
     """One fhevc_ctx: one picture geometry on one MI355X."""
 
-    def __init__(self, width, height, bit_depth=8, weights=None, device=0, max_frames=1):
+    def __init__(self, width, height, bit_depth=8, weights=None, device=0, max_frames=1, arith=None):
         self.lib = load_library()
         self.width, self.height, self.bit_depth = width, height, bit_depth
         self.ctus_x, self.ctus_y = (width + 63) // 64, (height + 63) // 64
@@ -182,6 +185,8 @@ class Context:
         if rc != OK:
             raise FastHevcError(rc, "fhevc_create (no gfx950 device?)" if rc == E_NO_DEVICE else "fhevc_create")
         self.h = h
+        if arith is not None:
+            self.set_cnn_arith(arith)
         if weights is not None:
             self.set_weights(weights)
 
@@ -348,6 +353,15 @@ class Context:
 
     def expand_depth_flags_device(self, d_flags, num_frames, d_depth, stream=None):
         self._check(self.lib.fhevc_expand_depth_flags_device(self.h, d_flags, num_frames, d_depth, stream))
+
+    def set_cnn_arith(self, arith):
+        """"i8" (default) or "f16": the arithmetic of the classifier's conv2 / conv3; the results are the same integers"""
+        self._check(self.lib.fhevc_set_cnn_arith(self.h, CNN_ARITH[arith]))
+
+    @property
+    def cnn_arith(self):
+        v = self.lib.fhevc_get_cnn_arith(self.h)
+        return {8: "i8", 16: "f16"}[v]
 
     def enable_kernel_timing(self, on=True):
         self._check(self.lib.fhevc_enable_kernel_timing(self.h, 1 if on else 0))

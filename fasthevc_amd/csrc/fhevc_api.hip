@@ -30,7 +30,7 @@ struct fhevc_ctx {
   uint4* d_frag_i8 = nullptr; int32_t* d_bias_i8 = nullptr;  // the i8 variant of conv2 / conv3 (k_cnn.hip)
   int shift[3] = { 0, 0, 0 };
   int requant_mode[3] = { 0, 0, 0 };
-  bool cnn_i8 = false;                                        // FHEVC_CNN_ARITH=i8 at fhevc_create
+  bool cnn_i8 = true;                                         // fhevc_set_cnn_arith / FHEVC_CNN_ARITH at fhevc_create
   float scale[3] = { 1, 1, 1 };
   // staging for the host-buffer entry points
   int16_t* d_luma = nullptr; uint8_t* d_depth = nullptr; int32_t* d_had = nullptr; FhevcNodeCost* d_nodes = nullptr;
@@ -354,7 +354,7 @@ int fhevc_create(fhevc_ctx** out, const fhevc_cfg* cfg)
   c->num_cus = prop.multiProcessorCount;
   if (const char* fz = std::getenv("FHEVC_FUSE_HADAMARD")) c->fuse_hadamard = fz[0] != '0';
   // arithmetic of conv2 / conv3 in the depth kernel: "f16" (16-bit MFMAs) or "i8" (v_mfma_i32_32x32x32_i8); both are exact
-  if (const char* ar = std::getenv("FHEVC_CNN_ARITH")) c->cnn_i8 = std::strcmp(ar, "i8") == 0;
+  if (const char* ar = std::getenv("FHEVC_CNN_ARITH")) c->cnn_i8 = std::strcmp(ar, "f16") != 0;
   c->ctus_x = (cfg->width + 63) / 64;
   c->ctus_y = (cfg->height + 63) / 64;
   c->num_ctus = c->ctus_x * c->ctus_y;
@@ -985,6 +985,20 @@ int fhevc_debug_cnn_phase_cycles(fhevc_ctx* c, const void* d_luma, int sample_by
   out10[8] = (double)num_frames * c->num_ctus / grid;
   out10[9] = grid;
   return FHEVC_OK;
+}
+
+int fhevc_set_cnn_arith(fhevc_ctx* c, int arith)
+{
+  if (!c) return FHEVC_E_INVALID;
+  if (arith != FHEVC_CNN_ARITH_I8 && arith != FHEVC_CNN_ARITH_F16) return fail(c, FHEVC_E_INVALID, "arith: FHEVC_CNN_ARITH_I8 or FHEVC_CNN_ARITH_F16");
+  c->cnn_i8 = arith == FHEVC_CNN_ARITH_I8;
+  return FHEVC_OK;
+}
+
+int fhevc_get_cnn_arith(const fhevc_ctx* c)
+{
+  if (!c) return FHEVC_E_INVALID;
+  return c->cnn_i8 ? FHEVC_CNN_ARITH_I8 : FHEVC_CNN_ARITH_F16;
 }
 
 int fhevc_get_stats(fhevc_ctx* c, void* out, size_t size)

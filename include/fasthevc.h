@@ -236,6 +236,15 @@ int  fhevc_band(int ctu_rows, int rank, int world, int* begin, int* end);
 int  fhevc_kernel_timing(fhevc_ctx* ctx, int which, int reset, double* avg_ms, uint64_t* launches);
 int  fhevc_enable_kernel_timing(fhevc_ctx* ctx, int on);
 
+/* Arithmetic of the depth classifier's conv2 / conv3 (both forms deliver the same integers, bit for bit):
+ *   FHEVC_CNN_ARITH_I8  (default): v_mfma_i32_32x32x32_i8 on activations kept as signed bytes, three workgroups per CU;
+ *   FHEVC_CNN_ARITH_F16          : 16-bit MFMAs (f16 activations), two workgroups per CU.
+ * The environment variable FHEVC_CNN_ARITH=i8|f16 sets the initial value at fhevc_create; a change takes effect at the next launch. */
+#define FHEVC_CNN_ARITH_I8   8
+#define FHEVC_CNN_ARITH_F16 16
+int  fhevc_set_cnn_arith(fhevc_ctx* ctx, int arith);
+int  fhevc_get_cnn_arith(const fhevc_ctx* ctx);   /* FHEVC_CNN_ARITH_*, or a negative status */
+
 int  fhevc_get_stats(fhevc_ctx* ctx, void* out, size_t size); /* copies min(size, sizeof(fhevc_stats)) */
 const char* fhevc_last_error(fhevc_ctx* ctx);
 const char* fhevc_version(void);

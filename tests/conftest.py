@@ -22,3 +22,17 @@ def oracle():
 def golden():
     import numpy as np
     return np.load(os.path.join(ROOT, "tests", "golden", "ref_vectors.npz"))
+
+
+@pytest.fixture(params=["i8", "f16", "i8-general-requant"])
+def cnn_arith(request, monkeypatch):
+    """Every arithmetic form of the depth classifier (k_cnn.hip) must deliver the oracle's integers: contexts created inside a
+    test that uses this fixture run conv2 / conv3 on the i8 MFMAs (the default), on the 16-bit MFMAs, and on the i8 MFMAs with the
+    general requant form instead of the short ones (FHEVC_CNN_REQUANT, read by fhevc_set_weights)."""
+    arith = request.param
+    monkeypatch.setenv("FHEVC_CNN_ARITH", "f16" if arith == "f16" else "i8")
+    if arith == "i8-general-requant":
+        monkeypatch.setenv("FHEVC_CNN_REQUANT", "general")
+    else:
+        monkeypatch.delenv("FHEVC_CNN_REQUANT", raising=False)
+    return arith

@@ -24,7 +24,7 @@ def _oracle(oracle, w, buf, org, stride, W, H, bd, qp):
     return depth.reshape(-1, 256), had
 
 
-def test_config3_4k_eight_bands(oracle):
+def test_config3_4k_eight_bands(oracle, cnn_arith):
     """3840x2160: 60x34 CTUs, last row 48 px tall.  The 8 CTU-row bands of an 8-rank node, launched one after the
     other on this GPU, must assemble (through the 4-byte flag words the ranks all-gather) into the oracle's map."""
     import torch
@@ -61,7 +61,7 @@ def test_config3_4k_eight_bands(oracle):
     ctx.close()
 
 
-def test_config5_10bit_1080p(oracle, golden):
+def test_config5_10bit_1080p(oracle, golden, cnn_arith):
     """encoder_intra_main10 geometry: 8-bit content at InternalBitDepth 10 (samples << 2) in 16-bit pel planes."""
     W, H, QP = 1920, 1080, 27
     w = weights.load(SHIPPED)
@@ -84,7 +84,7 @@ def test_config5_10bit_1080p(oracle, golden):
     ctx.close()
 
 
-def test_bench_gop_64_frames_properties(oracle):
+def test_bench_gop_64_frames_properties(oracle, cnn_arith):
     """The bench.py workload: 64 panned 1080p frames as HM-layout int16 planes in HBM, one launch."""
     import torch
     dev = torch.device("cuda:0")

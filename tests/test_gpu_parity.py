@@ -56,7 +56,7 @@ def test_satd_random_vs_oracle(oracle):
 
 @pytest.mark.parametrize("bd", [8, 10])
 @pytest.mark.parametrize("seed,extreme", [(0, False), (7, True)])
-def test_predict_frame_416x240(oracle, golden, bd, seed, extreme):
+def test_predict_frame_416x240(oracle, golden, bd, seed, extreme, cnn_arith):
     """config 1 geometry (7x4 CTUs, last column 32 px wide, last row 48 px tall), host-buffer entry point."""
     w = weights.random_weights(seed, extreme=extreme)
     luma = frames.texture16_luma(416, 240)
@@ -74,7 +74,7 @@ def test_predict_frame_416x240(oracle, golden, bd, seed, extreme):
 
 
 @pytest.mark.parametrize("which", ["random", "trained"])
-def test_predict_frame_1080p_hetero(oracle, golden, which):
+def test_predict_frame_1080p_hetero(oracle, golden, which, cnn_arith):
     """config 2 geometry, the heterogeneous content: 510 CTUs, last row 56 px tall; random-init and shipped weights."""
     w = weights.random_weights(1) if which == "random" else weights.load(
         os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fasthevc_amd", "weights", "depthnet_v1.fhw"))
@@ -91,7 +91,7 @@ def test_predict_frame_1080p_hetero(oracle, golden, which):
     ctx.close()
 
 
-def test_device_batch_logits_and_bands(oracle, torch_cuda):
+def test_device_batch_logits_and_bands(oracle, torch_cuda, cnn_arith):
     """Device-resident batch entry point: 3 frames, uint8 and int16 sample layouts, logits, CTU-row bands."""
     torch = torch_cuda
     w = weights.random_weights(2)
@@ -139,7 +139,7 @@ def test_device_batch_logits_and_bands(oracle, torch_cuda):
 
 
 @pytest.mark.parametrize("W,H", [(200, 136), (72, 72), (64, 8), (8, 200)])
-def test_split_flag_words_on_ragged_pictures(oracle, torch_cuda, W, H):
+def test_split_flag_words_on_ragged_pictures(oracle, torch_cuda, W, H, cnn_arith):
     """Pictures whose last CTU column/row is cut inside a 16x16 block (width, height = 8 mod 16): the depth maps equal the
     oracle's and the 4-byte split-flag words expand back to them (the expansion masks the units outside the picture)."""
     torch = torch_cuda
@@ -189,7 +189,7 @@ def test_source_hadamard_extremes(oracle, bd):
     ctx.close()
 
 
-def test_soft_decision_ranges(oracle, torch_cuda):
+def test_soft_decision_ranges(oracle, torch_cuda, cnn_arith):
     """fhevc_predict_frame_range / _device_range against the oracle's fho_depth_range_from_logits."""
     torch = torch_cuda
     w = weights.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fasthevc_amd", "weights", "depthnet_v1.fhw"))

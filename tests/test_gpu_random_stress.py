@@ -43,8 +43,8 @@ def test_random_configuration(oracle, seed):
     org = m * stride + m
     cw, ch = frames.ctu_grid(W, H)
     n = cw * ch
-    ctx = capi.Context(W, H, bd, w)
-    # depth CNN + source Hadamard
+    ctx = capi.Context(W, H, bd, w, arith=("i8", "f16")[seed & 1])  # both arithmetic forms of the classifier (the extreme blobs, seed % 3 == 0,
+    # depth CNN + source Hadamard                                      # overflow 24 bits: the i8 form then takes its general requant)
     depth_ref, logits = np.zeros(n * 256, np.uint8), np.zeros(n * 42, np.int32)
     oracle.fho_predict_frame(op.weights_from_arrays(w), op.ptr(buf.reshape(-1), org), stride, W, H, bd, qp, depth_ref, C.c_void_p(logits.ctypes.data))
     had_ref = np.zeros(n, np.int32)
