@@ -448,6 +448,11 @@ def main():
             if os.path.exists(path):
                 d = json.load(open(path))
                 for k, v in d.items():
+                    if kernel == "fhevc_cnn_depth_kernel" and k.startswith(kernel + "<"):
+                        # template arguments <STAMPS, HAD, ARITH>: ARITH 0 = the 16-bit form, 1 / 2 = the i8 form (files of before the i8 form: two arguments)
+                        targs = k.split("<", 1)[1].split(">", 1)[0].split(",")
+                        if (arith == "i8") != (len(targs) == 3 and targs[2].strip() in ("1", "2")):
+                            continue
                     if k.startswith(kernel) and isinstance(v, dict) and "hbm_read_bytes_corrected" in v and "hbm_write_bytes" in v:
                         return v["hbm_read_bytes_corrected"] + v["hbm_write_bytes"], f"profiles/{rnd}_pmc_bench_frames64_int16.json (commit {d.get('commit', 'of that round')})"
         return None, None

@@ -971,7 +971,7 @@ int fhevc_debug_cnn_phase_cycles(fhevc_ctx* c, const void* d_luma, int sample_by
   (void)hipSetDevice(c->device);
   const FhevcFrames fr = frames_of(c, d_luma, sample_bytes, stride_samples, frame_stride_samples, num_frames, 0, c->ctus_y);
   unsigned long long* d_st = nullptr;
-  const int max_grid = 2 * c->num_cus;
+  const int max_grid = 4 * c->num_cus;  // fhevc_launch_cnn_stamped runs at most four workgroups per CU
   HIP_TRY(c, hipMalloc(&d_st, (size_t)max_grid * 8 * sizeof(unsigned long long)));
   HIP_TRY(c, hipMemset(d_st, 0, (size_t)max_grid * 8 * sizeof(unsigned long long)));
   int grid = 0;

@@ -63,9 +63,22 @@ for layout, ptr, sb, st, fstride in (("int16 HM planes", d16.data_ptr() + 2 * or
         alg = NF * (W * H * sb + ctx.num_ctus * 4)
         if cx is ctx_unfused:
             out[f"src_hadamard[{layout}]"] = {"ms": ms_h, "launches": n, "algorithmic_bytes": alg, "GB/s": alg / ms_h / 1e6}
-            out[f"depth_cnn[{layout}]"] = {"ms": ms_c, "Mctu/s": NF * ctx.num_ctus / ms_c / 1e3}
+            out[f"depth_cnn i8[{layout}]"] = {"ms": ms_c, "Mctu/s": NF * ctx.num_ctus / ms_c / 1e3}
         else:
-            out[f"depth_cnn+fused_hadamard[{layout}]"] = {"ms": ms_c, "Mctu/s": NF * ctx.num_ctus / ms_c / 1e3, "stand_alone_hadamard_launches": n}
+            out[f"depth_cnn i8+fused_hadamard[{layout}]"] = {"ms": ms_c, "Mctu/s": NF * ctx.num_ctus / ms_c / 1e3, "stand_alone_hadamard_launches": n}
+        # the 16-bit form of the classifier on the same context
+        cx.set_cnn_arith("f16")
+        for _ in range(2):
+            cx.predict_frames_device(ptr, sb, st, fstride, NF, depth.data_ptr(), had.data_ptr())
+        torch.cuda.synchronize()
+        cx.kernel_timing(0, reset=True); cx.kernel_timing(1, reset=True)
+        for _ in range(REPS):
+            cx.predict_frames_device(ptr, sb, st, fstride, NF, depth.data_ptr(), had.data_ptr())
+        torch.cuda.synchronize()
+        ms_c, _ = cx.kernel_timing(0, reset=True)
+        cx.kernel_timing(1, reset=True)
+        cx.set_cnn_arith("i8")
+        out[f"depth_cnn f16{'' if cx is ctx_unfused else '+fused_hadamard'}[{layout}]"] = {"ms": ms_c, "Mctu/s": NF * ctx.num_ctus / ms_c / 1e3}
 
 # --- 35-mode first pass, one picture per call (host-buffer entry point; the kernel time excludes the copies)
 for _ in range(2):
