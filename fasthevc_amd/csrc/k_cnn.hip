@@ -653,6 +653,7 @@ __device__ __forceinline__ void stage_ctu(unsigned char* lds, int r2_off, const 
     }
   }
   // input halo: 66*66 - 64*64 = 260 two-byte cells of bf16(128)
+  asm volatile("" : "+v"(in_cells));
   *reinterpret_cast<unsigned short*>(lds + (in_cells & 0xFFFF)) = 0x4300;
   if (tid < 260 - 256) *reinterpret_cast<unsigned short*>(lds + (in_cells >> 16)) = 0x4300;
 }
@@ -705,6 +706,7 @@ __device__ __forceinline__ HaloCells halo_cells(int tid)
 template <bool I8>
 __device__ __forceinline__ void zero_a1_halo(unsigned char* lds, int tid, unsigned cells)
 {
+  asm volatile("" : "+v"(cells));  // unpack the two offsets here, every time: hoisted out of the CTU loop they are two more kernel-long registers
   constexpr unsigned Z = Lds<I8>::HALO_FILL;
   *reinterpret_cast<uint4*>(lds + (cells & 0xFFFF)) = make_uint4(Z, Z, Z, Z);
   if (tid < 132 * Lds<I8>::A1_PLANES - 256) *reinterpret_cast<uint4*>(lds + (cells >> 16)) = make_uint4(Z, Z, Z, Z);
@@ -902,7 +904,9 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
     if constexpr (I8) {
       FHEVC_PHASE_IDS
       constexpr unsigned Z = L::HALO_FILL;  // the input tile is dead: "activation 0" into the A2 halo (68 positions x 2 planes)
-      *reinterpret_cast<uint4*>(lds + (hc.a2 & 0xFFFF)) = make_uint4(Z, Z, Z, Z);
+      unsigned a2cells = hc.a2;
+      asm volatile("" : "+v"(a2cells));
+      *reinterpret_cast<uint4*>(lds + (a2cells & 0xFFFF)) = make_uint4(Z, Z, Z, Z);
       // lane -> pooled position as in the 16-bit form below; the lane half picks the input row of a tap pair (ky = 2 q + h)
       const int q = r >> 2;
       const int pr = (q ^ (q >> 1) ^ (q >> 2)) & 1, pc = ((r >> 3) << 2) | (r & 3);
@@ -1048,15 +1052,15 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
     // ================= P4: FC heads on v_dot4_i32_i8 (int8 weights resident in LDS, activations a - 128) =================
     {  // conv1's fragments for the next CTU: issued first so that they have landed before the depth phase, whose spill
        // reloads wait for vmcnt(0)
-      const uint4* fp = frag1p;
-      asm volatile("" : "+v"(fp));  // opaque address: keeps the re-fetch inside the loop
-      wA1a = __builtin_bit_cast(bf16x8, fp[0]);
-      wA1b = __builtin_bit_cast(bf16x8, fp[64]);
+      unsigned lane_off = (unsigned)(threadIdx.x & 63) * 16u;
+      asm volatile("" : "+v"(lane_off));  // opaque 32-bit lane offset on a scalar base: keeps the re-fetch inside the loop, no kernel-long pointer pair
+      const unsigned char* fp = reinterpret_cast<const unsigned char*>(W.frag + FHEVC_FRAG_CONV1) + lane_off;
+      wA1a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(fp));
+      wA1b = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(fp + 64 * 16));
       if (I8) {  // the i8 variant runs three workgroups per CU on 168 registers: conv2's fragments are dead during conv3 and come back here too
-        const uint4* f2 = W.frag_i8 + FHEVC_FRAGI8_CONV2 + lane;
-        asm volatile("" : "+v"(f2));
+        const unsigned char* f2 = reinterpret_cast<const unsigned char*>(W.frag_i8 + FHEVC_FRAGI8_CONV2) + lane_off;
 #pragma unroll
-        for (int s = 0; s < 6; ++s) wA2[s] = __builtin_bit_cast(bf16x8, f2[s * 64]);
+        for (int s = 0; s < 6; ++s) wA2[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(f2 + s * 64 * 16));
       }
     }
     {
@@ -1109,7 +1113,10 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
     }
     // the A2/input region (R2) is free since the P3 barrier: stage the next CTU now, its P1 needs no extra barrier
     FHEVC_STAMP(6)  // heads only
-    if (work + (int)gridDim.x < total) stage_ctu(lds, L::R2_OFF, pre, F, next, tid, ld_row, ld_seg, shift_in, hc.in);
+    if (work + (int)gridDim.x < total) {
+      FHEVC_PHASE_IDS  // the staging addresses are re-derived per CTU: hoisted, they were spilled to scratch in the 168-register form
+      stage_ctu(lds, L::R2_OFF, pre, F, next, tid, tid >> 2, tid & 3, shift_in, hc.in);
+    }
     FHEVC_STAMP(7)  // staging of the next CTU; slot 4 below is then the wait at the barrier
     __syncthreads();
     FHEVC_STAMP(4)
