@@ -827,6 +827,18 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
     step.f = g / per_frame; step.ry = (g - step.f * per_frame) / F.ctus_x; step.cx = (g - step.f * per_frame) - step.ry * F.ctus_x;
   }
   Prefetched pre = prefetch_ctu<HAD>(F, vblock < total, pos, ld_row, ld_seg);
+  // the heads' per-thread LDS rows (see P4): position (y, x) of quadrant `wave`, 16x16 block lane >> 4
+  uint2 head_addr;
+  {
+    const int q = wave, blk = lane >> 4;
+    const int y = (q >> 1) * 8 + (blk >> 1) * 4 + ((lane >> 2) & 3), x = (q & 1) * 8 + (blk & 1) * 4 + (lane & 3);
+    const unsigned psw = (x >> 2) & 3, sw16 = y & 3, sw32 = y & 3, sw64 = (y >> 1) & 3;  // chunk swizzles: a3 rows (P3), weight rows (prologue above)
+    const unsigned a_0 = (unsigned)(y * 16 + x) * 64 + (psw << 4);
+    const unsigned w16_0 = (unsigned)((y & 3) * 4 + (x & 3)) * 64 + (sw16 << 4);
+    const unsigned w32_0 = (unsigned)((y & 7) * 8 + (x & 7)) * 64 + (sw32 << 4);
+    const unsigned w64_0 = (unsigned)((y >> 1) * 8 + (x >> 1)) * 64 + (sw64 << 4);  // 2x2 sum pool: four positions share a weight row
+    head_addr = make_uint2(a_0 | (w16_0 << 16), w32_0 | (w64_0 << 16));
+  }
   int had_set = 0;  // which of the two sets of per-wave Hadamard sums belongs to the CTU in flight
   if (vblock < total) {  // prologue: first CTU of this workgroup
     stage_ctu(lds, L::R2_OFF, pre, F, pos, tid, ld_row, ld_seg, shift_in, hc.in);
@@ -1065,24 +1077,22 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
     }
     {
       FHEVC_PHASE_IDS
-      // wave = 32x32 quadrant q; 16-lane DPP row = one 16x16 block of it; lane bits [1:0] = x & 3, [3:2] = y & 3
+      // wave = 32x32 quadrant q; 16-lane DPP row = one 16x16 block of it; lane bits [1:0] = x & 3, [3:2] = y & 3 (head_addr)
       const int q = wave, blk = lane >> 4;
-      const int y = (q >> 1) * 8 + (blk >> 1) * 4 + ((lane >> 2) & 3);
-      const int x = (q & 1) * 8 + (blk & 1) * 4 + (lane & 3);
-      const unsigned char* arow = lds + A3_OFF + (y * 16 + x) * 64;
-      const int psw = (x >> 2) & 3;  // chunk swizzle of this position (see P3)
-      const unsigned char* w16 = lds + L::HEADW_OFF + HEAD16_OFF + ((y & 3) * 4 + (x & 3)) * 64;
-      const unsigned char* w32 = lds + L::HEADW_OFF + HEAD32_OFF + ((y & 7) * 8 + (x & 7)) * 64;
-      const unsigned char* w64 = lds + L::HEADW_OFF + HEAD64_OFF + ((y >> 1) * 8 + (x >> 1)) * 64;  // 2x2 sum pool
-      const int sw16 = y & 3, sw32 = y & 3, sw64 = (y >> 1) & 3;  // (row >> 2) & 3, (row >> 3) & 3 of the weight rows (both classes)
+      // the thread's a3 row and its three weight rows, each with its chunk swizzle applied: step qq reads chunk (qq ^ swizzle) of a
+      // 64-byte row = the row's address XOR (qq << 4); four 16-bit offsets in two kernel-long registers instead of ~40 VALU per CTU
+      unsigned ha0 = head_addr.x, ha1 = head_addr.y;
+      asm volatile("" : "+v"(ha0), "+v"(ha1));
+      const unsigned a_0 = ha0 & 0xFFFFu, w16_0 = ha0 >> 16, w32_0 = ha1 & 0xFFFFu, w64_0 = ha1 >> 16;
+      const unsigned char* hw = lds + L::HEADW_OFF;
       int s16a = 0, s16b = 0, s32a = 0, s32b = 0, s64a = 0, s64b = 0;
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) {  // 16 channels per step keeps this phase's register footprint small
-        const uint4 a = *reinterpret_cast<const uint4*>(arow + ((qq ^ psw) << 4));
-        const int o16 = (qq ^ sw16) << 4, o32 = (qq ^ sw32) << 4, o64 = (qq ^ sw64) << 4;
-        const uint4 b0 = *reinterpret_cast<const uint4*>(w16 + o16), b1 = *reinterpret_cast<const uint4*>(w16 + 1024 + o16);
-        const uint4 c0 = *reinterpret_cast<const uint4*>(w32 + o32), c1 = *reinterpret_cast<const uint4*>(w32 + 4096 + o32);
-        const uint4 d0 = *reinterpret_cast<const uint4*>(w64 + o64), d1 = *reinterpret_cast<const uint4*>(w64 + 4096 + o64);
+        const uint4 a = *reinterpret_cast<const uint4*>(lds + A3_OFF + (a_0 ^ (qq << 4)));
+        const unsigned char *w16 = hw + HEAD16_OFF + (w16_0 ^ (qq << 4)), *w32 = hw + HEAD32_OFF + (w32_0 ^ (qq << 4)), *w64 = hw + HEAD64_OFF + (w64_0 ^ (qq << 4));
+        const uint4 b0 = *reinterpret_cast<const uint4*>(w16), b1 = *reinterpret_cast<const uint4*>(w16 + 1024);
+        const uint4 c0 = *reinterpret_cast<const uint4*>(w32), c1 = *reinterpret_cast<const uint4*>(w32 + 4096);
+        const uint4 d0 = *reinterpret_cast<const uint4*>(w64), d1 = *reinterpret_cast<const uint4*>(w64 + 4096);
         s16a = sdot4(a.x, b0.x, s16a); s16a = sdot4(a.y, b0.y, s16a); s16a = sdot4(a.z, b0.z, s16a); s16a = sdot4(a.w, b0.w, s16a);
         s16b = sdot4(a.x, b1.x, s16b); s16b = sdot4(a.y, b1.y, s16b); s16b = sdot4(a.z, b1.z, s16b); s16b = sdot4(a.w, b1.w, s16b);
         s32a = sdot4(a.x, c0.x, s32a); s32a = sdot4(a.y, c0.y, s32a); s32a = sdot4(a.z, c0.z, s32a); s32a = sdot4(a.w, c0.w, s32a);
