@@ -81,6 +81,7 @@ static_assert(3 * Lds<true>::LDS_BYTES <= 160 * 1024, "three workgroups per CU")
 constexpr int A1_PLANE = Lds<false>::A1_PLANE;
 
 constexpr int HEAD64_OFF = 0, HEAD32_OFF = 2 * 4096, HEAD16_OFF = 4 * 4096;  // into whead (int8)
+constexpr int HEADM_OFF = 2 * 4096, HEADM_STEP = 10 * 64, HEADM_BYTES = 16 * HEADM_STEP;  // the i8 form's MFMA image of wh32 + wh16
 
 // max(v, value of the horizontally adjacent lane): with old = 0 and bound_ctrl the DPP move folds into ONE
 // v_max_f32_dpp quad_perm:[1,0,3,2] (the (v, v, bound_ctrl = 0) form costs v_mov + v_mov_dpp + v_max)
@@ -795,10 +796,25 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
   }
   // head weights stay in LDS for the life of the workgroup; the four 16-B chunks of a 64-B row are XOR-swizzled by
   // the row so that the 16 lanes of a ds_read_b128 group (a 4x4 block of positions) hit 16 distinct slots
-  for (int i = tid; i < 18432 / 16; i += 256) {
+  for (int i = tid; i < (I8 ? 8192 : 18432) / 16; i += 256) {
     const int row = i >> 2, c = i & 3;
     const int sw = (i < 2 * 4096 * 2 / 16) ? ((row >> 3) & 3) : ((row >> 2) & 3);  // wh64, wh32: rows of 8; wh16: rows of 4
     *reinterpret_cast<uint4*>(lds + L::HEADW_OFF + row * 64 + ((c ^ sw) << 4)) = reinterpret_cast<const uint4*>(W.whead)[i];
+  }
+  if (I8) {
+    // the i8 form runs the 16- and 32-level heads on v_mfma_i32_16x16x64_i8 (P4): B operand = [K step j = position (py, px) of a 16x16
+    // block][column n][64 channels], columns 0, 1 = the 16-level classes, 2 + 2 sub + class = the 32-level weights of a block at
+    // sub-position sub = (by & 1, bx & 1) of its quadrant: 16 steps x 10 columns x 64 B = the same 10 240 B, in MFMA order
+    for (int i = tid; i < HEADM_BYTES / 16; i += 256) {
+      const int j = i / 40, rem = i - j * 40, n = rem >> 2, kg = rem & 3;
+      int src;
+      if (n < 2) src = 16384 + (n * 16 + j) * 64;
+      else {
+        const int sub = (n - 2) >> 1, cls = n & 1, py = j >> 2, px = j & 3;
+        src = 8192 + (cls * 64 + ((sub >> 1) * 4 + py) * 8 + (sub & 1) * 4 + px) * 64;
+      }
+      *reinterpret_cast<uint4*>(lds + L::HEADW_OFF + HEADM_OFF + i * 16) = *reinterpret_cast<const uint4*>(W.whead + src + kg * 16);
+    }
   }
 
   const int band_rows = F.row_end - F.row_begin;
@@ -839,6 +855,16 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
     const unsigned w64_0 = (unsigned)((y >> 1) * 8 + (x >> 1)) * 64 + (sw64 << 4);  // 2x2 sum pool: four positions share a weight row
     head_addr = make_uint2(a_0 | (w16_0 << 16), w32_0 | (w64_0 << 16));
   }
+  // the i8 form's MFMA heads: lane (m = lane & 15, kg = lane >> 4) reads, as the A operand, channels 16 kg .. of position (py = wave, px = step)
+  // of block m = (by, bx) (chunk swizzle of that position = bx), and as the B operand column min(m, 9) of K step 4 wave + px
+  unsigned headm_addr = 0;
+  if (I8) {
+    const int m = lane & 15, kg = lane >> 4, by = m >> 2, bx = m & 3;
+    const unsigned am = (unsigned)((4 * by + wave) * 16 + 4 * bx) * 64 + ((unsigned)(kg ^ bx) << 4);
+    const unsigned bm = (unsigned)(HEADM_OFF + 4 * wave * HEADM_STEP + min(m, 9) * 64 + 16 * kg);
+    headm_addr = am | (bm << 16);
+  }
+  (void)headm_addr;
   int had_set = 0;  // which of the two sets of per-wave Hadamard sums belongs to the CTU in flight
   if (vblock < total) {  // prologue: first CTU of this workgroup
     stage_ctu(lds, L::R2_OFF, pre, F, pos, tid, ld_row, ld_seg, shift_in, hc.in);
@@ -919,6 +945,8 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
       unsigned a2cells = hc.a2;
       asm volatile("" : "+v"(a2cells));
       *reinterpret_cast<uint4*>(lds + (a2cells & 0xFFFF)) = make_uint4(Z, Z, Z, Z);
+      // the 32- and 16-level logits start from their head biases: P4's MFMA heads add to them (the previous CTU's readers are two barriers back)
+      if (tid < 40) logitL[2 + tid] = tid < 8 ? ((tid & 1) ? hb32b : hb32a) : ((tid & 1) ? hb16b : hb16a);
       // lane -> pooled position as in the 16-bit form below; the lane half picks the input row of a tap pair (ky = 2 q + h)
       const int q = r >> 2;
       const int pr = (q ^ (q >> 1) ^ (q >> 2)) & 1, pc = ((r >> 3) << 2) | (r & 3);
@@ -1075,6 +1103,50 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
         for (int s = 0; s < 6; ++s) wA2[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(f2 + s * 64 * 16));
       }
     }
+    if constexpr (I8) {
+      FHEVC_PHASE_IDS
+      // 16- and 32-level heads as ONE GEMM on v_mfma_i32_16x16x64_i8: rows = the 16 blocks of the CTU, K step = one position of a block x
+      // 64 channels (this wave: the four positions of block row py = wave), columns = the weight variants (see the prologue).  D: lane
+      // (n = lane & 15, rg = lane >> 4), register i = block (by = rg, bx = i), column n: partial sums over this wave's positions
+      unsigned hm = headm_addr, ha0 = head_addr.x, ha1 = head_addr.y;
+      asm volatile("" : "+v"(hm), "+v"(ha0), "+v"(ha1));
+      const unsigned char* hw = lds + L::HEADW_OFF;
+      const unsigned char* ap = lds + A3_OFF + (hm & 0xFFFFu);
+      const unsigned char* bp = hw + (hm >> 16);
+      i32x4 hacc = { 0, 0, 0, 0 };
+#pragma unroll
+      for (int px = 0; px < 4; ++px)
+        hacc = __builtin_amdgcn_mfma_i32_16x16x64_i8(*reinterpret_cast<const i32x4*>(ap + px * 64), *reinterpret_cast<const i32x4*>(bp + px * HEADM_STEP), hacc, 0, 0, 0);
+      // 64-level head (unique weights per position: nothing for an MFMA to reuse) on v_dot4_i32_i8, the lane = one position of quadrant `wave`
+      const unsigned a_0 = ha0 & 0xFFFFu, w64_0 = ha1 >> 16;
+      int s64a = 0, s64b = 0;
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        const uint4 a = *reinterpret_cast<const uint4*>(lds + A3_OFF + (a_0 ^ (qq << 4)));
+        const unsigned char* w64 = hw + HEAD64_OFF + (w64_0 ^ (qq << 4));
+        const uint4 d0 = *reinterpret_cast<const uint4*>(w64), d1 = *reinterpret_cast<const uint4*>(w64 + 4096);
+        s64a = sdot4(a.x, d0.x, s64a); s64a = sdot4(a.y, d0.y, s64a); s64a = sdot4(a.z, d0.z, s64a); s64a = sdot4(a.w, d0.w, s64a);
+        s64b = sdot4(a.x, d1.x, s64b); s64b = sdot4(a.y, d1.y, s64b); s64b = sdot4(a.z, d1.z, s64b); s64b = sdot4(a.w, d1.w, s64b);
+      }
+      // the MFMA's partial sums join the logits (initialised to the head biases in P3) by LDS atomic adds: columns 0, 1 every block's
+      // 16-level logit, column 2 + 2 sub + class the 32-level logit of the quadrant -- only from the blocks that sit at sub-position sub
+      {
+        const int n = lane & 15, rg = lane >> 4, subn = (n - 2) >> 1;
+        const bool is16 = n < 2, is32 = n >= 2 && n < 10 && ((rg & 1) == (subn >> 1));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const bool act = is16 || (is32 && ((i & 1) == (subn & 1)));
+          const int idx = is16 ? 2 * (5 + 4 * rg + i) + n : 2 * (1 + (rg >> 1) * 2 + (i >> 1)) + (n & 1);
+          if (act) atomicAdd(logitL + idx, hacc[i]);
+        }
+      }
+      const int r64a = dpp_row_sum(s64a), r64b = dpp_row_sum(s64b);
+      const int q64a = __builtin_amdgcn_readlane(r64a, 0) + __builtin_amdgcn_readlane(r64a, 16) +
+                       __builtin_amdgcn_readlane(r64a, 32) + __builtin_amdgcn_readlane(r64a, 48);
+      const int q64b = __builtin_amdgcn_readlane(r64b, 0) + __builtin_amdgcn_readlane(r64b, 16) +
+                       __builtin_amdgcn_readlane(r64b, 32) + __builtin_amdgcn_readlane(r64b, 48);
+      if (lane == 0) *reinterpret_cast<int2*>(logitL + 44 + 2 * wave) = make_int2(q64a, q64b);  // the readers add the four waves' parts
+    } else
     {
       FHEVC_PHASE_IDS
       // wave = 32x32 quadrant q; 16-lane DPP row = one 16x16 block of it; lane bits [1:0] = x & 3, [3:2] = y & 3 (head_addr)
