@@ -335,6 +335,13 @@ def test_errors_are_status_codes():
     odd.close()
     with pytest.raises(capi.FastHevcError):
         capi.Context(416, 240, 7)
+    # arithmetic form of the classifier: i8 by default, f16 on request, anything else is a status code
+    c2 = capi.Context(416, 240, 8)
+    assert c2.cnn_arith == "i8"
+    c2.set_cnn_arith("f16")
+    assert c2.cnn_arith == "f16"
+    assert c2.lib.fhevc_set_cnn_arith(c2.h, 4) == capi.E_INVALID and c2.cnn_arith == "f16"
+    c2.close()
 
 
 def _oracle_first_pass_all(oracle, buf, org, stride, W, H, bd, qp, ctus):
