@@ -52,6 +52,9 @@ constexpr int IN_PITCH = 68;                      // dwords per input row PAIR (
 //   I8 = false: f16 (16-bit MFMAs): A1 = 2 planes of 8 channels, A2 = 4 planes of 8 channels;
 //   I8 = true : signed bytes a - 128 (v_mfma_i32_32x32x32_i8 in conv2 and conv3): A1 = 1 plane of 16 channels (+ one phantom row that
 //               only zero weights meet), A2 = 2 planes of 16 channels -- half the LDS, which is what lets three workgroups share a CU
+#ifndef FHEVC_MFMA_HEADS_F16
+#define FHEVC_MFMA_HEADS_F16 0  // the 16-bit form keeps its v_dot4 heads: with the MFMA heads it measured the same (0.5756 against 0.5767 ms, parity green)
+#endif
 #ifndef FHEVC_I8_WG_PER_CU
 #define FHEVC_I8_WG_PER_CU 3
 #endif
@@ -753,6 +756,7 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   constexpr bool I8 = ARITH != 0, FASTRQ = ARITH == 2;
+  constexpr bool MFMA_HEADS = FHEVC_MFMA_HEADS_F16 || I8;  // the two smaller FC heads as an i8 MFMA GEMM (P4)
   (void)FASTRQ;
   using L = Lds<I8>;
   const HaloCells hc = halo_cells<I8>(tid);  // three registers for the life of the kernel
@@ -796,13 +800,13 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
   }
   // head weights stay in LDS for the life of the workgroup; the four 16-B chunks of a 64-B row are XOR-swizzled by
   // the row so that the 16 lanes of a ds_read_b128 group (a 4x4 block of positions) hit 16 distinct slots
-  for (int i = tid; i < (I8 ? 8192 : 18432) / 16; i += 256) {
+  for (int i = tid; i < (MFMA_HEADS ? 8192 : 18432) / 16; i += 256) {
     const int row = i >> 2, c = i & 3;
     const int sw = (i < 2 * 4096 * 2 / 16) ? ((row >> 3) & 3) : ((row >> 2) & 3);  // wh64, wh32: rows of 8; wh16: rows of 4
     *reinterpret_cast<uint4*>(lds + L::HEADW_OFF + row * 64 + ((c ^ sw) << 4)) = reinterpret_cast<const uint4*>(W.whead)[i];
   }
-  if (I8) {
-    // the i8 form runs the 16- and 32-level heads on v_mfma_i32_16x16x64_i8 (P4): B operand = [K step j = position (py, px) of a 16x16
+  if (MFMA_HEADS) {
+    // the 16- and 32-level heads run on v_mfma_i32_16x16x64_i8 (P4; both arithmetic forms: conv3's output is bytes in either): B operand = [K step j = position (py, px) of a 16x16
     // block][column n][64 channels], columns 0, 1 = the 16-level classes, 2 + 2 sub + class = the 32-level weights of a block at
     // sub-position sub = (by & 1, bx & 1) of its quadrant: 16 steps x 10 columns x 64 B = the same 10 240 B, in MFMA order
     for (int i = tid; i < HEADM_BYTES / 16; i += 256) {
@@ -858,7 +862,7 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
   // the i8 form's MFMA heads: lane (m = lane & 15, kg = lane >> 4) reads, as the A operand, channels 16 kg .. of position (py = wave, px = step)
   // of block m = (by, bx) (chunk swizzle of that position = bx), and as the B operand column min(m, 9) of K step 4 wave + px
   unsigned headm_addr = 0;
-  if (I8) {
+  if (MFMA_HEADS) {
     const int m = lane & 15, kg = lane >> 4, by = m >> 2, bx = m & 3;
     const unsigned am = (unsigned)((4 * by + wave) * 16 + 4 * bx) * 64 + ((unsigned)(kg ^ bx) << 4);
     const unsigned bm = (unsigned)(HEADM_OFF + 4 * wave * HEADM_STEP + min(m, 9) * 64 + 16 * kg);
@@ -981,6 +985,7 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
       // the input tile is dead: zero the A2 halo (68 positions x 4 planes) while conv2 fills the interior
       *reinterpret_cast<uint4*>(lds + (hc.a2 & 0xFFFF)) = make_uint4(0, 0, 0, 0);
       if (tid < 272 - 256) *reinterpret_cast<uint4*>(lds + (hc.a2 >> 16)) = make_uint4(0, 0, 0, 0);
+      if (MFMA_HEADS && tid < 40) logitL[2 + tid] = tid < 8 ? ((tid & 1) ? hb32b : hb32a) : ((tid & 1) ? hb16b : hb16a);  // see the i8 form above
       // lane -> pooled position: the 32 columns of a B operand are two pooled rows (pr) x 16 pooled columns (pc), assigned so
       // that each 16-lane group of a ds_read_b128 ({0-3, 12-15, 20-27} and {4-11, 16-19, 28-31}) is one row's 16 columns =
       // 256 contiguous bytes (conflict-free whatever the row pitch)
@@ -1103,7 +1108,7 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
         for (int s = 0; s < 6; ++s) wA2[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(f2 + s * 64 * 16));
       }
     }
-    if constexpr (I8) {
+    if constexpr (MFMA_HEADS) {
       FHEVC_PHASE_IDS
       // 16- and 32-level heads as ONE GEMM on v_mfma_i32_16x16x64_i8: rows = the 16 blocks of the CTU, K step = one position of a block x
       // 64 channels (this wave: the four positions of block row py = wave), columns = the weight variants (see the prologue).  D: lane
