@@ -492,7 +492,12 @@ def main():
             "value": value, "unit": "CTU/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
-            "dtype": ARITH_DTYPE[arith], "data": "synthetic",
+            "dtype": ARITH_DTYPE[arith],
+            "dtype_note": ("the classifier is an exact integer network (int8 weights, 8-bit activations): since round 2 the library's default runs conv2 / conv3 on the "
+                           "i8 MFMAs instead of the 16-bit ones -- the same integers out, bit for bit (every GPU parity test runs both forms); this is a change of the "
+                           "headline's arithmetic type, not of its precision; \"variants\" times the other form in the same process and prices each form against its "
+                           "own dense MFMA peak; --arith f16 makes the 16-bit form (round 1's) the headline"),
+            "data": "synthetic",
             "config": {"workload": f"{geom} {W}x{H} all-intra QP32, GOP of {total_frames} synthetic 'hetero' frames "
                                    f"({'int16 Pel planes, HM stride/margins' if sample_b == 2 else 'uint8 planes'}) resident in HBM, "
                                    f"source Hadamard + CTU-batched CNN depth predictor, {wdesc}",
