@@ -73,6 +73,22 @@ def test_predict_frame_416x240(oracle, golden, bd, seed, extreme, cnn_arith):
     ctx.close()
 
 
+@pytest.mark.parametrize("shifts", [(6, 7, 8), (6, 8, 7), (5, 3, 8), (7, 7, 1), (6, 0, 14), (4, 8, 8)])
+def test_requant_shifts_of_the_i8_form(oracle, shifts):
+    """The i8 form's requant has three forms (k_cnn.hip: requant4_i8) chosen from the blob's shifts and accumulator bounds: shifts
+    (6, 7, 8) with small weights take the short ones, every other combination the general one; all must floor and clamp as the oracle does."""
+    w = weights.random_weights(11)
+    w["shift"] = np.array(shifts, np.int32)
+    luma = frames.hetero_luma(416, 240)
+    buf, org, stride, depth_ref, logits_ref, had_ref = _oracle_frame(oracle, w, luma, 8, qp=27)
+    for arith in ("i8", "f16"):
+        ctx = capi.Context(416, 240, 8, w, arith=arith)
+        depth, had = ctx.predict_frame(buf, org, stride, qp=27)
+        assert np.array_equal(depth, depth_ref), (shifts, arith)
+        assert np.array_equal(had, had_ref)
+        ctx.close()
+
+
 @pytest.mark.parametrize("which", ["random", "trained"])
 def test_predict_frame_1080p_hetero(oracle, golden, which, cnn_arith):
     """config 2 geometry, the heterogeneous content: 510 CTUs, last row 56 px tall; random-init and shipped weights."""
