@@ -55,6 +55,20 @@ constexpr int IN_PITCH = 68;                      // dwords per input row PAIR (
 #ifndef FHEVC_MFMA_HEADS_F16
 #define FHEVC_MFMA_HEADS_F16 0  // the 16-bit form keeps its v_dot4 heads: with the MFMA heads it measured the same (0.5756 against 0.5767 ms, parity green)
 #endif
+// Phases that run at raised wave priority (s_setprio; bit 0 conv2, bit 1 conv3, bit 2 conv1, bit 3 heads).  With three workgroups per
+// CU the i8 form gains 4 % when its three conv phases outrank the heads / staging / depth phases of the other workgroups' waves on the
+// same SIMD (same-box A/B: none 0.4440, conv2+conv3 0.4336, +conv1 0.4285 at level 1 and 0.4262 at level 2, +heads 0.4355 ms)
+#ifndef FHEVC_I8_PRIO
+#define FHEVC_I8_PRIO 7
+#endif
+#ifndef FHEVC_F16_PRIO
+#define FHEVC_F16_PRIO 7  // the 16-bit form (two workgroups per CU) gains 3.5 % from the same setting (0.5828 -> 0.5624 ms; conv2+conv3 only: 0.5720)
+#endif
+#ifndef FHEVC_PRIO_LEVEL
+#define FHEVC_PRIO_LEVEL 2
+#endif
+#define FHEVC_PRIO_ON(bit)  if ((I8 ? FHEVC_I8_PRIO : FHEVC_F16_PRIO) & (bit)) __builtin_amdgcn_s_setprio(FHEVC_PRIO_LEVEL);
+#define FHEVC_PRIO_OFF(bit) if ((I8 ? FHEVC_I8_PRIO : FHEVC_F16_PRIO) & (bit)) __builtin_amdgcn_s_setprio(0);
 #ifndef FHEVC_I8_WG_PER_CU
 #define FHEVC_I8_WG_PER_CU 3
 #endif
@@ -907,6 +921,7 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
     // ====== P1: conv1 (1 -> 16): one MFMA per 32 positions x 2 rows, K = 4x3 window, fused maxpool + requant ======
     {
       FHEVC_PHASE_IDS
+      FHEVC_PRIO_ON(4)
       // unit = one pooled row of 32 positions (picture rows 2yp, 2yp+1, all 64 columns); lane (n, h): pooled column n,
       // K slots = the 4x4 input window of the 2x2 pre-pool outputs: lanes h=0 hold window columns 0-1, h=1 columns 2-3,
       // each column as two row-pair dwords -> the fragment is two ds_read_b64, all 16 K slots carry data
@@ -938,6 +953,7 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
         else conv1_store(acc0, acc1, dp);
         dp += 4 * A1_ROW;
       }
+      FHEVC_PRIO_OFF(4)
     }
     __syncthreads();
     FHEVC_STAMP(1)
@@ -945,6 +961,7 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
     // ================= P2: conv2 (16 -> 32), K = 9 taps x 16 ch, fused maxpool + requant =================
     if constexpr (I8) {
       FHEVC_PHASE_IDS
+      FHEVC_PRIO_ON(1)
       constexpr unsigned Z = L::HALO_FILL;  // the input tile is dead: "activation 0" into the A2 halo (68 positions x 2 planes)
       unsigned a2cells = hc.a2;
       asm volatile("" : "+v"(a2cells));
@@ -980,8 +997,10 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
       __builtin_amdgcn_sched_barrier(0);
       pool_v_i8(t1, a1, t0);
       conv2_requant_store_i8m<FASTRQ ? 1 : 0>(t1, a2dst + (2 * u1) * A2_PITCH * 16, shift2);
+      FHEVC_PRIO_OFF(1)
     } else {
       FHEVC_PHASE_IDS
+      FHEVC_PRIO_ON(1)
       // the input tile is dead: zero the A2 halo (68 positions x 4 planes) while conv2 fills the interior
       *reinterpret_cast<uint4*>(lds + (hc.a2 & 0xFFFF)) = make_uint4(0, 0, 0, 0);
       if (tid < 272 - 256) *reinterpret_cast<uint4*>(lds + (hc.a2 >> 16)) = make_uint4(0, 0, 0, 0);
@@ -1019,6 +1038,7 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
       __builtin_amdgcn_sched_barrier(0);
       conv2_pool_v(t1, a1, t0);
       conv2_requant_store(t1, a2dst + (2 * u1) * A2_PITCH * 16);
+      FHEVC_PRIO_OFF(1)
     }
     __syncthreads();
     FHEVC_STAMP(2)
@@ -1027,6 +1047,7 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
     pre = prefetch_ctu<HAD>(F, work + (int)gridDim.x < total, next, ld_row, ld_seg);  // next CTU's samples travel under conv3 and the heads
     if constexpr (I8) {
       FHEVC_PHASE_IDS
+      FHEVC_PRIO_ON(2)
       const int x = lane & 15, rs = (lane >> 4) & 1;  // B column n = lane & 31: row 8 rs of the pair, position x; lane half h = activation plane
       const int y0 = 2 * (wave >> 1);                 // this wave's row pairs: y0 + {0, 1, 4, 5} + {0, 8}
       const unsigned char* a2 = lds + L::R2_OFF + h * A2_PLANE + ((y0 + 8 * rs) * A2_PITCH + x) * 16;
@@ -1045,8 +1066,10 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
       sched_pairs18_i8<4>();
       conv3_store_i8m<FASTRQ ? 2 : 0>(q0, a3dst + conv3_pair_row_i8(2) * 1024, tile3, psw, shift3);
       conv3_store_i8m<FASTRQ ? 2 : 0>(q1, a3dst + conv3_pair_row_i8(3) * 1024, tile3, psw, shift3);
+      FHEVC_PRIO_OFF(2)
     } else {
       FHEVC_PHASE_IDS
+      FHEVC_PRIO_ON(2)
       const int x = lane & 15, kg = lane >> 4;  // B column = position x of the row, K group = activation plane kg; D rows 4 kg ..
       const int y0 = 2 * (wave >> 1);           // this wave's rows: y0 + {0, 1, 4, 5, 8, 9, 12, 13} (+ {2, 3, ...} for the next wave pair)
       const unsigned char* a2 = lds + L::R2_OFF + kg * A2_PLANE + (y0 * A2_PITCH + x) * 16;
@@ -1084,6 +1107,7 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
       conv3_store(p0, p1, a3dst + FHEVC_ROW_OFF(6), tile3, psw);
       sched_row18();
       conv3_store(q0, q1, a3dst + FHEVC_ROW_OFF(7), tile3, psw);
+      FHEVC_PRIO_OFF(2)
 #undef FHEVC_ROW_OFF
     }
     if (HAD) {  // the next CTU's source Hadamard from its samples in flight: VALU work at the tail of the MFMA-bound phase
@@ -1110,6 +1134,7 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
     }
     if constexpr (MFMA_HEADS) {
       FHEVC_PHASE_IDS
+      FHEVC_PRIO_ON(8)
       // 16- and 32-level heads as ONE GEMM on v_mfma_i32_16x16x64_i8: rows = the 16 blocks of the CTU, K step = one position of a block x
       // 64 channels (this wave: the four positions of block row py = wave), columns = the weight variants (see the prologue).  D: lane
       // (n = lane & 15, rg = lane >> 4), register i = block (by = rg, bx = i), column n: partial sums over this wave's positions
@@ -1151,6 +1176,7 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
       const int q64b = __builtin_amdgcn_readlane(r64b, 0) + __builtin_amdgcn_readlane(r64b, 16) +
                        __builtin_amdgcn_readlane(r64b, 32) + __builtin_amdgcn_readlane(r64b, 48);
       if (lane == 0) *reinterpret_cast<int2*>(logitL + 44 + 2 * wave) = make_int2(q64a, q64b);  // the readers add the four waves' parts
+      FHEVC_PRIO_OFF(8)
     } else
     {
       FHEVC_PHASE_IDS
