@@ -55,20 +55,20 @@ constexpr int IN_PITCH = 68;                      // dwords per input row PAIR (
 #ifndef FHEVC_MFMA_HEADS_F16
 #define FHEVC_MFMA_HEADS_F16 0  // the 16-bit form keeps its v_dot4 heads: with the MFMA heads it measured the same (0.5756 against 0.5767 ms, parity green)
 #endif
-// Phases that run at raised wave priority (s_setprio; bit 0 conv2, bit 1 conv3, bit 2 conv1, bit 3 heads).  With three workgroups per
-// CU the i8 form gains 4 % when its three conv phases outrank the heads / staging / depth phases of the other workgroups' waves on the
-// same SIMD (same-box A/B: none 0.4440, conv2+conv3 0.4336, +conv1 0.4285 at level 1 and 0.4262 at level 2, +heads 0.4355 ms)
+// Wave priority per phase (s_setprio 0..3), one hex digit each: 0x<heads><conv3><conv2><conv1>.  With three workgroups per CU the i8
+// form gains 4 % when its three conv phases outrank the heads / staging / depth phases of the other workgroups' waves on the same SIMD
+// (same-box A/B: none 0.4440, conv2+conv3 0.4336, +conv1 0.4285 at level 1 and 0.4262 at level 2, +heads 0.4355 ms); the 16-bit form
+// (two workgroups per CU) gains 3.5 % from the same setting (0.5828 -> 0.5624 ms; conv2+conv3 only: 0.5720)
 #ifndef FHEVC_I8_PRIO
-#define FHEVC_I8_PRIO 7
+#define FHEVC_I8_PRIO 0x0222
 #endif
 #ifndef FHEVC_F16_PRIO
-#define FHEVC_F16_PRIO 7  // the 16-bit form (two workgroups per CU) gains 3.5 % from the same setting (0.5828 -> 0.5624 ms; conv2+conv3 only: 0.5720)
+#define FHEVC_F16_PRIO 0x0222
 #endif
-#ifndef FHEVC_PRIO_LEVEL
-#define FHEVC_PRIO_LEVEL 2
-#endif
-#define FHEVC_PRIO_ON(bit)  if ((I8 ? FHEVC_I8_PRIO : FHEVC_F16_PRIO) & (bit)) __builtin_amdgcn_s_setprio(FHEVC_PRIO_LEVEL);
-#define FHEVC_PRIO_OFF(bit) if ((I8 ? FHEVC_I8_PRIO : FHEVC_F16_PRIO) & (bit)) __builtin_amdgcn_s_setprio(0);
+// phase: 0 conv1, 1 conv2, 2 conv3, 3 heads
+#define FHEVC_PRIO_OF(phase) (((I8 ? FHEVC_I8_PRIO : FHEVC_F16_PRIO) >> (4 * (phase))) & 3)
+#define FHEVC_PRIO_ON(phase)  if (FHEVC_PRIO_OF(phase)) __builtin_amdgcn_s_setprio(FHEVC_PRIO_OF(phase));
+#define FHEVC_PRIO_OFF(phase) if (FHEVC_PRIO_OF(phase)) __builtin_amdgcn_s_setprio(0);
 #ifndef FHEVC_I8_WG_PER_CU
 #define FHEVC_I8_WG_PER_CU 3
 #endif
@@ -921,7 +921,7 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
     // ====== P1: conv1 (1 -> 16): one MFMA per 32 positions x 2 rows, K = 4x3 window, fused maxpool + requant ======
     {
       FHEVC_PHASE_IDS
-      FHEVC_PRIO_ON(4)
+      FHEVC_PRIO_ON(0)
       // unit = one pooled row of 32 positions (picture rows 2yp, 2yp+1, all 64 columns); lane (n, h): pooled column n,
       // K slots = the 4x4 input window of the 2x2 pre-pool outputs: lanes h=0 hold window columns 0-1, h=1 columns 2-3,
       // each column as two row-pair dwords -> the fragment is two ds_read_b64, all 16 K slots carry data
@@ -953,7 +953,7 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
         else conv1_store(acc0, acc1, dp);
         dp += 4 * A1_ROW;
       }
-      FHEVC_PRIO_OFF(4)
+      FHEVC_PRIO_OFF(0)
     }
     __syncthreads();
     FHEVC_STAMP(1)
@@ -1134,7 +1134,7 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
     }
     if constexpr (MFMA_HEADS) {
       FHEVC_PHASE_IDS
-      FHEVC_PRIO_ON(8)
+      FHEVC_PRIO_ON(3)
       // 16- and 32-level heads as ONE GEMM on v_mfma_i32_16x16x64_i8: rows = the 16 blocks of the CTU, K step = one position of a block x
       // 64 channels (this wave: the four positions of block row py = wave), columns = the weight variants (see the prologue).  D: lane
       // (n = lane & 15, rg = lane >> 4), register i = block (by = rg, bx = i), column n: partial sums over this wave's positions
@@ -1176,7 +1176,7 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
       const int q64b = __builtin_amdgcn_readlane(r64b, 0) + __builtin_amdgcn_readlane(r64b, 16) +
                        __builtin_amdgcn_readlane(r64b, 32) + __builtin_amdgcn_readlane(r64b, 48);
       if (lane == 0) *reinterpret_cast<int2*>(logitL + 44 + 2 * wave) = make_int2(q64a, q64b);  // the readers add the four waves' parts
-      FHEVC_PRIO_OFF(8)
+      FHEVC_PRIO_OFF(3)
     } else
     {
       FHEVC_PHASE_IDS
