@@ -171,7 +171,14 @@ int build_weight_image(fhevc_ctx* c, const BlobView& b)
     for (int j = 0; j < 8; ++j)
       for (int t = 0; t < 2; ++t)
         for (int s = 0; s < 18; ++s) {
+#if FHEVC_F16_CONV3_32
+          // v_mfma_f32_32x32x16_f16: lane (row = lane & 31, h = lane >> 5) holds A[row][8 h + j]; fragment s = 2 tap + c2: K = the tap's
+          // channels 16 c2 .. 16 c2 + 15, rows = the tile's 32 output channels
+          (void)m; (void)kg;
+          const int oc = 32 * t + (lane & 31), ic = 16 * (s & 1) + 8 * (lane >> 5) + j, tap = s >> 1;
+#else
           const int oc = 32 * t + 16 * (s / 9) + m, ic = 8 * kg + j, tap = s % 9;
+#endif
           put_scaled(2, FHEVC_FRAG_CONV3 + (t * 18 + s) * 64, lane, j, b.w3[(oc * 32 + ic) * 9 + tap]);
         }
   }

@@ -16,6 +16,12 @@
 #define FHEVC_FRAG_CONV2 128
 #define FHEVC_FRAG_CONV3 (128 + 9 * 64)
 #define FHEVC_FRAG_TOTAL (128 + 9 * 64 + 2 * 18 * 64)
+// conv3 of the 16-bit form: 0 = v_mfma_f32_16x16x32_f16 (M tiles of 16 channels, one output row per chain), 1 = v_mfma_f32_32x32x16_f16
+// (the wave's 32 channels x two output rows 8 apart per MFMA, K step = one tap x 16 channels).  The fragment image differs:
+// kernel and build_weight_image read this switch
+#ifndef FHEVC_F16_CONV3_32
+#define FHEVC_F16_CONV3_32 0  // measured equal (0.5624 against 0.5659 ms on one box, parity green): the 16x16x32 form stays
+#endif
 // the i8 variant's fragments (one uint4 = 16 signed bytes per lane): conv2 [2 row pairs][3 columns of taps][64], conv3 [2 tiles][9 taps][64]
 #define FHEVC_FRAGI8_CONV2 0
 #define FHEVC_FRAGI8_CONV3 (6 * 64)

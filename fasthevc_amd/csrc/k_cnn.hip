@@ -497,6 +497,52 @@ __device__ __forceinline__ void sched_pairs18_i8()
     if (VALU_PER_GROUP > 0) __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_GROUP, 0);
   }
 }
+// conv3 of the 16-bit form on v_mfma_f32_32x32x16_f16 (FHEVC_F16_CONV3_32): one MFMA = one tap x 16 input channels (lane half h = plane
+// 2 c2 + h) x the wave's 32 output channels x TWO output rows 8 apart (the mapping of the i8 form: conflict-free ds_read_b128 groups);
+// 18 MFMAs and 18 reads per row pair, two row pairs interleaved (two accumulators), fragment g = 36 S + 2 step + (pair & 1)
+__device__ __forceinline__ constexpr int conv3_frag_off_f32(int g)
+{
+  const int k = 2 * (g / 36) + (g & 1), st = (g % 36) / 2, t = st >> 1, c2 = st & 1;
+  return 2 * c2 * A2_PLANE + ((conv3_pair_row_i8(k) + t / 3) * A2_PITCH + t % 3) * 16;
+}
+template <int S>
+__device__ __forceinline__ void conv3_pairs_f32(const unsigned char* base, const bf16x8 (&wA3)[18], bf16x8 (&ring)[RING3], const f32x16& binit,
+                                                f32x16& acc0, f32x16& acc1)
+{
+  acc0 = binit;
+  acc1 = binit;
+  if (S == 0) {
+#pragma unroll
+    for (int g = 0; g < RING3; ++g) ring[g] = lds_frag(base + conv3_frag_off_f32(g));
+  }
+#pragma unroll
+  for (int st = 0; st < 18; ++st) {
+    const int g = 36 * S + 2 * st;
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wA3[st]), __builtin_bit_cast(f16x8, ring[g % RING3]), acc0, 0, 0, 0);
+    if (g + RING3 < 72) ring[g % RING3] = lds_frag(base + conv3_frag_off_f32(g + RING3));
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wA3[st]), __builtin_bit_cast(f16x8, ring[(g + 1) % RING3]), acc1, 0, 0, 0);
+    if (g + 1 + RING3 < 72) ring[(g + 1) % RING3] = lds_frag(base + conv3_frag_off_f32(g + 1 + RING3));
+  }
+}
+template <int VALU_PER_GROUP>
+__device__ __forceinline__ void sched_pairs36_f32()
+{
+#pragma unroll
+  for (int i = 0; i < 36; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    if (VALU_PER_GROUP > 0) __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_GROUP, 0);
+  }
+}
+// its epilogue: reg i -> channel 32 tile + (i & 3) + 8 g + 4 h of the lane's position: v_cvt_pk_u8_f32 (floor + clamp under the round-down
+// mode), a - 128, one dword per g at chunk 2 tile + (g >> 1), bytes 8 (g & 1) + 4 h
+__device__ __forceinline__ void conv3_store_f32(const f32x16& acc, unsigned char* dst, int tile, int psw)
+{
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    *reinterpret_cast<unsigned*>(dst + (((2 * tile + (g >> 1)) ^ psw) << 4) + 8 * (g & 1)) =
+        u8x4_floor_clamp(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]) ^ 0x80808080u;
+}
 // One thread's 16 samples of a CTU (picture row ld_row, columns 16*ld_seg..) fetched ahead of use.  fast = 0:
 // picture edge or unaligned plane, P0 falls back to guarded scalar loads.
 struct Prefetched { uint4 a, b; int fast; };
@@ -1066,6 +1112,27 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
       sched_pairs18_i8<4>();
       conv3_store_i8m<FASTRQ ? 2 : 0>(q0, a3dst + conv3_pair_row_i8(2) * 1024, tile3, psw, shift3);
       conv3_store_i8m<FASTRQ ? 2 : 0>(q1, a3dst + conv3_pair_row_i8(3) * 1024, tile3, psw, shift3);
+      FHEVC_PRIO_OFF(2)
+    } else if constexpr (FHEVC_F16_CONV3_32 != 0) {
+      FHEVC_PHASE_IDS
+      FHEVC_PRIO_ON(2)
+      const int x = lane & 15, rs = (lane >> 4) & 1;  // B column n = lane & 31: row 8 rs of the pair, position x; lane half h = plane 2 c2 + h
+      const int y0 = 2 * (wave >> 1);                 // this wave's row pairs: y0 + {0, 1, 4, 5} + {0, 8}
+      const unsigned char* a2 = lds + L::R2_OFF + h * A2_PLANE + ((y0 + 8 * rs) * A2_PITCH + x) * 16;
+      const int psw = (x >> 2) & 3;
+      unsigned char* a3dst = lds + A3_OFF + ((y0 + 8 * rs) * 16 + x) * 64 + 4 * h;
+      const f32x16 b3t = bias_tile(biasL + 48 + 32 * tile3, h);
+      bf16x8 ring[RING3];
+      f32x16 p0, p1, q0, q1;
+      conv3_pairs_f32<0>(a2, wA3, ring, b3t, p0, p1);
+      __builtin_amdgcn_sched_group_barrier(0x100, RING3 + 4, 0);
+      sched_pairs36_f32<0>();
+      conv3_pairs_f32<1>(a2, wA3, ring, b3t, q0, q1);
+      conv3_store_f32(p0, a3dst + conv3_pair_row_i8(0) * 1024, tile3, psw);
+      conv3_store_f32(p1, a3dst + conv3_pair_row_i8(1) * 1024, tile3, psw);
+      sched_pairs36_f32<1>();
+      conv3_store_f32(q0, a3dst + conv3_pair_row_i8(2) * 1024, tile3, psw);
+      conv3_store_f32(q1, a3dst + conv3_pair_row_i8(3) * 1024, tile3, psw);
       FHEVC_PRIO_OFF(2)
     } else {
       FHEVC_PHASE_IDS
