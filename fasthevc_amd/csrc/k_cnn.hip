@@ -69,6 +69,33 @@ constexpr int IN_PITCH = 68;                      // dwords per input row PAIR (
 #define FHEVC_PRIO_OF(phase) (((I8 ? FHEVC_I8_PRIO : FHEVC_F16_PRIO) >> (4 * (phase))) & 3)
 #define FHEVC_PRIO_ON(phase)  if (FHEVC_PRIO_OF(phase)) __builtin_amdgcn_s_setprio(FHEVC_PRIO_OF(phase));
 #define FHEVC_PRIO_OFF(phase) if (FHEVC_PRIO_OF(phase)) __builtin_amdgcn_s_setprio(0);
+// tuning knobs of the i8 form's pipeline descriptions (VALU instructions offered per MFMA group of a chain; fences around the pools).
+// conv2 measured best with the chains pinned as (MFMA, DS read) groups only and the epilogue VALU left to the scheduler, without
+// fences: 0.4322 ms (fences, 2 / 5 VALU per group) -> 0.4226 (no fences) -> 0.4212 (no fences, no VALU groups), same-box A/B
+#ifndef FHEVC_I8_C2_FILL_POOL
+#define FHEVC_I8_C2_FILL_POOL 0
+#endif
+#ifndef FHEVC_I8_C2_FILL_REQUANT
+#define FHEVC_I8_C2_FILL_REQUANT 0
+#endif
+#ifndef FHEVC_I8_C3_FILL
+#define FHEVC_I8_C3_FILL 4
+#endif
+#ifndef FHEVC_I8_C2_FENCE
+#define FHEVC_I8_C2_FENCE 0
+#endif
+#ifndef FHEVC_F16_C2_FILL_POOL
+#define FHEVC_F16_C2_FILL_POOL 1
+#endif
+#ifndef FHEVC_F16_C2_FILL_REQUANT
+#define FHEVC_F16_C2_FILL_REQUANT 3
+#endif
+#ifndef FHEVC_F16_C2_FENCE
+#define FHEVC_F16_C2_FENCE 1
+#endif
+#ifndef FHEVC_CONV1_UNROLL
+#define FHEVC_CONV1_UNROLL 2
+#endif
 #ifndef FHEVC_I8_WG_PER_CU
 #define FHEVC_I8_WG_PER_CU 3
 #endif
@@ -989,7 +1016,7 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
       const unsigned char* fp = inb + wave * (IN_PITCH * 4);
       unsigned char* dp = lds + R1_OFF + (I8 ? 8 * h : h * A1_PLANE) + (wave + 1) * A1_ROW + (((r + 1) & 1) ? 0 : A1_EVEN) + ((r + 1) >> 1) * 16;  // column r (halo +1)
       bf16x8 bq = early_bq;  // = frag1(fp), in flight since before the previous CTU's depth phase
-#pragma unroll 2
+#pragma unroll FHEVC_CONV1_UNROLL
       for (int i = 0; i < 8; ++i) {
         const f32x16 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA1a, bq, bias1, 0, 0, 0);
         const f32x16 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA1b, bq, bias1, 0, 0, 0);
@@ -1030,17 +1057,17 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
       sched_chain12_i8<0>();
       conv2_half_i8<false, false>(h00 + A1_ROW, h10, wA2, ring, b2t, h, a0, a1);
       pool_h_i8(t0, t1);
-      sched_chain12_i8<2>();
-      __builtin_amdgcn_sched_barrier(0);
+      sched_chain12_i8<FHEVC_I8_C2_FILL_POOL>();
+      if (FHEVC_I8_C2_FENCE) __builtin_amdgcn_sched_barrier(0);
       pool_v_i8(t0, a0, a1);
-      __builtin_amdgcn_sched_barrier(0);
+      if (FHEVC_I8_C2_FENCE) __builtin_amdgcn_sched_barrier(0);
       conv2_half_i8<false, false>(h10, h10 + A1_ROW, wA2, ring, b2t, h, t1, a0);
       conv2_requant_store_i8m<FASTRQ ? 1 : 0>(t0, a2dst + (2 * u0) * A2_PITCH * 16, shift2);
-      sched_chain12_i8<5>();
+      sched_chain12_i8<FHEVC_I8_C2_FILL_REQUANT>();
       conv2_half_i8<false, true>(h10 + A1_ROW, h10 + A1_ROW, wA2, ring, b2t, h, a1, t0);
       pool_h_i8(t1, a0);
-      sched_chain12_i8<2>();
-      __builtin_amdgcn_sched_barrier(0);
+      sched_chain12_i8<FHEVC_I8_C2_FILL_POOL>();
+      if (FHEVC_I8_C2_FENCE) __builtin_amdgcn_sched_barrier(0);
       pool_v_i8(t1, a1, t0);
       conv2_requant_store_i8m<FASTRQ ? 1 : 0>(t1, a2dst + (2 * u1) * A2_PITCH * 16, shift2);
       FHEVC_PRIO_OFF(1)
@@ -1071,17 +1098,17 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
       sched_chain18<0>();
       conv2_half<false, false>(h00 + A1_ROW, h10, wA2, ring, b2t, a0, a1);
       conv2_pool_h(t0, t1);
-      sched_chain18<1>();
-      __builtin_amdgcn_sched_barrier(0);
+      sched_chain18<FHEVC_F16_C2_FILL_POOL>();
+      if (FHEVC_F16_C2_FENCE) __builtin_amdgcn_sched_barrier(0);
       conv2_pool_v(t0, a0, a1);
-      __builtin_amdgcn_sched_barrier(0);
+      if (FHEVC_F16_C2_FENCE) __builtin_amdgcn_sched_barrier(0);
       conv2_half<false, false>(h10, h10 + A1_ROW, wA2, ring, b2t, t1, a0);  // (the registers of t1, a0, a1 are free again)
       conv2_requant_store(t0, a2dst + (2 * u0) * A2_PITCH * 16);
-      sched_chain18<3>();
+      sched_chain18<FHEVC_F16_C2_FILL_REQUANT>();
       conv2_half<false, true>(h10 + A1_ROW, h10 + A1_ROW, wA2, ring, b2t, a1, t0);
       conv2_pool_h(t1, a0);
-      sched_chain18<1>();
-      __builtin_amdgcn_sched_barrier(0);
+      sched_chain18<FHEVC_F16_C2_FILL_POOL>();
+      if (FHEVC_F16_C2_FENCE) __builtin_amdgcn_sched_barrier(0);
       conv2_pool_v(t1, a1, t0);
       conv2_requant_store(t1, a2dst + (2 * u1) * A2_PITCH * 16);
       FHEVC_PRIO_OFF(1)
@@ -1109,7 +1136,7 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
       __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
       conv3_store_i8m<FASTRQ ? 2 : 0>(p0, a3dst + conv3_pair_row_i8(0) * 1024, tile3, psw, shift3);
       conv3_store_i8m<FASTRQ ? 2 : 0>(p1, a3dst + conv3_pair_row_i8(1) * 1024, tile3, psw, shift3);
-      sched_pairs18_i8<4>();
+      sched_pairs18_i8<FHEVC_I8_C3_FILL>();
       conv3_store_i8m<FASTRQ ? 2 : 0>(q0, a3dst + conv3_pair_row_i8(2) * 1024, tile3, psw, shift3);
       conv3_store_i8m<FASTRQ ? 2 : 0>(q1, a3dst + conv3_pair_row_i8(3) * 1024, tile3, psw, shift3);
       FHEVC_PRIO_OFF(2)
