@@ -93,6 +93,15 @@ constexpr int IN_PITCH = 68;                      // dwords per input row PAIR (
 #ifndef FHEVC_F16_C2_FENCE
 #define FHEVC_F16_C2_FENCE 1
 #endif
+#ifndef FHEVC_I8_C2_SCHED
+#define FHEVC_I8_C2_SCHED 1
+#endif
+#ifndef FHEVC_I8_C3_SCHED
+#define FHEVC_I8_C3_SCHED 0  // conv3 of the i8 form runs 0.7 % faster WITHOUT a pipeline description (0.4231 -> 0.4202 ms); conv2 needs its (MFMA, DS read)
+#endif                       // pairing: without it 0.4575 ms
+#ifndef FHEVC_CONV1_MFMA_FIRST
+#define FHEVC_CONV1_MFMA_FIRST 0
+#endif
 #ifndef FHEVC_CONV1_UNROLL
 #define FHEVC_CONV1_UNROLL 2
 #endif
@@ -1025,6 +1034,10 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
         if (I8) conv1_store_i8(acc0, acc1, dp);
         else conv1_store(acc0, acc1, dp);
         dp += 4 * A1_ROW;
+        if (FHEVC_CONV1_MFMA_FIRST && (i & 1)) {  // (experiment) both units' MFMAs of an unrolled pair ahead of their epilogues
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 60, 0);
+        }
       }
       FHEVC_PRIO_OFF(0)
     }
@@ -1053,20 +1066,20 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
       i32x16 t0, t1, a0, a1;
       bf16x8 ring[RING];
       conv2_half_i8<true, false>(h00, h00 + A1_ROW, wA2, ring, b2t, h, t0, t1);
-      __builtin_amdgcn_sched_group_barrier(0x100, RING + 4, 0);  // bias tile + the ring's first fragments go out together
-      sched_chain12_i8<0>();
+      if (FHEVC_I8_C2_SCHED) __builtin_amdgcn_sched_group_barrier(0x100, RING + 4, 0);  // bias tile + the ring's first fragments go out together
+      if (FHEVC_I8_C2_SCHED) sched_chain12_i8<0>();
       conv2_half_i8<false, false>(h00 + A1_ROW, h10, wA2, ring, b2t, h, a0, a1);
       pool_h_i8(t0, t1);
-      sched_chain12_i8<FHEVC_I8_C2_FILL_POOL>();
+      if (FHEVC_I8_C2_SCHED) sched_chain12_i8<FHEVC_I8_C2_FILL_POOL>();
       if (FHEVC_I8_C2_FENCE) __builtin_amdgcn_sched_barrier(0);
       pool_v_i8(t0, a0, a1);
       if (FHEVC_I8_C2_FENCE) __builtin_amdgcn_sched_barrier(0);
       conv2_half_i8<false, false>(h10, h10 + A1_ROW, wA2, ring, b2t, h, t1, a0);
       conv2_requant_store_i8m<FASTRQ ? 1 : 0>(t0, a2dst + (2 * u0) * A2_PITCH * 16, shift2);
-      sched_chain12_i8<FHEVC_I8_C2_FILL_REQUANT>();
+      if (FHEVC_I8_C2_SCHED) sched_chain12_i8<FHEVC_I8_C2_FILL_REQUANT>();
       conv2_half_i8<false, true>(h10 + A1_ROW, h10 + A1_ROW, wA2, ring, b2t, h, a1, t0);
       pool_h_i8(t1, a0);
-      sched_chain12_i8<FHEVC_I8_C2_FILL_POOL>();
+      if (FHEVC_I8_C2_SCHED) sched_chain12_i8<FHEVC_I8_C2_FILL_POOL>();
       if (FHEVC_I8_C2_FENCE) __builtin_amdgcn_sched_barrier(0);
       pool_v_i8(t1, a1, t0);
       conv2_requant_store_i8m<FASTRQ ? 1 : 0>(t1, a2dst + (2 * u1) * A2_PITCH * 16, shift2);
@@ -1130,13 +1143,13 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
       bf16x8 ring[RING3];
       i32x16 p0, p1, q0, q1;
       conv3_pairs_i8<0>(a2, wA3, ring, b3p, h, p0, p1);
-      __builtin_amdgcn_sched_group_barrier(0x100, RING3 + 4, 0);
-      sched_pairs18_i8<0>();
+      if (FHEVC_I8_C3_SCHED) __builtin_amdgcn_sched_group_barrier(0x100, RING3 + 4, 0);
+      if (FHEVC_I8_C3_SCHED) sched_pairs18_i8<0>();
       conv3_pairs_i8<1>(a2, wA3, ring, b3p, h, q0, q1);
-      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      if (FHEVC_I8_C3_SCHED) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
       conv3_store_i8m<FASTRQ ? 2 : 0>(p0, a3dst + conv3_pair_row_i8(0) * 1024, tile3, psw, shift3);
       conv3_store_i8m<FASTRQ ? 2 : 0>(p1, a3dst + conv3_pair_row_i8(1) * 1024, tile3, psw, shift3);
-      sched_pairs18_i8<FHEVC_I8_C3_FILL>();
+      if (FHEVC_I8_C3_SCHED) sched_pairs18_i8<FHEVC_I8_C3_FILL>();
       conv3_store_i8m<FASTRQ ? 2 : 0>(q0, a3dst + conv3_pair_row_i8(2) * 1024, tile3, psw, shift3);
       conv3_store_i8m<FASTRQ ? 2 : 0>(q1, a3dst + conv3_pair_row_i8(3) * 1024, tile3, psw, shift3);
       FHEVC_PRIO_OFF(2)
