@@ -183,8 +183,8 @@ def main():
         return cpu_worker(sys.argv[2:])
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)    # 5 regions x 50 steps = 0.1 s of GPU time at the default workload
+    ap.add_argument("--warmup", type=int, default=20)   # the clocks of a fresh process take ~30 steps to settle
     ap.add_argument("--repeats", type=int, default=5, help="how many times the timed region of --steps steps is run (value = median)")
     ap.add_argument("--frames", type=int, default=None, help="frames per GOP (default 64; 16 with --bands)")
     ap.add_argument("--width", type=int, default=None)
