@@ -185,6 +185,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)    # 5 regions x 50 steps = 0.1 s of GPU time at the default workload
     ap.add_argument("--warmup", type=int, default=20)   # the clocks of a fresh process take ~30 steps to settle
+    ap.add_argument("--prewarm", type=int, default=30, help="untimed steps before the --warmup steps: a fresh process's GPU clocks settle over ~30 steps "
+                                                            "(reported as prewarm_steps; 0 = none)")
     ap.add_argument("--repeats", type=int, default=5, help="how many times the timed region of --steps steps is run (value = median)")
     ap.add_argument("--frames", type=int, default=None, help="frames per GOP (default 64; 16 with --bands)")
     ap.add_argument("--width", type=int, default=None)
@@ -301,7 +303,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
+    for i in range(max(0, args.prewarm) + args.warmup):
         step(i)
     fence()
     ctx.enable_kernel_timing(True)
@@ -490,7 +492,7 @@ def main():
         line = {
             "metric": "CTU depth decisions/sec at 1080p all-intra + BD-rate delta vs full-RDO HM" if (W, H) == (1920, 1080) else f"CTU depth decisions/sec at {W}x{H} all-intra",
             "value": value, "unit": "CTU/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prewarm_steps": max(0, args.prewarm), "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": ARITH_DTYPE[arith],
             "dtype_note": ("the classifier is an exact integer network (int8 weights, 8-bit activations): since round 2 the library's default runs conv2 / conv3 on the "
