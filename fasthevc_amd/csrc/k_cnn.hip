@@ -63,8 +63,8 @@ constexpr int IN_PITCH = 68;                      // dwords per input row PAIR (
 #define FHEVC_I8_PRIO 0x0222
 #endif
 #ifndef FHEVC_F16_PRIO
-#define FHEVC_F16_PRIO 0x0222
-#endif
+#define FHEVC_F16_PRIO 0x0123  // two workgroups per CU: the earlier phase outranks the later one (conv1 3, conv2 2, conv3 1): 0.5377 ms at 0x0222,
+#endif                         // 0.5199 at 0x0122, 0.5093 at 0x0123 (0x0133 0.5124, 0x0022 0.5216, 0x0112 0.5251); the i8 form measures equal across these
 // phase: 0 conv1, 1 conv2, 2 conv3, 3 heads
 #define FHEVC_PRIO_OF(phase) (((I8 ? FHEVC_I8_PRIO : FHEVC_F16_PRIO) >> (4 * (phase))) & 3)
 #define FHEVC_PRIO_ON(phase)  if (FHEVC_PRIO_OF(phase)) __builtin_amdgcn_s_setprio(FHEVC_PRIO_OF(phase));
@@ -101,6 +101,9 @@ constexpr int IN_PITCH = 68;                      // dwords per input row PAIR (
 #endif                       // pairing: without it 0.4575 ms
 #ifndef FHEVC_CONV1_MFMA_FIRST
 #define FHEVC_CONV1_MFMA_FIRST 0
+#endif
+#ifndef FHEVC_F16_C3_SCHED
+#define FHEVC_F16_C3_SCHED 1
 #endif
 #ifndef FHEVC_CONV1_UNROLL
 #define FHEVC_CONV1_UNROLL 2
@@ -1194,29 +1197,29 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
       f32x4 p0, p1, q0, q1;
 #define FHEVC_ROW_OFF(k) ((4 * ((k) >> 1) + ((k) & 1)) * 1024)
       conv3_row<0>(a2, wA3, ring, b30, b31, p0, p1);
-      __builtin_amdgcn_sched_group_barrier(0x100, RING3 + 2, 0);
-      sched_row18();
+      if (FHEVC_F16_C3_SCHED) __builtin_amdgcn_sched_group_barrier(0x100, RING3 + 2, 0);
+      if (FHEVC_F16_C3_SCHED) sched_row18();
       conv3_row<1>(a2, wA3, ring, b30, b31, q0, q1);
       conv3_store(p0, p1, a3dst + FHEVC_ROW_OFF(0), tile3, psw);
-      sched_row18();
+      if (FHEVC_F16_C3_SCHED) sched_row18();
       conv3_row<2>(a2, wA3, ring, b30, b31, p0, p1);
       conv3_store(q0, q1, a3dst + FHEVC_ROW_OFF(1), tile3, psw);
-      sched_row18();
+      if (FHEVC_F16_C3_SCHED) sched_row18();
       conv3_row<3>(a2, wA3, ring, b30, b31, q0, q1);
       conv3_store(p0, p1, a3dst + FHEVC_ROW_OFF(2), tile3, psw);
-      sched_row18();
+      if (FHEVC_F16_C3_SCHED) sched_row18();
       conv3_row<4>(a2, wA3, ring, b30, b31, p0, p1);
       conv3_store(q0, q1, a3dst + FHEVC_ROW_OFF(3), tile3, psw);
-      sched_row18();
+      if (FHEVC_F16_C3_SCHED) sched_row18();
       conv3_row<5>(a2, wA3, ring, b30, b31, q0, q1);
       conv3_store(p0, p1, a3dst + FHEVC_ROW_OFF(4), tile3, psw);
-      sched_row18();
+      if (FHEVC_F16_C3_SCHED) sched_row18();
       conv3_row<6>(a2, wA3, ring, b30, b31, p0, p1);
       conv3_store(q0, q1, a3dst + FHEVC_ROW_OFF(5), tile3, psw);
-      sched_row18();
+      if (FHEVC_F16_C3_SCHED) sched_row18();
       conv3_row<7>(a2, wA3, ring, b30, b31, q0, q1);
       conv3_store(p0, p1, a3dst + FHEVC_ROW_OFF(6), tile3, psw);
-      sched_row18();
+      if (FHEVC_F16_C3_SCHED) sched_row18();
       conv3_store(q0, q1, a3dst + FHEVC_ROW_OFF(7), tile3, psw);
       FHEVC_PRIO_OFF(2)
 #undef FHEVC_ROW_OFF
