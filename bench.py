@@ -318,7 +318,7 @@ def main():
         fence()
         dt = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            t = torch.tensor([dt], dtype=torch.float64)  # the default group is gloo (gather.init_groups): host tensors
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         regions.append(dt)
@@ -340,7 +340,7 @@ def main():
         fence()
         dto = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([dto], dtype=torch.float64, device=dev)
+            t = torch.tensor([dto], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dto = float(t.item())
         o_ms, o_n = ctx.kernel_timing(0, reset=True)
@@ -356,7 +356,7 @@ def main():
         torch.cuda.synchronize()
         g = gathered.view(total_frames, ch, cw, 256)
         mine = g[f0:f1, r0:r1].reshape(-1, 256)
-        chk = torch.tensor([float(torch.equal(check, mine)), float(gathered.to(torch.int64).sum().item())], dtype=torch.float64, device=dev)
+        chk = torch.tensor([float(torch.equal(check, mine)), float(gathered.to(torch.int64).sum().item())], dtype=torch.float64)
         lo, hi = chk.clone(), chk.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)

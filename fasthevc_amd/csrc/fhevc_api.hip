@@ -405,6 +405,13 @@ void fhevc_destroy(fhevc_ctx* c)
   (void)hipFree(c->d_frag); (void)hipFree(c->d_bias); (void)hipFree(c->d_whead); (void)hipFree(c->d_bhead);
   (void)hipFree(c->d_frag_i8); (void)hipFree(c->d_bias_i8);
   (void)hipFree(c->d_luma); (void)hipFree(c->d_depth); (void)hipFree(c->d_had); (void)hipFree(c->d_nodes); (void)hipFree(c->d_satd); (void)hipFree(c->d_satd_out); (void)hipFree(c->d_act); (void)hipFree(c->d_depth_max); (void)hipFree(c->d_pair); (void)hipFree(c->d_motion);
+  for (auto& sl : c->slot) {  // the host-batch ring of fhevc_predict_frames: stream, device buffers, pinned staging
+    if (sl.st) { (void)hipStreamSynchronize(sl.st); (void)hipStreamDestroy(sl.st); }
+    (void)hipFree(sl.d_in); (void)hipFree(sl.d_depth); (void)hipFree(sl.d_had);
+    if (sl.h_in) (void)hipHostFree(sl.h_in);
+    if (sl.h_depth) (void)hipHostFree(sl.h_depth);
+    if (sl.h_had) (void)hipHostFree(sl.h_had);
+  }
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -606,6 +613,7 @@ int fhevc_predict_frames(fhevc_ctx* c, const void* luma, int sample_bytes, int s
     }
   }
   int rc = FHEVC_OK;
+  auto hip_rc = [&](hipError_t e, const char* what) { return e == hipSuccess ? FHEVC_OK : fail(c, FHEVC_E_HIP, what, e); };
   for (int f0 = 0, k = 0; f0 < num_frames && rc == FHEVC_OK; f0 += chunk, ++k) {
     fhevc_ctx::Slot& sl = c->slot[k & 1];
     rc = drain_slot(c, sl);  // chunk k-2: its maps reach the caller while chunk k-1 computes
@@ -614,24 +622,40 @@ int fhevc_predict_frames(fhevc_ctx* c, const void* luma, int sample_bytes, int s
     const uint8_t* src = static_cast<const uint8_t*>(luma) + (size_t)f0 * fs_bytes;
     const size_t bytes = (size_t)(nf - 1) * fs_bytes + (size_t)frame_extent * sample_bytes;
     if (!in_pinned) { std::memcpy(sl.h_in, src, bytes); src = sl.h_in; }
-    HIP_TRY(c, hipMemcpyAsync(sl.d_in, src, bytes, hipMemcpyHostToDevice, sl.st));
+    rc = hip_rc(hipMemcpyAsync(sl.d_in, src, bytes, hipMemcpyHostToDevice, sl.st), "upload of a chunk");
+    if (rc != FHEVC_OK) break;
     rc = fhevc_predict_frames_device(c, sl.d_in, sample_bytes, stride_samples, (long long)(fs_bytes / sample_bytes), nf, 0, c->ctus_y, qp, sl.d_depth,
                                      ctu_src_hadamard ? sl.d_had : nullptr, nullptr, nullptr, sl.st);
     if (rc != FHEVC_OK) break;
+    rc = hip_rc(hipMemcpyAsync(out_pinned ? depth_map + (size_t)f0 * c->num_ctus * 256 : sl.h_depth, sl.d_depth, (size_t)nf * c->num_ctus * 256,
+                               hipMemcpyDeviceToHost, sl.st), "download of a chunk's maps");
+    if (rc == FHEVC_OK && ctu_src_hadamard)
+      rc = hip_rc(hipMemcpyAsync(out_pinned ? (void*)(ctu_src_hadamard + (size_t)f0 * c->num_ctus) : (void*)sl.h_had, sl.d_had, (size_t)nf * c->num_ctus * 4,
+                                 hipMemcpyDeviceToHost, sl.st), "download of a chunk's Hadamard sums");
+    if (rc != FHEVC_OK) break;
+    // only now is the slot "in flight": a failure above leaves nothing for a later drain to copy into this caller's buffers
     sl.frames = nf;
     sl.out_depth = depth_map + (size_t)f0 * c->num_ctus * 256;
     sl.out_had = ctu_src_hadamard ? ctu_src_hadamard + (size_t)f0 * c->num_ctus : nullptr;
     sl.staged_out = !out_pinned;
-    HIP_TRY(c, hipMemcpyAsync(out_pinned ? sl.out_depth : sl.h_depth, sl.d_depth, (size_t)nf * c->num_ctus * 256, hipMemcpyDeviceToHost, sl.st));
-    if (ctu_src_hadamard)
-      HIP_TRY(c, hipMemcpyAsync(out_pinned ? (void*)sl.out_had : (void*)sl.h_had, sl.d_had, (size_t)nf * c->num_ctus * 4, hipMemcpyDeviceToHost, sl.st));
     c->stats.bytes_h2d += bytes;
     c->stats.bytes_d2h += (uint64_t)nf * c->num_ctus * (256 + (ctu_src_hadamard ? 4 : 0));
+  }
+  if (rc != FHEVC_OK) {
+    // error path: let both streams finish whatever they hold, hand nothing more to the caller, and forget the slots' destinations
+    // (the caller's buffers may be gone by the next call)
+    for (auto& sl : c->slot) {
+      if (sl.st) (void)hipStreamSynchronize(sl.st);
+      sl.frames = 0; sl.out_depth = nullptr; sl.out_had = nullptr;
+    }
+    return rc;
   }
   for (auto& sl : c->slot) {
     const int r2 = drain_slot(c, sl);
     if (rc == FHEVC_OK) rc = r2;
   }
+  if (rc != FHEVC_OK)
+    for (auto& sl : c->slot) { sl.frames = 0; sl.out_depth = nullptr; sl.out_had = nullptr; }
   return rc;
 }
 

@@ -1467,10 +1467,12 @@ hipError_t fhevc_cnn_prepare_device()
 // d_had != nullptr: the fused source Hadamard (only where fhevc_cnn_can_fuse_hadamard says so)
 bool fhevc_cnn_can_fuse_hadamard(const FhevcFrames& fr)
 {
-  // every thread's 16 samples must come through the aligned fast path or lie wholly outside the picture, and the packed
-  // 16-bit butterflies need samples below 2^10
+  // every thread's 16 samples must come through the aligned fast path or lie wholly outside the picture, the packed
+  // 16-bit butterflies need samples below 2^10, and the height must be a multiple of 8: the prefetch zero-fills rows below the
+  // picture, so a bottom 8x8 block that is only partly inside would enter the sum with real rows plus zero rows, where
+  // updateCtuDataISlice (TEncCu.cpp:1324-1343) and the stand-alone kernel count WHOLE blocks only
   const size_t sb = (size_t)fr.sample_bytes;
-  return fr.bit_depth <= 10 && (fr.width % 16) == 0 && (reinterpret_cast<uintptr_t>(fr.luma) % 16) == 0 &&
+  return fr.bit_depth <= 10 && (fr.width % 16) == 0 && (fr.height % 8) == 0 && (reinterpret_cast<uintptr_t>(fr.luma) % 16) == 0 &&
          ((size_t)fr.stride * sb) % 16 == 0 && ((size_t)fr.frame_stride * sb) % 16 == 0;
 }
 

@@ -9,12 +9,23 @@ split-flag serialisation in fixed bit positions, TComSysuCuMDTools.cpp:16-38); e
 slice because all_gather_into_tensor needs equal sizes, and one index_select puts the gathered words into whole-picture CTU
 raster order, ready for fhevc_expand_depth_flags_device.
 
-Collective: torch.distributed "nccl" = RCCL over xGMI.  If RCCL cannot be initialised or a collective raises, the gather
-falls back to a HOST-side gather (D2H of the words, all-gather over a gloo group, H2D) and says so in `status` -- a status,
-never an abort ("acceptable fallback when RCCL init fails").
+Collective: torch.distributed "nccl" = RCCL over xGMI.  The fallback to a HOST-side gather (D2H of the words, all-gather
+over the gloo group, H2D; SURVEY 8(e): "acceptable fallback when RCCL init fails") is a COLLECTIVE decision, never a rank's
+own: init_groups brings the gloo group up first (it always comes up), tries RCCL with one test collective, and all ranks
+all-reduce(MIN) their verdicts over gloo -- one rank without RCCL puts every rank on the host gather, and `status` says so.
+A collective that raises in mid-run cannot be rescued by the rank that saw it (its peers are inside the RCCL collective and
+would wait for it for ever): the rank raises GatherError, the process ends non-zero and the launcher (torchrun) takes the
+other ranks down -- a loud failure instead of a hang with ranks in different collectives.
 """
+import datetime
+import os
+
 import torch
 import torch.distributed as dist
+
+
+class GatherError(RuntimeError):
+    """the path's only collective failed on this rank after the ranks had agreed on its backend"""
 
 
 def span(total, rank, world):
@@ -29,8 +40,12 @@ class FlagGather:
         self.num_frames, self.ctus_x, self.ctus_y = num_frames, ctus_x, ctus_y
         self.device = torch.device(device)
         self.group, self.host_group = group, host_group
-        self.status = "single rank" if world == 1 else "rccl" if self.device.type == "cuda" and group is not False else "host-gather"
-        if group is False:  # the caller could not bring RCCL up
+        # group: the RCCL group of init_groups; False = the ranks agreed that RCCL is not usable; None = no RCCL group was made
+        # (CPU tensors: the gloo group is the gather)
+        rccl = self.device.type == "cuda" and group is not None and group is not False
+        self.status = "single rank" if world == 1 else "rccl" if rccl else \
+            "host-gather (RCCL unavailable on at least one rank)" if group is False and self.device.type == "cuda" else "host-gather"
+        if not rccl:
             self.group = None
         n = ctus_x * ctus_y
         if mode == "frames":
@@ -87,15 +102,15 @@ class FlagGather:
             self._inflight = (None, b)
             return
         self.pack(b)
-        if self.status == "rccl" or (self.status == "host-gather" and self.device.type == "cpu"):
+        if self.status == "rccl" or (self.status.startswith("host-gather") and self.device.type == "cpu"):
             try:
                 src = self.send[b].clone() if self.device.type == "cpu" else self.send[b]
                 work = dist.all_gather_into_tensor(self.recv[b], src, group=self.group if self.device.type == "cuda" else self.host_group,
                                                    async_op=True)
-                self._inflight = (work, b)
-                return
-            except Exception as e:  # RCCL refused the collective: fall back for the rest of the run
-                self.status = f"host-gather (collective failed: {type(e).__name__})"
+            except Exception as e:  # the ranks agreed on this backend at start-up (init_groups): see the module docstring
+                raise GatherError(f"all-gather of the split-flag words failed on rank {self.rank}: {type(e).__name__}: {e}") from e
+            self._inflight = (work, b)
+            return
         self._host_gather(b)
         self._inflight = (None, b)
 
@@ -118,27 +133,46 @@ class FlagGather:
             try:
                 work.wait()
             except Exception as e:
-                self.status = f"host-gather (collective failed: {type(e).__name__})"
-                self._host_gather(b)
+                raise GatherError(f"all-gather of the split-flag words failed on rank {self.rank}: {type(e).__name__}: {e}") from e
         torch.index_select(self.recv[b], 0, self.index, out=self.whole)
         return self.whole
 
 
-def init_groups(world, rank, device, backend="nccl"):
-    """(group, host_group): the RCCL group (None = default group; False = RCCL could not be brought up) and a gloo group for
-    the host-side fallback.  world == 1: (None, None)."""
+def agree(ok, host_group=None):
+    """collective over the gloo group: True only if EVERY rank says ok"""
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=host_group)
+    return bool(t.item())
+
+
+def init_groups(world, rank, device, backend="nccl", timeout_s=120):
+    """(group, host_group) for FlagGather.  The DEFAULT process group is gloo (host_group None = the default group): it carries
+    the barriers, the timing reductions and the fallback gather, and it comes up wherever TCP does.  `group` is the RCCL group,
+    or False when the ranks AGREED that RCCL is not usable (backend != "nccl", a CPU device, RCCL refusing to come up or failing
+    its test collective on ANY rank).  world == 1: (None, None).
+    FHEVC_TEST_FAIL_RCCL_RANK=<rank> makes that rank report a failed test collective (the multi-rank tests use it; with
+    backend "gloo-as-rccl" a second gloo group stands in for RCCL so that the agreement runs on CPU-only machines)."""
     if world == 1:
         return None, None
-    if backend != "nccl":
-        dist.init_process_group(backend, rank=rank, world_size=world)
-        return (False if torch.device(device).type == "cuda" else None), None
-    try:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
-        group = None
-    except Exception:
-        if dist.is_initialized():
-            dist.destroy_process_group()
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device(device)
+    stand_in = backend == "gloo-as-rccl"
+    if not stand_in and (backend != "nccl" or dev.type != "cuda"):
         return False, None
-    host_group = dist.new_group(backend="gloo")  # every rank creates it, in the same order
-    return group, host_group
+    group, ok = None, True
+    try:  # new_group is itself a collective over the default group: every rank calls it, in the same order
+        group = dist.new_group(backend="gloo" if stand_in else "nccl", timeout=datetime.timedelta(seconds=timeout_s))
+    except Exception:
+        ok = False
+    if ok:
+        try:
+            t = torch.ones(1, dtype=torch.int32, device=dev if not stand_in else "cpu")
+            dist.all_reduce(t, group=group)
+            if dev.type == "cuda" and not stand_in:
+                torch.cuda.synchronize(dev)
+            ok = int(t.item()) == world and os.environ.get("FHEVC_TEST_FAIL_RCCL_RANK") != str(rank)
+        except Exception:
+            ok = False
+    if not agree(ok):  # one rank without RCCL: every rank gathers through the host, and says so
+        return False, None
+    return group, None

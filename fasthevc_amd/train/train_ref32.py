@@ -11,8 +11,8 @@ with every label, CShow_PredResiReco.h:93, and never reads it).  Its one numeric
 
 Here: float32 PyTorch, the same layers and options, crops cut from the label files of tests/quality/make_labels.py (the
 reference's own full-RDO depth maps), every 8th picture held out (the split of train.py), all four QPs pooled as the reference's
-dump would.  Prints the validation error (balanced, and at the natural class prior) next to the 32-level accuracy of the shipped
-fixed-point network on the same held-out crops.  The reference zeroes the learning rate after the first epoch
+dump would.  Prints the validation error (balanced, and at the natural class prior); tests/quality/ref32_vs_shipped.py adds the 32-level
+error of the shipped fixed-point network on the same held-out crops to the JSON.  The reference zeroes the learning rate after the first epoch
 (LearnRateDropFactor 0, period 1); the error after epoch 1 is therefore the like-for-like figure, later epochs are extra.
 
 usage: python -m fasthevc_amd.train.train_ref32 --data /tmp/fhevc_labels [--json profiles/r02_reference_32x32_classifier.json]
@@ -119,36 +119,8 @@ def main():
         report["epochs"].append({"epoch": ep + 1, "val_error_balanced": eb, "val_error_natural_prior": en, "val_error_per_qp": per_qp})
         print(f"epoch {ep + 1}: validation error balanced {eb:.4f}, natural prior {en:.4f}, per QP {per_qp} ({time.time() - t0:.0f} s)", flush=True)
 
-    # the shipped fixed-point network's 32-level decision on the same held-out quadrants (it sees the whole CTU and the QP)
-    try:
-        import ctypes as C
-        from fasthevc_amd import weights
-        from oracle import oracle_py as op
-        oracle = op.load_oracle()
-        ws = op.weights_from_arrays(weights.load(os.path.join(ROOT, "fasthevc_amd", "weights", "depthnet_v1.fhw")))
-        wrong = total = 0
-        per_qp = {}
-        logits = np.zeros(42, np.int32)
-        for f in va_files[::4]:
-            z = np.load(f)
-            for qp in QPS:
-                d = z[f"depth_q{qp}"]
-                for c in np.nonzero(d[:, 0, 0] != 0)[0]:
-                    ctu = (z["tiles"][c].astype(np.int16) - 128).astype(np.int8).reshape(-1)
-                    oracle.fho_cnn_ctu(ws, np.ascontiguousarray(ctu), qp, logits)
-                    for k, (oy, ox) in enumerate(((0, 0), (0, 8), (8, 0), (8, 8))):
-                        pred = logits[2 * (1 + k) + 1] > logits[2 * (1 + k)]
-                        bad = int(pred != (d[c, oy, ox] != 1))
-                        wrong += bad
-                        total += 1
-                        a = per_qp.setdefault(int(qp), [0, 0])
-                        a[0] += bad
-                        a[1] += 1
-        report["shipped_fixed_point_32_level"] = {"val_error_natural_prior": wrong / total, "crops": total,
-                                                  "val_error_per_qp": {k: v[0] / v[1] for k, v in per_qp.items()}}
-        print(f"shipped fixed-point network, 32-level decision on held-out quadrants: error {wrong / total:.4f} ({total} crops)")
-    except Exception as e:  # the comparison needs the oracle library
-        print("skipped the fixed-point comparison:", e)
+    # (the shipped fixed-point network's 32-level decision on the same held-out quadrants is evaluated by
+    # tests/quality/ref32_vs_shipped.py: it needs the CPU oracle, which nothing under fasthevc_amd/ may import)
     report["reference_trace"] = "0.0989 validation error of one Bayesian-optimisation trial (filteredResults.m:2); dataset and split unknown"
     if args.json:
         with open(args.json, "w") as fo:

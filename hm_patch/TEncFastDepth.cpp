@@ -81,24 +81,31 @@ void TEncFastDepth::setExternalRange(const unsigned char* mapMin, const unsigned
 bool TEncFastDepth::predictPicture(TComPic* pcPic, int sliceQp, int sliceType)
 {
   if (m_external) return true;       // validation feed wins
+  // cheap early-outs first: pictures this hook can do nothing for never pay for the fingerprint below
+  // the depth-map layout (16x16 units of a 64x64 CTU, depths 0..3) is what the library produces and forcedRange() reads:
+  // any other CTU geometry runs stock RDO
+  const TComSPS& sps = pcPic->getPicSym()->getSPS();
+  const bool geometryOk = sps.getMaxCUWidth() == 64 && sps.getMaxCUHeight() == 64 && sps.getLog2DiffMaxMinCodingBlockSize() == 3;
+  bool possible = geometryOk && (sliceType == I_SLICE ? m_enabled : m_pMode != P_OFF);
+#ifdef FHEVC_HOOK_NO_GPU
+  if (sliceType == I_SLICE || m_pMode != P_WINDOW) possible = false;   // the CPU-test build of the hook has the temporal window only
+#endif
+  if (!possible) { m_valid = false; m_cachePic = NULL; return false; }
   // compressSlice runs once per slice and once more per precompressSlice iteration (DeltaQpRD): the map of a picture is
-  // computed once per (picture object, POC, slice QP, slice type, fingerprint of the original luma) and kept; the fingerprint
-  // (every 16th row, FNV-1a) tells a recycled TComPic with a repeated POC (IDR-only streams) from the same picture
+  // computed once per (picture object, POC, slice QP, slice type, fingerprint of the original luma) and kept.  The fingerprint
+  // (FNV-1a over EVERY luma sample: ~2 M multiplies per 1080p picture, nothing beside HM's seconds per picture) tells a recycled
+  // TComPic with a repeated POC (IDR-only streams) from the same picture; a sparse hash could miss a change in the rows it skips
   unsigned long long fp = 1469598103934665603ULL;
   {
     const TComPicYuv* o = pcPic->getPicYuvOrg();
     const Pel* p = o->getAddr(COMPONENT_Y);
     const int w = o->getWidth(COMPONENT_Y), h = o->getHeight(COMPONENT_Y), st = o->getStride(COMPONENT_Y);
-    for (int y = 0; y < h; y += 16)
+    for (int y = 0; y < h; y++)
       for (int x = 0; x < w; x++) { fp ^= (unsigned long long)(unsigned short)p[(size_t)y * st + x]; fp *= 1099511628211ULL; }
   }
   if (m_valid && pcPic == m_cachePic && pcPic->getPOC() == m_cachePoc && sliceQp == m_cacheQp && sliceType == m_cacheType && fp == m_cacheFp) return true;
   m_valid = false;
   m_cachePic = pcPic; m_cachePoc = pcPic->getPOC(); m_cacheQp = sliceQp; m_cacheType = sliceType; m_cacheFp = fp;
-  // the depth-map layout (16x16 units of a 64x64 CTU, depths 0..3) is what the library produces and forcedRange() reads:
-  // any other CTU geometry runs stock RDO
-  const TComSPS& sps = pcPic->getPicSym()->getSPS();
-  if (sps.getMaxCUWidth() != 64 || sps.getMaxCUHeight() != 64 || sps.getLog2DiffMaxMinCodingBlockSize() != 3) return false;
   if (sliceType != I_SLICE)
   {
     // Config 4, "inter-CU depth reuse": a P/B picture takes its depth range from the co-located depths of its first reference

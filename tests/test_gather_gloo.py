@@ -94,3 +94,55 @@ def test_partition_arithmetic_matches_fhevc_band():
         assert got[0][0] == 0 and got[-1][1] == total and all(a[1] == b[0] for a, b in zip(got, got[1:]))
     fg = gather.FlagGather("bands", 8, 3, 2, 60, 34, "cpu")   # config 3: 4K, 34 CTU rows over 8 ranks -> padded slices of 5 rows
     assert fg.max_rows == 5 and fg.slice_words == 2 * 5 * 60 and fg.rows == (12, 17)
+
+
+def _agreement_worker(rank, world, port, fail_rank, q):
+    """init_groups with a second gloo group standing in for RCCL: the verdict on the fast backend must be the same on all ranks"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if fail_rank is not None:
+        os.environ["FHEVC_TEST_FAIL_RCCL_RANK"] = str(fail_rank)   # every rank has it in its environment; only rank == fail_rank fails
+    torch.set_num_threads(1)
+    group, host_group = gather.init_groups(world, rank, "cpu", backend="gloo-as-rccl", timeout_s=60)
+    verdict = "fallback" if group is False else "fast"
+    # whichever way the ranks agreed, the gather itself still works and gives the same words everywhere
+    fg = gather.FlagGather("frames", world, rank, 4, 2, 2, "cpu", group=group, host_group=host_group)
+    f0, f1 = fg.frames
+    full = torch.arange(16, dtype=torch.int32) * 7 + 3
+    fg.local_words(0)[:] = full[f0 * 4:f1 * 4]
+    fg.start(0)
+    same = torch.equal(fg.finish(), full)
+    # a collective that raises in mid-run is a loud failure on the rank that saw it, never a private switch of backend
+    raised = False
+    if rank == 0:
+        real = dist.all_gather_into_tensor
+        dist.all_gather_into_tensor = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("injected"))
+        try:
+            fg.local_words(1)[:] = full[f0 * 4:f1 * 4]
+            fg.start(1)
+        except gather.GatherError:
+            raised = True
+        finally:
+            dist.all_gather_into_tensor = real
+        fg._inflight = None
+    q.put((rank, verdict, bool(same), raised))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail_rank", [None, 1])
+def test_the_fallback_from_rccl_is_a_collective_decision(fail_rank):
+    """a rank whose RCCL bring-up fails must not end up in a gloo collective while its peers sit in RCCL.  One rank
+    reporting a failed test collective puts EVERY rank on the host gather; with no failure every rank keeps the fast group."""
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_agreement_worker, args=(r, world, port, fail_rank, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    want = "fast" if fail_rank is None else "fallback"
+    assert [(r, v, s) for r, v, s, _ in res] == [(r, want, True) for r in range(world)]
+    assert res[0][3] is True   # rank 0's injected mid-run failure surfaced as GatherError

@@ -181,6 +181,35 @@ def test_split_flag_words_on_ragged_pictures(oracle, torch_cuda, W, H, cnn_arith
     ctx.close()
 
 
+@pytest.mark.parametrize("W,H", [(416, 244), (128, 68), (64, 4), (192, 130)])
+def test_source_hadamard_on_heights_that_cut_an_8x8_block(oracle, torch_cuda, W, H, cnn_arith):
+    """Width a multiple of 16 (the fused form's condition) but height NOT a multiple of 8: updateCtuDataISlice (TEncCu.cpp:1324-1343)
+    counts whole 8x8 blocks only, so the bottom block row that the picture cuts must not enter the sum.  The library has to route
+    these pictures to the stand-alone kernel (fhevc_cnn_can_fuse_hadamard); host-buffer and device-batch entry points."""
+    torch = torch_cuda
+    w = weights.random_weights(3)
+    NF = 2
+    lumas = [frames.texture16_luma(W, H, seed=900 + f) for f in range(NF)]
+    refs = [_oracle_frame(oracle, w, y, 8, 32) for y in lumas]
+    ctx = capi.Context(W, H, 8, w, max_frames=NF)
+    for f in range(NF):
+        buf, org, stride, depth_ref, _, had_ref = refs[f]
+        depth, had = ctx.predict_frame(buf, org, stride)
+        assert np.array_equal(had, had_ref), (W, H, f)
+        assert np.array_equal(depth, depth_ref), (W, H, f)
+    dev = torch.device("cuda:0")
+    d8 = torch.from_numpy(np.stack(lumas)).to(dev)
+    depth = torch.zeros((NF, ctx.num_ctus, 256), dtype=torch.uint8, device=dev)
+    had = torch.zeros((NF, ctx.num_ctus), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ctx.predict_frames_device(d8.data_ptr(), 1, W, W * H, NF, depth.data_ptr(), had.data_ptr(), None, qp=32)
+    torch.cuda.synchronize()
+    for f in range(NF):
+        assert np.array_equal(had[f].cpu().numpy(), refs[f][5]), (W, H, f)
+        assert np.array_equal(depth[f].cpu().numpy(), refs[f][3]), (W, H, f)
+    ctx.close()
+
+
 @pytest.mark.parametrize("bd", [8, 10, 12])
 def test_source_hadamard_extremes(oracle, bd):
     """updateCtuDataISlice twin on patterns that maximise single coefficients: at 8/10 bit the kernel runs wrapping packed
