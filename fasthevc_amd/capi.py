@@ -84,15 +84,17 @@ def _share_the_hosts_hip_runtime():
         C.CDLL(rt, mode=C.RTLD_GLOBAL)
 
 
-def load_library():
-    """dlopen the in-tree HIP library; raises if it has not been built (no silent fallback)."""
+def load_library(path=None):
+    """dlopen the in-tree HIP library; raises if it has not been built (no silent fallback).  `path`: another build of the same
+    library (tools/build_variant.sh), bound separately and not cached -- same-process A/B timing of kernel variants only."""
     global _lib
-    if _lib is not None:
+    if path is None and _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise FileNotFoundError(f"{LIB_PATH} not built: run `python -m fasthevc_amd.build` (or __graft_entry__.build())")
+    lib_path = path or LIB_PATH
+    if not os.path.exists(lib_path):
+        raise FileNotFoundError(f"{lib_path} not built: run `python -m fasthevc_amd.build` (or __graft_entry__.build())")
     _share_the_hosts_hip_runtime()
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(lib_path)
     vp = C.c_void_p
     lib.fhevc_create.argtypes = [C.POINTER(vp), C.POINTER(Cfg)]
     lib.fhevc_destroy.argtypes = [vp]
@@ -134,7 +136,8 @@ def load_library():
     lib.fhevc_last_error.argtypes = [vp]
     lib.fhevc_last_error.restype = C.c_char_p
     lib.fhevc_version.restype = C.c_char_p
-    _lib = lib
+    if path is None:
+        _lib = lib
     return lib
 
 
@@ -173,8 +176,8 @@ def band(ctu_rows, rank, world):
 class Context:
     """One fhevc_ctx: one picture geometry on one MI355X."""
 
-    def __init__(self, width, height, bit_depth=8, weights=None, device=0, max_frames=1, arith=None):
-        self.lib = load_library()
+    def __init__(self, width, height, bit_depth=8, weights=None, device=0, max_frames=1, arith=None, lib_path=None):
+        self.lib = load_library(lib_path)
         self.width, self.height, self.bit_depth = width, height, bit_depth
         self.ctus_x, self.ctus_y = (width + 63) // 64, (height + 63) // 64
         self.num_ctus = self.ctus_x * self.ctus_y

@@ -38,6 +38,8 @@ struct fhevc_ctx {
   hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
   // kernel timing
   bool fuse_hadamard = true;  // FHEVC_FUSE_HADAMARD=0 keeps the stand-alone Hadamard launch (A/B measurements)
+  bool had_valu = true;       // FHEVC_HADAMARD_FORM=mfma: the fused Hadamard of 8-bit content on the bf16 MFMA from the staged tile instead of packed
+                              // 16-bit VALU (parity-green, and measured 7 % SLOWER in round 3: profiles/r03_ab_hadamard_forms.log) -- kept for A/B and tests
   bool timing = false;
   std::vector<TimedLaunch> pending;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
@@ -182,6 +184,22 @@ int build_weight_image(fhevc_ctx* c, const BlobView& b)
           put_scaled(2, FHEVC_FRAG_CONV3 + (t * 18 + s) * 64, lane, j, b.w3[(oc * 32 + ic) * 9 + tap]);
         }
   }
+  // the source Hadamard's constant A operands (k_cnn.hip, HAD == 2; v_mfma_f32_32x32x16_bf16): row m of M tile mt = coefficient
+  // c = 32 mt + m = (u = c >> 3, v = c & 7) of the 2-D Walsh-Hadamard transform of an 8x8 block, K slot 8 h + j of step st = the sample
+  // at column 4 h + (j >> 1), row 2 st - 1 + (j & 1) of the block (the staged tile keeps picture rows 2P - 1 and 2P in one dword):
+  // +-1 by the parity of popcount(u & row) + popcount(v & column); rows -1 and 8 belong to the neighbouring blocks and the DC
+  // coefficient is not part of the sum (TEncCu.cpp:1319): zero
+  for (int mt = 0; mt < 2; ++mt)
+    for (int st = 0; st < 5; ++st)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int c = 32 * mt + (lane & 31), u = c >> 3, v = c & 7, h = lane >> 5;
+        for (int j = 0; j < 8; ++j) {
+          const int col = 4 * h + (j >> 1), row = 2 * st - 1 + (j & 1);
+          uint16_t bits = 0;
+          if (c != 0 && row >= 0 && row <= 7) bits = ((__builtin_popcount(u & row) + __builtin_popcount(v & col)) & 1) ? 0xBF80 : 0x3F80;
+          frag[((size_t)FHEVC_FRAG_HAD + (mt * 5 + st) * 64 + lane) * 8 + j] = bits;
+        }
+      }
   // the i8 variant (v_mfma_i32_32x32x32_i8: a lane holds 16 signed bytes of K; lanes 0-31 K 0-15, lanes 32-63 K 16-31):
   //   conv2 fragment (q, kx): row = output channel lane & 31, K byte j of lane half h = input channel j at tap (ky = 2 q + h, kx)
   //                           (ky = 3: the phantom row, zero);
@@ -276,6 +294,7 @@ FhevcCnnWeights cnn_weights(const fhevc_ctx* c)
   w.shift[0] = c->shift[0]; w.shift[1] = c->shift[1]; w.shift[2] = c->shift[2];
   w.requant_mode[0] = 0; w.requant_mode[1] = c->requant_mode[1]; w.requant_mode[2] = c->requant_mode[2];
   w.i8 = c->cnn_i8 ? 1 : 0;
+  w.had_valu = c->had_valu ? 1 : 0;
   return w;
 }
 
@@ -360,6 +379,7 @@ int fhevc_create(fhevc_ctx** out, const fhevc_cfg* cfg)
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) { delete c; return FHEVC_E_NO_DEVICE; }  // code object is gfx950-only
   c->num_cus = prop.multiProcessorCount;
   if (const char* fz = std::getenv("FHEVC_FUSE_HADAMARD")) c->fuse_hadamard = fz[0] != '0';
+  if (const char* hf = std::getenv("FHEVC_HADAMARD_FORM")) c->had_valu = std::strcmp(hf, "mfma") != 0;
   // arithmetic of conv2 / conv3 in the depth kernel: "f16" (16-bit MFMAs) or "i8" (v_mfma_i32_32x32x32_i8); both are exact
   if (const char* ar = std::getenv("FHEVC_CNN_ARITH")) c->cnn_i8 = std::strcmp(ar, "f16") != 0;
   c->ctus_x = (cfg->width + 63) / 64;

@@ -15,7 +15,8 @@
 #define FHEVC_FRAG_CONV1 0
 #define FHEVC_FRAG_CONV2 128
 #define FHEVC_FRAG_CONV3 (128 + 9 * 64)
-#define FHEVC_FRAG_TOTAL (128 + 9 * 64 + 2 * 18 * 64)
+#define FHEVC_FRAG_HAD (128 + 9 * 64 + 2 * 18 * 64)  // the source Hadamard's constant A operands (k_cnn.hip, HAD == 2): [M tile 2][K step 5][64]
+#define FHEVC_FRAG_TOTAL (FHEVC_FRAG_HAD + 2 * 5 * 64)
 // conv3 of the 16-bit form: 0 = v_mfma_f32_16x16x32_f16 (M tiles of 16 channels, one output row per chain), 1 = v_mfma_f32_32x32x16_f16
 // (the wave's 32 channels x two output rows 8 apart per MFMA, K step = one tap x 16 channels).  The fragment image differs:
 // kernel and build_weight_image read this switch
@@ -52,6 +53,7 @@ struct FhevcCnnWeights {
   int shift[3];
   int requant_mode[3];       // per layer: 0 general, 1 shift <= 7 (packed 16-bit shift), 2 shift == 8 and |accumulator| < 2^23 (byte gather)
   int i8;                    // 1: run that variant
+  int had_valu;              // 1: the fused source Hadamard stays on packed 16-bit VALU also for 8-bit content (FHEVC_HADAMARD_FORM=valu)
 };
 
 hipError_t fhevc_cnn_prepare_device();  // LDS opt-in of the depth kernel on the current device (once per context)

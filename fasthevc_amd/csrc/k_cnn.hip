@@ -123,7 +123,8 @@ struct Lds {
                                                             // four waves' partial 64-level sums; at [56..63] two sets of the four waves' source-
                                                             // Hadamard sums (the set of the CTU in flight and the set of the next one)
   static constexpr int HEADW_OFF = LOGIT_OFF + 64 * 4;      // int8 head weights: wh64, wh32, wh16 = 18432 B
-  static constexpr int LDS_BYTES = HEADW_OFF + 18432;       // 79808 -> two workgroups per CU (155.9 of 160 KiB) / 50048 -> three
+  static constexpr int HADP_OFF = HEADW_OFF + 18432;        // MFMA form of the source Hadamard: float partial sums [set 2][M tile 2][block 64]
+  static constexpr int LDS_BYTES = HADP_OFF + 1024;         // 80832 -> two workgroups per CU (157.9 of 160 KiB) / 51072 -> three
   static constexpr unsigned HALO_FILL = I8 ? 0x80808080u : 0u;  // "activation 0" in the halos of A1 and A2
   static_assert(A2_PLANE % 256 == 0, "conv3 reads lane groups of a ds_read_b128 from different planes");
   static_assert(33 * IN_PITCH * 4 + 4 * IN_PITCH * 4 <= R2_BYTES, "input tile (and conv1's one fragment read past it) must fit the A2 region");
@@ -324,9 +325,20 @@ __device__ __forceinline__ void conv1_store_i8(const f32x16& acc0, const f32x16&
   for (int k = 0; k < 8; ++k) m[k] = fmaxf(fmaxf(acc0[k], acc0[k + 8]), fmaxf(acc1[k], acc1[k + 8]));
   *reinterpret_cast<uint2*>(dst) = make_uint2(u8x4_floor_clamp(m[0], m[1], m[2], m[3]) ^ 0x80808080u, u8x4_floor_clamp(m[4], m[5], m[6], m[7]) ^ 0x80808080u);
 }
+#ifndef FHEVC_X_NOBIAS
+#define FHEVC_X_NOBIAS 0   // (sensitivity experiments, tools/experiments: 1 = no bias-tile reads, WRONG results, timing only)
+#endif
+#ifndef FHEVC_X_C3_HALF
+#define FHEVC_X_C3_HALF 0  // (sensitivity experiments: 1 = conv3 reads half of its fragments, WRONG results, timing only)
+#endif
 __device__ __forceinline__ i32x16 bias_tile_i8(const int* b32, int h)  // the integer twin of bias_tile
 {
   i32x16 acc;
+  if (FHEVC_X_NOBIAS) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0;
+    return acc;
+  }
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const int4 v = *reinterpret_cast<const int4*>(b32 + 8 * g + 4 * h);
@@ -526,8 +538,8 @@ __device__ __forceinline__ void conv3_pairs_i8(const unsigned char* base, const 
     const int g = 18 * S + 2 * t;
     acc0 = mfma_i8(wA3[t], ring[g % RING3], acc0);
     if (g + RING3 < 36) ring[g % RING3] = lds_frag(base + conv3_frag_off_i8(g + RING3));
-    acc1 = mfma_i8(wA3[t], ring[(g + 1) % RING3], acc1);
-    if (g + 1 + RING3 < 36) ring[(g + 1) % RING3] = lds_frag(base + conv3_frag_off_i8(g + 1 + RING3));
+    acc1 = mfma_i8(wA3[t], ring[(g + (FHEVC_X_C3_HALF ? 2 : 1)) % RING3], acc1);
+    if (!FHEVC_X_C3_HALF && g + 1 + RING3 < 36) ring[(g + 1) % RING3] = lds_frag(base + conv3_frag_off_i8(g + 1 + RING3));
   }
 }
 template <int VALU_PER_GROUP>
@@ -841,10 +853,12 @@ __device__ __forceinline__ unsigned long long stamp()
 
 // STAMPS = true is a separate diagnostic instantiation (fhevc_debug_cnn_phase_cycles): wave 0 of every workgroup
 // adds the cycles of each phase (incl. the barrier that ends it) into d_stamps[blockIdx.x * 8 + phase].
-// HAD: also write the per-CTU source Hadamard (d_had), computed from the samples the kernel loads anyway (one pass over the frame)
+// HAD: also write the per-CTU source Hadamard (d_had), computed from the samples the kernel loads anyway (one pass over the frame):
+//      1 = on packed 16-bit VALU from the prefetched samples (up to 10 bit: wave_src_hadamard), 2 = on the bf16 MFMA from the staged
+//      tile (8-bit content only: the tile holds the samples rounded to 8 bits; src_hadamard_mfma)
 // I8: conv2 and conv3 on v_mfma_i32_32x32x32_i8 with the activations as signed bytes (see Lds); the same integers come out.
 // I8 = 2: the same with the short requant forms (requant4_i8: conv2 mode 1, conv3 mode 2), where the host found them valid
-template <bool STAMPS, bool HAD, int ARITH>
+template <bool STAMPS, int HAD, int ARITH>
 __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn_depth_kernel(FhevcFrames F, FhevcCnnWeights W,
                                                                   uint8_t* __restrict__ d_depth, int32_t* __restrict__ d_had,
                                                                   int32_t* __restrict__ d_logits,
@@ -949,7 +963,7 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
     pos.f = vb / per_frame; pos.ry = (vb - pos.f * per_frame) / F.ctus_x; pos.cx = (vb - pos.f * per_frame) - pos.ry * F.ctus_x;
     step.f = g / per_frame; step.ry = (g - step.f * per_frame) / F.ctus_x; step.cx = (g - step.f * per_frame) - step.ry * F.ctus_x;
   }
-  Prefetched pre = prefetch_ctu<HAD>(F, vblock < total, pos, ld_row, ld_seg);
+  Prefetched pre = prefetch_ctu<HAD == 1>(F, vblock < total, pos, ld_row, ld_seg);
   // the heads' per-thread LDS rows (see P4): position (y, x) of quadrant `wave`, 16x16 block lane >> 4
   uint2 head_addr;
   {
@@ -976,7 +990,7 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
   if (vblock < total) {  // prologue: first CTU of this workgroup
     stage_ctu(lds, L::R2_OFF, pre, F, pos, tid, ld_row, ld_seg, shift_in, hc.in);
     zero_a1_halo<I8>(lds, tid, hc.a1);
-    if (HAD) {
+    if (HAD == 1) {
       const int hs = F.sample_bytes == 2 ? wave_src_hadamard<2>(pre, lane) : wave_src_hadamard<1>(pre, lane);
       if (lane == 0) logitL[56 + wave] = hs;
     }
@@ -998,6 +1012,17 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
     early_bq = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));                           \
   }
   FHEVC_CONV1_EARLY_READS
+  // HAD == 2: the source Hadamard's A operands (constant +-1 / 0 fragments) travel with them: five L2-hot loads per CTU, requested
+  // one phase before their MFMAs; an opaque lane offset keeps the loads inside the loop (hoisted they would be 20 kernel-long registers)
+  bf16x8 wH[5];
+#define FHEVC_HAD_FRAG_LOADS                                                                                                              \
+  if (HAD == 2) {                                                                                                                         \
+    unsigned hoff = (unsigned)(threadIdx.x & 63) * 16u + (unsigned)((threadIdx.x >> 6) & 1) * (5u * 64u * 16u); /* M tile = wave & 1 */  \
+    asm volatile("" : "+v"(hoff));                                                                                                        \
+    const unsigned char* hf = reinterpret_cast<const unsigned char*>(W.frag + FHEVC_FRAG_HAD) + hoff;                                     \
+    _Pragma("unroll") for (int st = 0; st < 5; ++st) wH[st] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(hf + st * 64 * 16)); \
+  }
+  FHEVC_HAD_FRAG_LOADS
 
   // Per CTU: P1 conv1 | P2 conv2 | P3 conv3 (next CTU's samples are requested) | P4 heads + next CTU staged into LDS |
   // P5 depth map + conv1 halo re-zeroed -- four barriers; P5 runs into the next P1 without one (disjoint LDS).
@@ -1032,6 +1057,36 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
       const unsigned char* fp = inb + wave * (IN_PITCH * 4);
       unsigned char* dp = lds + R1_OFF + (I8 ? 8 * h : h * A1_PLANE) + (wave + 1) * A1_ROW + (((r + 1) & 1) ? 0 : A1_EVEN) + ((r + 1) >> 1) * 16;  // column r (halo +1)
       bf16x8 bq = early_bq;  // = frag1(fp), in flight since before the previous CTU's depth phase
+      if (HAD == 2) {
+        // Source Hadamard of THIS CTU (TEncCu::updateCtuDataISlice / xCalcHADs8x8_ISlice, TEncCu.cpp:1230-1343) as one small GEMM on the
+        // bf16 MFMA, fed from the staged tile (8-bit content: the tile holds the samples themselves, exact in bf16): D[m][n] = sum_k
+        // A[m][k] B[k][n], m = one of the 64 coefficients (u, v) of the 2-D Walsh-Hadamard transform (M tile = wave & 1), n = one of
+        // the 64 blocks (N tile = wave >> 1: block rows 4 nt .., n = 8 (by & 3) + bx), k = a sample of the block.  The tile stores
+        // picture rows 2P - 1 (low half) and 2P (high half) in one dword, so a block's 8 rows span FIVE row pairs P = 4 by + s, the
+        // first and the last half used: 5 K steps of 16 slots = (2 rows) x (4 columns per lane half), the slots of rows -1 and 8 and
+        // the whole DC row carry zero weights (host: build_weight_image).  Products are +-sample, sums stay below 2^24: exact.
+        // Then sum |D| over the lane's 16 rows (abs is a source modifier), add the other lane half (permlane32 swap), and the
+        // (M tile, block) partial goes to LDS; wave 1 finishes the CTU's total in the depth phase.  ~25 VALU instead of ~130.
+        // (Runs BEFORE the conv1 units: its A operands were requested one phase early, like conv1's first reads, and are dead after the
+        // five MFMAs -- at the end of the phase they would be live across the conv1 units and spill.)
+        const int mt = wave & 1, nt = wave >> 1;
+        const unsigned* hb = reinterpret_cast<const unsigned*>(lds + L::R2_OFF) + (16 * nt + 4 * (r >> 3)) * IN_PITCH + 8 * (r & 7) + 1 + 4 * h;
+        f32x16 hacc;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) hacc[k] = 0.0f;
+#pragma unroll
+        for (int st = 0; st < 5; ++st) {
+          const unsigned* q = hb + st * IN_PITCH;  // 4-byte aligned only (column 8 bx + 1): two ds_read2_b32
+          const bf16x8 smp = __builtin_bit_cast(bf16x8, make_uint4(q[0], q[1], q[2], q[3]));
+          hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wH[st], smp, hacc, 0, 0, 0);
+        }
+        float t = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += __builtin_fabsf(hacc[k]);
+        const u32x2_t sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(t), __float_as_uint(t), false, false);
+        t = __uint_as_float(sw.x) + __uint_as_float(sw.y);   // rows of both lane halves: the (M tile, block) partial, in every lane
+        if (h == 0) reinterpret_cast<float*>(lds + L::HADP_OFF)[128 * had_set + 64 * mt + 32 * nt + r] = t;
+      }
 #pragma unroll FHEVC_CONV1_UNROLL
       for (int i = 0; i < 8; ++i) {
         const f32x16 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA1a, bq, bias1, 0, 0, 0);
@@ -1137,7 +1192,7 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
     FHEVC_STAMP(2)
 
     // ================= P3: conv3 (32 -> 64), K = 9 taps x 32 ch, requant to u8 =================
-    pre = prefetch_ctu<HAD>(F, work + (int)gridDim.x < total, next, ld_row, ld_seg);  // next CTU's samples travel under conv3 and the heads
+    pre = prefetch_ctu<HAD == 1>(F, work + (int)gridDim.x < total, next, ld_row, ld_seg);  // next CTU's samples travel under conv3 and the heads
     if constexpr (I8) {
       FHEVC_PHASE_IDS
       FHEVC_PRIO_ON(2)
@@ -1224,7 +1279,7 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
       FHEVC_PRIO_OFF(2)
 #undef FHEVC_ROW_OFF
     }
-    if (HAD) {  // the next CTU's source Hadamard from its samples in flight: VALU work at the tail of the MFMA-bound phase
+    if (HAD == 1) {  // the next CTU's source Hadamard from its samples in flight: VALU work at the tail of the MFMA-bound phase
       FHEVC_PHASE_IDS
       const int hs = F.sample_bytes == 2 ? wave_src_hadamard<2>(pre, lane) : wave_src_hadamard<1>(pre, lane);
       if (lane == 0) logitL[56 + 4 * (had_set ^ 1) + wave] = hs;
@@ -1348,6 +1403,7 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
     __syncthreads();
     FHEVC_STAMP(4)
     FHEVC_CONV1_EARLY_READS  // the next CTU's tile is staged (harmless reads if there is none)
+    FHEVC_HAD_FRAG_LOADS
 
     // ================= P5: top-down depth map (forced split at the picture edge), branch-free =================
     {
@@ -1380,9 +1436,16 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
         d_depth_max[o * 256 + tid] = (uint8_t)d;
       }
       if (d_logits != nullptr && tid < 42) d_logits[o * 42 + tid] = tid == 0 ? l64.x : (tid == 1 ? l64.y : logitL[tid]);
-      if (HAD && tid == 64) {  // (a lane of wave 1: wave 0 also assembles the split-flag word)
+      if (HAD == 1 && tid == 64) {  // (a lane of wave 1: wave 0 also assembles the split-flag word)
         const int4 hp = *reinterpret_cast<const int4*>(logitL + 56 + 4 * had_set);
         d_had[o] = hp.x + hp.y + hp.z + hp.w;
+      }
+      if (HAD == 2 && wave == 1) {  // MFMA form: lane = 8x8 block; its two M tiles' sums of |coefficients| (DC row zeroed), (s + 2) >> 2, CTU total
+        const float* hp = reinterpret_cast<const float*>(lds + L::HADP_OFF) + 128 * had_set + lane;
+        const int sb = (int)(hp[0] + hp[64]);                     // exact: integers below 2^24
+        int v = dpp_row_sum((sb + 2) >> 2);                      // xCalcHADs8x8_ISlice: (sum + 2) >> 2 per block (TEncCu.cpp:1319-1321)
+        v = __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+        if (lane == 0) d_had[o] = v;
       }
       if (d_flags != nullptr && wave == 0) {  // the 21 decisions as one word: lane k < 21 evaluates node k
         const int k = lane;
@@ -1416,6 +1479,7 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
   }
 #undef FHEVC_STAMP
 #undef FHEVC_CONV1_EARLY_READS
+#undef FHEVC_HAD_FRAG_LOADS
 }
 
 // split-flag words -> depth maps (whole pictures, CTU raster order): one thread per row of 16 units = one 16-byte store,
@@ -1459,9 +1523,10 @@ hipError_t fhevc_launch_expand_flags(const FhevcFrames& fr, const uint32_t* d_fl
 // > 64 KiB of dynamic LDS needs an opt-in per function AND per device: fhevc_create calls this with its device current
 hipError_t fhevc_cnn_prepare_device()
 {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_kernel<false, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, Lds<false>::LDS_BYTES);
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_kernel<false, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, Lds<false>::LDS_BYTES);
-  return e;  // (the i8 variant's 50 048 B need no opt-in)
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_kernel<false, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, Lds<false>::LDS_BYTES);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_kernel<false, 1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, Lds<false>::LDS_BYTES);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_kernel<false, 2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, Lds<false>::LDS_BYTES);
+  return e;  // (the i8 variant's 51 072 B need no opt-in)
 }
 
 // d_had != nullptr: the fused source Hadamard (only where fhevc_cnn_can_fuse_hadamard says so)
@@ -1477,7 +1542,7 @@ bool fhevc_cnn_can_fuse_hadamard(const FhevcFrames& fr)
 }
 
 namespace {
-template <bool STAMPS, bool HAD, int ARITH>
+template <bool STAMPS, int HAD, int ARITH>
 void launch_depth_kernel(int grid, hipStream_t stream, const FhevcFrames& fr, const FhevcCnnWeights& w, uint8_t* d_depth, int32_t* d_had, int32_t* d_logits,
                          uint32_t* d_flags, unsigned long long* d_stamps, uint8_t* d_depth_max, int margin_split, int margin_stop)
 {
@@ -1504,12 +1569,16 @@ hipError_t fhevc_launch_cnn(const FhevcFrames& fr, const FhevcCnnWeights& w, uin
   int grid = cnn_wg_per_cu(w) * num_cus;
   if (total < grid) grid = (int)total;
 #define FHEVC_LAUNCH(HAD, ARITH) launch_depth_kernel<false, HAD, ARITH>(grid, stream, fr, w, d_depth, d_had, d_logits, d_flags, nullptr, d_depth_max, margin_split, margin_stop)
-  const bool had = d_had != nullptr;
+  // the fused source Hadamard's form: on the MFMA from the staged tile for 8-bit content (the tile IS the samples), on packed
+  // 16-bit VALU from the prefetched samples otherwise (the tile is rounded to 8 bits); w.had_valu forces the latter (A/B, tests)
+  const int had = d_had == nullptr ? 0 : (fr.bit_depth == 8 && !w.had_valu) ? 2 : 1;
+#define FHEVC_LAUNCH_HAD(ARITH) do { if (had == 2) FHEVC_LAUNCH(2, ARITH); else if (had == 1) FHEVC_LAUNCH(1, ARITH); else FHEVC_LAUNCH(0, ARITH); } while (0)
   switch (cnn_arith(w)) {
-    case 2: if (had) FHEVC_LAUNCH(true, 2); else FHEVC_LAUNCH(false, 2); break;
-    case 1: if (had) FHEVC_LAUNCH(true, 1); else FHEVC_LAUNCH(false, 1); break;
-    default: if (had) FHEVC_LAUNCH(true, 0); else FHEVC_LAUNCH(false, 0); break;
+    case 2: FHEVC_LAUNCH_HAD(2); break;
+    case 1: FHEVC_LAUNCH_HAD(1); break;
+    default: FHEVC_LAUNCH_HAD(0); break;
   }
+#undef FHEVC_LAUNCH_HAD
 #undef FHEVC_LAUNCH
   return hipGetLastError();
 }
@@ -1527,10 +1596,10 @@ hipError_t fhevc_launch_cnn_stamped(const FhevcFrames& fr, const FhevcCnnWeights
   if (total <= 0) return hipSuccess;
   const int arith = cnn_arith(w);
   if (arith == 0) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_kernel<true, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, Lds<false>::LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_kernel<true, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, Lds<false>::LDS_BYTES);
     if (e != hipSuccess) return e;
-    launch_depth_kernel<true, false, 0>(grid, stream, fr, w, d_depth, nullptr, nullptr, nullptr, d_stamps, nullptr, 0, 0);
-  } else if (arith == 1) launch_depth_kernel<true, false, 1>(grid, stream, fr, w, d_depth, nullptr, nullptr, nullptr, d_stamps, nullptr, 0, 0);
-  else launch_depth_kernel<true, false, 2>(grid, stream, fr, w, d_depth, nullptr, nullptr, nullptr, d_stamps, nullptr, 0, 0);
+    launch_depth_kernel<true, 0, 0>(grid, stream, fr, w, d_depth, nullptr, nullptr, nullptr, d_stamps, nullptr, 0, 0);
+  } else if (arith == 1) launch_depth_kernel<true, 0, 1>(grid, stream, fr, w, d_depth, nullptr, nullptr, nullptr, d_stamps, nullptr, 0, 0);
+  else launch_depth_kernel<true, 0, 2>(grid, stream, fr, w, d_depth, nullptr, nullptr, nullptr, d_stamps, nullptr, 0, 0);
   return hipGetLastError();
 }

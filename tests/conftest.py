@@ -33,6 +33,8 @@ def cnn_arith(request, monkeypatch):
     monkeypatch.setenv("FHEVC_CNN_ARITH", "f16" if arith == "f16" else "i8")
     if arith == "i8-general-requant":
         monkeypatch.setenv("FHEVC_CNN_REQUANT", "general")
+        monkeypatch.setenv("FHEVC_HADAMARD_FORM", "mfma")   # and the fused source Hadamard's MFMA form at 8 bit (default: the VALU form)
     else:
         monkeypatch.delenv("FHEVC_CNN_REQUANT", raising=False)
+        monkeypatch.delenv("FHEVC_HADAMARD_FORM", raising=False)
     return arith
