@@ -38,6 +38,7 @@ struct fhevc_ctx {
   hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
   // kernel timing
   bool fuse_hadamard = true;  // FHEVC_FUSE_HADAMARD=0 keeps the stand-alone Hadamard launch (A/B measurements)
+  bool cnn_pipe = false;      // FHEVC_CNN_PIPE=1: the i8 form as the two-stage software pipeline over CTUs (k_cnn.hip: fhevc_cnn_depth_pipe_kernel)
   bool had_valu = true;       // FHEVC_HADAMARD_FORM=mfma: the fused Hadamard of 8-bit content on the bf16 MFMA from the staged tile instead of packed
                               // 16-bit VALU (parity-green, and measured 7 % SLOWER in round 3: profiles/r03_ab_hadamard_forms.log) -- kept for A/B and tests
   bool timing = false;
@@ -295,6 +296,7 @@ FhevcCnnWeights cnn_weights(const fhevc_ctx* c)
   w.requant_mode[0] = 0; w.requant_mode[1] = c->requant_mode[1]; w.requant_mode[2] = c->requant_mode[2];
   w.i8 = c->cnn_i8 ? 1 : 0;
   w.had_valu = c->had_valu ? 1 : 0;
+  w.pipe = c->cnn_pipe ? 1 : 0;
   return w;
 }
 
@@ -379,6 +381,7 @@ int fhevc_create(fhevc_ctx** out, const fhevc_cfg* cfg)
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) { delete c; return FHEVC_E_NO_DEVICE; }  // code object is gfx950-only
   c->num_cus = prop.multiProcessorCount;
   if (const char* fz = std::getenv("FHEVC_FUSE_HADAMARD")) c->fuse_hadamard = fz[0] != '0';
+  if (const char* pp = std::getenv("FHEVC_CNN_PIPE")) c->cnn_pipe = pp[0] == '1';
   if (const char* hf = std::getenv("FHEVC_HADAMARD_FORM")) c->had_valu = std::strcmp(hf, "mfma") != 0;
   // arithmetic of conv2 / conv3 in the depth kernel: "f16" (16-bit MFMAs) or "i8" (v_mfma_i32_32x32x32_i8); both are exact
   if (const char* ar = std::getenv("FHEVC_CNN_ARITH")) c->cnn_i8 = std::strcmp(ar, "f16") != 0;

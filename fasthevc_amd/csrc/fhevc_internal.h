@@ -53,7 +53,8 @@ struct FhevcCnnWeights {
   int shift[3];
   int requant_mode[3];       // per layer: 0 general, 1 shift <= 7 (packed 16-bit shift), 2 shift == 8 and |accumulator| < 2^23 (byte gather)
   int i8;                    // 1: run that variant
-  int had_valu;              // 1: the fused source Hadamard stays on packed 16-bit VALU also for 8-bit content (FHEVC_HADAMARD_FORM=valu)
+  int had_valu;              // 1: the fused source Hadamard on packed 16-bit VALU also for 8-bit content (default; FHEVC_HADAMARD_FORM=mfma: 0)
+  int pipe;                  // 1: the i8 form runs as the two-stage software pipeline over CTUs (fhevc_cnn_depth_pipe_kernel; FHEVC_CNN_PIPE)
 };
 
 hipError_t fhevc_cnn_prepare_device();  // LDS opt-in of the depth kernel on the current device (once per context)

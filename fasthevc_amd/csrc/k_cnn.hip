@@ -27,6 +27,7 @@
 //     coordinates are re-derived per phase so that nothing address-like stays live across the conv2 phase (no spills).
 #include "fhevc_internal.h"
 #include <cstdlib>
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8;   // 8 x 16-bit operand slots of an MFMA fragment (bf16 for conv1, f16 for conv2/conv3)
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
@@ -34,6 +35,17 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
 
 namespace {
+
+// compile-time loop: f(std::integral_constant<int, I>) for I = B .. E-1 (a 36-step body with nested loops is past what `#pragma unroll`
+// unrolls; register arrays indexed by a loop variable that stays a variable go through v_movrel / scratch)
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
+}
 
 // ---- LDS map (bytes) ---------------------------------------------------------------------------------------
 // conv1 output: 32x32 + 1 halo each side = 34 x 34 positions, 16 B per position and plane
@@ -661,18 +673,30 @@ __device__ __forceinline__ void had_exchange(unsigned& P, unsigned& Q)
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
 // -> the sum over this wave's 16 whole 8x8 blocks of (sum |WHT8x8| - |DC| + 2) >> 2, in every lane.  Threads without samples
 // (rows or columns outside the picture) pass zeros: their blocks then contribute (0 + 2) >> 2 = 0.
+// the thread's 16 samples as eight registers of two 16-bit samples each (uint8 planes: bytes -> 16-bit pairs, selector 0x0C = zero byte)
 template <int SB>
-__device__ __forceinline__ int wave_src_hadamard(const Prefetched& pre, int lane)
+__device__ __forceinline__ void hadamard_samples(const Prefetched& pre, unsigned (&r)[8])
 {
-  unsigned r[8];
   if (SB == 2) {
     r[0] = pre.a.x; r[1] = pre.a.y; r[2] = pre.a.z; r[3] = pre.a.w; r[4] = pre.b.x; r[5] = pre.b.y; r[6] = pre.b.z; r[7] = pre.b.w;
-  } else {  // bytes -> 16-bit pairs (selector 0x0C = zero byte)
+  } else {
     r[0] = __builtin_amdgcn_perm(0u, pre.a.x, 0x0C010C00u); r[1] = __builtin_amdgcn_perm(0u, pre.a.x, 0x0C030C02u);
     r[2] = __builtin_amdgcn_perm(0u, pre.a.y, 0x0C010C00u); r[3] = __builtin_amdgcn_perm(0u, pre.a.y, 0x0C030C02u);
     r[4] = __builtin_amdgcn_perm(0u, pre.a.z, 0x0C010C00u); r[5] = __builtin_amdgcn_perm(0u, pre.a.z, 0x0C030C02u);
     r[6] = __builtin_amdgcn_perm(0u, pre.a.w, 0x0C010C00u); r[7] = __builtin_amdgcn_perm(0u, pre.a.w, 0x0C030C02u);
   }
+}
+__device__ __forceinline__ int wave_src_hadamard_core(unsigned (&r)[8], int lane);
+template <int SB>
+__device__ __forceinline__ int wave_src_hadamard(const Prefetched& pre, int lane)
+{
+  unsigned r[8];
+  hadamard_samples<SB>(pre, r);
+  return wave_src_hadamard_core(r, lane);
+}
+// the transform itself: straight-line code (the pipelined kernel places it inside conv2's MFMA chain)
+__device__ __forceinline__ int wave_src_hadamard_core(unsigned (&r)[8], int lane)
+{
   int t[2];  // per block: 2 * (this lane's share of sum |coefficients| / 2) - (this lane's share of the block's sample sum)
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
@@ -732,6 +756,7 @@ __device__ __forceinline__ unsigned sample8_pair(unsigned w, int shift, unsigned
 
 // Stage one CTU into LDS (region R2): 8-bit samples as bf16, two picture rows per dword, halo = 128 (the centre).
 // halo coordinates: hy = row + 1, hx = col + 1; dword (hy >> 1) * IN_PITCH + hx, half (hy & 1)
+template <bool HALO = true>
 __device__ __forceinline__ void stage_ctu(unsigned char* lds, int r2_off, const Prefetched& pre, const FhevcFrames& F, CtuPos c,
                                           int tid, int ld_row, int ld_seg, int shift_in, unsigned in_cells)
 {
@@ -771,10 +796,12 @@ __device__ __forceinline__ void stage_ctu(unsigned char* lds, int r2_off, const 
       dst[2 * j] = (unsigned short)(__float_as_uint((float)v) >> 16);
     }
   }
-  // input halo: 66*66 - 64*64 = 260 two-byte cells of bf16(128)
-  asm volatile("" : "+v"(in_cells));
-  *reinterpret_cast<unsigned short*>(lds + (in_cells & 0xFFFF)) = 0x4300;
-  if (tid < 260 - 256) *reinterpret_cast<unsigned short*>(lds + (in_cells >> 16)) = 0x4300;
+  // input halo: 66*66 - 64*64 = 260 two-byte cells of bf16(128) (the pipelined kernel's tile region is never overwritten: it fills the halo once)
+  if (HALO) {
+    asm volatile("" : "+v"(in_cells));
+    *reinterpret_cast<unsigned short*>(lds + (in_cells & 0xFFFF)) = 0x4300;
+    if (tid < 260 - 256) *reinterpret_cast<unsigned short*>(lds + (in_cells >> 16)) = 0x4300;
+  }
 }
 // LDS byte offsets of the halo cells a thread zeroes (computed once per kernel: the index arithmetic with its three-way
 // divergence cost ~700 cycles per CTU when it ran inside the phases).  Cell e of: the conv1 output halo (264 x 16 B),
@@ -1482,6 +1509,430 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
 #undef FHEVC_HAD_FRAG_LOADS
 }
 
+
+// =====================================================================================================================================
+// The i8 form as a TWO-STAGE SOFTWARE PIPELINE over the CTUs of a workgroup (round 3; FHEVC_CNN_PIPE).  Same network, same arithmetic, same
+// per-wave work split as fhevc_cnn_depth_kernel<.., ARITH = 1 | 2>; what changes is WHEN each piece runs.  The kernel above runs a CTU
+// through five phases with four barriers, and in three of them (conv1's pooling / requant, the heads, staging + depth map) the matrix
+// pipe has nothing to do while in the other two the vector ALUs idle: the counters show matrix and vector instructions co-executing in
+// only a third of the matrix-busy cycles.  Here every barrier interval pairs an MFMA-bound piece of one CTU with VALU-bound pieces of
+// its neighbours IN THE SAME WAVE, so the vector work sits in the shadow of the wave's own MFMA chain:
+//     X(k):  conv2(k)   ||  heads(k-1)  +  staging(k+1)  +  source Hadamard(k+1)          barrier
+//     Y(k):  conv3(k)   ||  conv1(k+1)  +  depth map(k-1)  +  prefetch(k+2)               barrier
+// Two barriers per CTU instead of four.  Every activation map has a region of its own (tile, A1, A2, A3 are all live in both
+// intervals): 76 800 B of LDS, two workgroups per CU, up to 256 VGPRs (conv3's and conv1's accumulators are live together).  The halos
+// are written once per kernel (no region is ever recycled for another map).
+//   hazards: conv2(k) reads A1(k) (written in Y(k-1)) and writes A2 (last read by conv3(k-1) in Y(k-1)); staging(k+1) writes the tile
+//   (last read by conv1(k) in Y(k-1)); heads(k-1) read A3(k-1) (written in Y(k-1)); conv3(k) writes A3 (last read in X(k)); conv1(k+1)
+//   writes A1 (last read in X(k)).  Logits: set k & 1 is initialised in Y(k), summed by heads(k) in X(k+1), read by the depth map in Y(k+1).
+struct LdsPipe {
+  static constexpr int A1_OFF = 0;                                // conv1 output [35][36][16 B] (a - 128), parity-split columns
+  static constexpr int A3_OFF = A1_OFF + 35 * A1_ROW;             // 20160: conv3 output [256][64 B], swizzled chunks
+  static constexpr int A2_OFF = A3_OFF + 16384;                   // 36544: conv2 output, 2 planes [18][18][16 B]
+  static constexpr int T_OFF = A2_OFF + 2 * A2_PLANE;             // 47296: input tile bf16 [33 row pairs][68 dwords] (+ conv1's one fragment read past it)
+  static constexpr int BIAS_OFF = T_OFF + 37 * IN_PITCH * 4;      // 57360: b1 (float) b2 b3 (int32)
+  static constexpr int LOGIT_OFF = BIAS_OFF + 112 * 4;            // 57808: two sets of 64 ints (as Lds::LOGIT_OFF [0..51])
+  static constexpr int HADS_OFF = LOGIT_OFF + 2 * 64 * 4;         // 58320: four sets of the four waves' source-Hadamard sums
+  static constexpr int HEADW_OFF = HADS_OFF + 16 * 4;             // 58384: wh64 (8192 B) + the MFMA image of wh32 / wh16 (10240 B)
+  static constexpr int LDS_BYTES = HEADW_OFF + 18432;             // 76816
+  static_assert(A3_OFF % 16 == 0 && A2_OFF % 16 == 0 && T_OFF % 16 == 0 && BIAS_OFF % 16 == 0 && LOGIT_OFF % 16 == 0 && HEADW_OFF % 16 == 0, "");
+  static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+};
+#ifndef FHEVC_PIPE_RING3
+#define FHEVC_PIPE_RING3 4
+#endif
+#ifndef FHEVC_PIPE_SCHED_X
+#define FHEVC_PIPE_SCHED_X 9    // VALU instructions offered per (MFMA, fragment read) group of conv2's chains in interval X: Hadamard, heads, pools, requant
+#endif
+#ifndef FHEVC_PIPE_SCHED_Y
+#define FHEVC_PIPE_SCHED_Y 10   // VALU instructions offered per conv3 MFMA step of interval Y (0: no pipeline description)
+#endif
+
+// top-down depth map of one CTU from its logits (the depth phase of the kernel above, as a function: the pipelined kernel needs it twice)
+__device__ __forceinline__ void depth_map_of_ctu(const FhevcFrames& F, const int* logitL, const int* hads, int tid, int lane, int wave, int f, int cy, int cx,
+                                                 int band_rows, int hb64a, int hb64b, int margin_split, int margin_stop, uint8_t* __restrict__ d_depth,
+                                                 uint8_t* __restrict__ d_depth_max, int32_t* __restrict__ d_logits, uint32_t* __restrict__ d_flags,
+                                                 int32_t* __restrict__ d_had, bool had)
+{
+  const int vw = min(64, F.width - cx * 64), vh = min(64, F.height - cy * 64);
+  const int ux = tid & 15, uy = tid >> 4;
+  const int4 pa = *reinterpret_cast<const int4*>(logitL + 44), pb = *reinterpret_cast<const int4*>(logitL + 48);
+  const int2 l64 = make_int2(hb64a + pa.x + pa.z + pb.x + pb.z, hb64b + pa.y + pa.w + pb.y + pb.w);
+  const int2 l32 = *reinterpret_cast<const int2*>(logitL + 2 * (1 + (uy >> 3) * 2 + (ux >> 3)));
+  const int2 l16 = *reinterpret_cast<const int2*>(logitL + 2 * (5 + (uy >> 2) * 4 + (ux >> 2)));
+  const bool e64 = (vw < 64) || (vh < 64);
+  bool inside = true, e32 = false, e16 = false;
+  if (e64) {
+    inside = (ux * 4 < vw) && (uy * 4 < vh);
+    e32 = ((ux >> 3) * 32 + 32 > vw) || ((uy >> 3) * 32 + 32 > vh);
+    e16 = ((ux >> 2) * 16 + 16 > vw) || ((uy >> 2) * 16 + 16 > vh);
+  }
+  const int d64 = l64.y - l64.x, d32 = l32.y - l32.x, d16 = l16.y - l16.x;
+  const long long o = (long long)(f * band_rows + (cy - F.row_begin)) * F.ctus_x + cx;
+  {
+    const bool s64 = e64 || d64 > margin_split, s32 = e32 || d32 > margin_split, s16 = e16 || d16 > margin_split;
+    const int d = (inside && s64) ? (s32 ? (s16 ? 3 : 2) : 1) : 0;
+    d_depth[o * 256 + tid] = (uint8_t)d;
+  }
+  if (d_depth_max != nullptr) {
+    const bool s64 = e64 || d64 > -margin_stop, s32 = e32 || d32 > -margin_stop, s16 = e16 || d16 > -margin_stop;
+    const int d = (inside && s64) ? (s32 ? (s16 ? 3 : 2) : 1) : 0;
+    d_depth_max[o * 256 + tid] = (uint8_t)d;
+  }
+  if (d_logits != nullptr && tid < 42) d_logits[o * 42 + tid] = tid == 0 ? l64.x : (tid == 1 ? l64.y : logitL[tid]);
+  if (had && tid == 64) {
+    const int4 hp = *reinterpret_cast<const int4*>(hads);
+    d_had[o] = hp.x + hp.y + hp.z + hp.w;
+  }
+  if (d_flags != nullptr && wave == 0) {  // the 21 decisions as one word: lane k < 21 evaluates node k
+    const int k = lane;
+    const int bi = k - 5, qq = k < 5 ? k - 1 : (bi >> 3) * 2 + ((bi >> 1) & 1);
+    const int qx = (qq & 1) * 32, qy = (qq >> 1) * 32, bxx = (bi & 3) * 16, byy = (bi >> 2) * 16;
+    const bool n64 = (vw < 64) || (vh < 64) || (l64.y - l64.x > margin_split);
+    bool bit = n64;
+    if (k >= 1 && k < 21) {
+      const int2 a32 = *reinterpret_cast<const int2*>(logitL + 2 * (1 + qq));
+      const bool n32 = n64 && (qx < vw) && (qy < vh) && ((qx + 32 > vw) || (qy + 32 > vh) || (a32.y - a32.x > margin_split));
+      bit = n32;
+      if (k >= 5) {
+        const int2 a16 = *reinterpret_cast<const int2*>(logitL + 2 * k);
+        bit = n32 && (bxx < vw) && (byy < vh) && ((bxx + 16 > vw) || (byy + 16 > vh) || (a16.y - a16.x > margin_split));
+      }
+    }
+    const unsigned long long m = __ballot(bit && k < 21);
+    if (lane == 0) d_flags[o] = (uint32_t)(m & 0x1FFFFFu);
+  }
+}
+
+template <int HAD, int ARITH>
+__global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_pipe_kernel(FhevcFrames F, FhevcCnnWeights W, uint8_t* __restrict__ d_depth, int32_t* __restrict__ d_had,
+                                                                       int32_t* __restrict__ d_logits, uint32_t* __restrict__ d_flags,
+                                                                       uint8_t* __restrict__ d_depth_max, int margin_split, int margin_stop)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  __builtin_amdgcn_s_setreg((1 << 11) | 1, 2);  // fp32 rounding toward -inf: v_cvt_pk_u8_f32 = floor + clamp (conv1's requant); see the kernel above
+  using P = LdsPipe;
+  constexpr bool FASTRQ = ARITH == 2;
+  constexpr int RING3P = FHEVC_PIPE_RING3;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int hb64a = W.bhead[0], hb64b = W.bhead[1] + W.bhead[6 + 0 * 52 + F.qp];
+  const int hb32a = W.bhead[2], hb32b = W.bhead[3] + W.bhead[6 + 1 * 52 + F.qp];
+  const int hb16a = W.bhead[4], hb16b = W.bhead[5] + W.bhead[6 + 2 * 52 + F.qp];
+  // ---- resident weight fragments: 8 + 24 + 36 registers ----
+  const bf16x8 wA1a = __builtin_bit_cast(bf16x8, W.frag[FHEVC_FRAG_CONV1 + lane]);
+  const bf16x8 wA1b = __builtin_bit_cast(bf16x8, W.frag[FHEVC_FRAG_CONV1 + 64 + lane]);
+  bf16x8 wA2[9], wA3[18];
+  const int tile3 = wave & 1;
+#pragma unroll
+  for (int s = 0; s < 6; ++s) wA2[s] = __builtin_bit_cast(bf16x8, W.frag_i8[FHEVC_FRAGI8_CONV2 + s * 64 + lane]);
+#pragma unroll
+  for (int s = 0; s < 9; ++s) wA3[s] = __builtin_bit_cast(bf16x8, W.frag_i8[FHEVC_FRAGI8_CONV3 + (tile3 * 9 + s) * 64 + lane]);
+  const int shift2 = W.shift[1], shift3 = W.shift[2];
+
+  float* biasL = reinterpret_cast<float*>(lds + P::BIAS_OFF);
+  int* logit0 = reinterpret_cast<int*>(lds + P::LOGIT_OFF);
+  int* hadsL = reinterpret_cast<int*>(lds + P::HADS_OFF);
+  if (tid < 112) {
+    if (tid >= 16) reinterpret_cast<int*>(biasL)[tid] = W.bias_i8[tid];
+    else biasL[tid] = W.bias[tid] * W.scale[0];
+  }
+  // wh64 with its chunk swizzle, and the MFMA image of wh32 / wh16 (as in the kernel above)
+  for (int i = tid; i < 8192 / 16; i += 256) {
+    const int row = i >> 2, c = i & 3, sw = (row >> 3) & 3;
+    *reinterpret_cast<uint4*>(lds + P::HEADW_OFF + row * 64 + ((c ^ sw) << 4)) = reinterpret_cast<const uint4*>(W.whead)[i];
+  }
+  for (int i = tid; i < HEADM_BYTES / 16; i += 256) {
+    const int j = i / 40, rem = i - j * 40, n = rem >> 2, kg = rem & 3;
+    int src;
+    if (n < 2) src = 16384 + (n * 16 + j) * 64;
+    else {
+      const int sub = (n - 2) >> 1, cls = n & 1, py = j >> 2, px = j & 3;
+      src = 8192 + (cls * 64 + ((sub >> 1) * 4 + py) * 8 + (sub & 1) * 4 + px) * 64;
+    }
+    *reinterpret_cast<uint4*>(lds + P::HEADW_OFF + HEADM_OFF + i * 16) = *reinterpret_cast<const uint4*>(W.whead + src + kg * 16);
+  }
+  // the halos, once: "activation 0" (0x80) everywhere in A1 and A2, bf16(128) everywhere in the tile; the interiors are rewritten per CTU
+  for (int i = tid; i < (35 * A1_ROW) / 16; i += 256) *reinterpret_cast<uint4*>(lds + P::A1_OFF + i * 16) = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
+  for (int i = tid; i < (2 * A2_PLANE) / 16; i += 256) *reinterpret_cast<uint4*>(lds + P::A2_OFF + i * 16) = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
+  for (int i = tid; i < (37 * IN_PITCH * 4) / 16; i += 256) *reinterpret_cast<uint4*>(lds + P::T_OFF + i * 16) = make_uint4(0x43004300u, 0x43004300u, 0x43004300u, 0x43004300u);
+  if (tid < 128 + 16) logit0[tid] = 0;
+  __syncthreads();  // the fills above and the first staging below write the same tile cells from different threads
+
+  const int band_rows = F.row_end - F.row_begin;
+  const int per_frame = band_rows * F.ctus_x;
+  const int total = per_frame * F.num_frames;
+  const int shift_in = F.bit_depth - 8;
+  const int ld_row = tid >> 2, ld_seg = tid & 3;
+  const int grid = (int)gridDim.x;
+  const int vblock = (grid & 7) ? (int)blockIdx.x : (int)((blockIdx.x & 7) * (grid >> 3) + (blockIdx.x >> 3));
+  CtuPos pos, step;
+  {
+    const int vb = min(vblock, total - 1);
+    pos.f = vb / per_frame; pos.ry = (vb - pos.f * per_frame) / F.ctus_x; pos.cx = (vb - pos.f * per_frame) - pos.ry * F.ctus_x;
+    step.f = grid / per_frame; step.ry = (grid - step.f * per_frame) / F.ctus_x; step.cx = (grid - step.f * per_frame) - step.ry * F.ctus_x;
+  }
+  // heads: per-thread LDS rows (as in the kernel above)
+  uint2 head_addr;
+  {
+    const int q = wave, blk = lane >> 4;
+    const int y = (q >> 1) * 8 + (blk >> 1) * 4 + ((lane >> 2) & 3), x = (q & 1) * 8 + (blk & 1) * 4 + (lane & 3);
+    const unsigned psw = (x >> 2) & 3, sw64 = (y >> 1) & 3;
+    const unsigned a_0 = (unsigned)(y * 16 + x) * 64 + (psw << 4);
+    const unsigned w64_0 = (unsigned)((y >> 1) * 8 + (x >> 1)) * 64 + (sw64 << 4);
+    head_addr = make_uint2(a_0, w64_0);
+  }
+  unsigned headm_addr;
+  {
+    const int m = lane & 15, kg = lane >> 4, by = m >> 2, bx = m & 3;
+    const unsigned am = (unsigned)((4 * by + wave) * 16 + 4 * bx) * 64 + ((unsigned)(kg ^ bx) << 4);
+    const unsigned bm = (unsigned)(HEADM_OFF + 4 * wave * HEADM_STEP + min(m, 9) * 64 + 16 * kg);
+    headm_addr = am | (bm << 16);
+  }
+  // ---- the pieces ----
+  // conv1 of the CTU whose samples sit in the tile: T -> A1 (8 units = pooled rows wave, wave + 4, ..: see P1 of the kernel above)
+  f32x16 bias1;
+  {
+    const float4 b0 = *reinterpret_cast<const float4*>(W.bias + 8 * h), b1 = *reinterpret_cast<const float4*>(W.bias + 8 * h + 4);
+    const float sc = W.scale[0];
+    bias1[0] = b0.x * sc; bias1[1] = b0.y * sc; bias1[2] = b0.z * sc; bias1[3] = b0.w * sc;
+    bias1[4] = b1.x * sc; bias1[5] = b1.y * sc; bias1[6] = b1.z * sc; bias1[7] = b1.w * sc;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bias1[8 + i] = bias1[i];
+  }
+  auto frag1 = [](const unsigned char* p) {
+    const uint2 lo = *reinterpret_cast<const uint2*>(p);
+    const uint2 hi = *reinterpret_cast<const uint2*>(p + IN_PITCH * 4);
+    return __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+  };
+  const unsigned char* c1_in = lds + P::T_OFF + (2 * r + 2 * h) * 4 + wave * (IN_PITCH * 4);
+  unsigned char* c1_out = lds + P::A1_OFF + 8 * h + (wave + 1) * A1_ROW + (((r + 1) & 1) ? 0 : A1_EVEN) + ((r + 1) >> 1) * 16;
+#define FHEVC_PIPE_CONV1_UNIT(i)                                                                                   \
+  {                                                                                                                \
+    const bf16x8 bq_ = frag1(c1_in + (i) * (4 * IN_PITCH * 4));                                                    \
+    const f32x16 acc0_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA1a, bq_, bias1, 0, 0, 0);                       \
+    const f32x16 acc1_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA1b, bq_, bias1, 0, 0, 0);                       \
+    conv1_store_i8(acc0_, acc1_, c1_out + (i) * (4 * A1_ROW));                                                     \
+  }
+  // conv2: A1 -> A2 (lane -> pooled position and units as in P2 of the kernel above)
+  const int q2 = r >> 2;
+  const int pr2 = (q2 ^ (q2 >> 1) ^ (q2 >> 2)) & 1, pc2 = ((r >> 3) << 2) | (r & 3);
+  const unsigned char* a1p = lds + P::A1_OFF + (2 * pr2 + h) * A1_ROW + pc2 * 16;
+  unsigned char* a2dst = lds + P::A2_OFF + ((pr2 + 1) * A2_PITCH + pc2 + 1) * 16 + 4 * h;
+  const int* b2t = reinterpret_cast<const int*>(biasL) + 16;
+  // conv3: A2 -> A3 (B column n = lane & 31: row 8 rs of the pair, position x; lane half = activation plane)
+  const int x3 = lane & 15, rs3 = (lane >> 4) & 1, y03 = 2 * (wave >> 1);
+  const unsigned char* a2 = lds + P::A2_OFF + h * A2_PLANE + ((y03 + 8 * rs3) * A2_PITCH + x3) * 16;
+  const int psw3 = (x3 >> 2) & 3;
+  unsigned char* a3dst = lds + P::A3_OFF + ((y03 + 8 * rs3) * 16 + x3) * 64 + 4 * h;
+  const int* b3p = reinterpret_cast<const int*>(biasL) + 48 + 32 * tile3;
+
+  // ---- prologue: first CTU staged, its conv1 done, the second CTU's samples in flight ----
+  CtuPos p_prev = pos, p_cur = pos, p_next = advance(pos, step, band_rows, F.ctus_x);   // c(k-1), c(k), c(k+1)
+  Prefetched pre = prefetch_ctu<HAD == 1>(F, vblock < total, p_cur, ld_row, ld_seg);
+  if (vblock < total) {
+    stage_ctu<false>(lds, P::T_OFF, pre, F, p_cur, tid, ld_row, ld_seg, shift_in, 0u);
+    if (HAD == 1) {
+      const int hs = F.sample_bytes == 2 ? wave_src_hadamard<2>(pre, lane) : wave_src_hadamard<1>(pre, lane);
+      if (lane == 0) hadsL[wave] = hs;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) FHEVC_PIPE_CONV1_UNIT(i)
+  pre = prefetch_ctu<HAD == 1>(F, vblock + grid < total, p_next, ld_row, ld_seg);
+  __syncthreads();
+
+  int k = 0;
+  for (int work = vblock; work < total; work += grid, ++k) {
+    const CtuPos p_next2 = advance(p_next, step, band_rows, F.ctus_x);
+    const bool have_next = work + grid < total;
+    int* logit_prev = logit0 + 64 * ((k + 1) & 1);   // set (k - 1) & 1: heads(k-1) add to it in X(k), the depth map reads it in Y(k)
+    int* logit_cur = logit0 + 64 * (k & 1);          // set k & 1: initialised in Y(k)
+    // ================= X(k): staging(k+1) + Hadamard(k+1), then conv2(k) with heads(k-1) in its shadow =================
+    unsigned hr[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };  // the next CTU's samples for the source Hadamard (zeros: no next CTU, or not through the aligned path)
+    if (have_next) {
+      stage_ctu<false>(lds, P::T_OFF, pre, F, p_next, tid, ld_row, ld_seg, shift_in, 0u);
+      if (HAD == 1) {
+        if (F.sample_bytes == 2) hadamard_samples<2>(pre, hr); else hadamard_samples<1>(pre, hr);
+      }
+    }
+    {
+      // source Hadamard(k+1): straight-line VALU work in the shadow of conv2's MFMAs (the set's write is harmless without a next CTU)
+      if (HAD == 1) {
+        const int hs = wave_src_hadamard_core(hr, lane);
+        hadsL[4 * ((k + 1) & 3) + wave] = hs;   // every lane holds the wave's sum: 64 lanes, one address, one value
+      }
+      // heads(k-1): 16- and 32-level heads as ONE GEMM on v_mfma_i32_16x16x64_i8, 64-level head on v_dot4_i32_i8 (P4 of the kernel above)
+      const unsigned char* hw = lds + P::HEADW_OFF;
+      const unsigned char* ap = lds + P::A3_OFF + (headm_addr & 0xFFFFu);
+      const unsigned char* bp = hw + (headm_addr >> 16);
+      i32x4 hacc = { 0, 0, 0, 0 };
+#pragma unroll
+      for (int px = 0; px < 4; ++px)
+        hacc = __builtin_amdgcn_mfma_i32_16x16x64_i8(*reinterpret_cast<const i32x4*>(ap + px * 64), *reinterpret_cast<const i32x4*>(bp + px * HEADM_STEP), hacc, 0, 0, 0);
+      int s64a = 0, s64b = 0;
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        const uint4 a = *reinterpret_cast<const uint4*>(lds + P::A3_OFF + (head_addr.x ^ (qq << 4)));
+        const unsigned char* w64 = hw + HEAD64_OFF + (head_addr.y ^ (qq << 4));
+        const uint4 d0 = *reinterpret_cast<const uint4*>(w64), d1 = *reinterpret_cast<const uint4*>(w64 + 4096);
+        s64a = sdot4(a.x, d0.x, s64a); s64a = sdot4(a.y, d0.y, s64a); s64a = sdot4(a.z, d0.z, s64a); s64a = sdot4(a.w, d0.w, s64a);
+        s64b = sdot4(a.x, d1.x, s64b); s64b = sdot4(a.y, d1.y, s64b); s64b = sdot4(a.z, d1.z, s64b); s64b = sdot4(a.w, d1.w, s64b);
+      }
+      // conv2(k): four half-chains (u0 dy 0, u0 dy 1, u1 dy 0, u1 dy 1), pools and requants under the following chains
+      const int u0 = wave, u1 = wave + 4;
+      const unsigned char* h00 = a1p + (4 * u0) * A1_ROW;
+      const unsigned char* h10 = a1p + (4 * u1) * A1_ROW;
+      i32x16 t0, t1, a0, a1;
+      bf16x8 ring[RINGI];
+      conv2_half_i8<true, false>(h00, h00 + A1_ROW, wA2, ring, b2t, h, t0, t1);
+      __builtin_amdgcn_sched_group_barrier(0x100, RINGI + 4, 0);
+      sched_chain12_i8<FHEVC_PIPE_SCHED_X>();
+      conv2_half_i8<false, false>(h00 + A1_ROW, h10, wA2, ring, b2t, h, a0, a1);
+      pool_h_i8(t0, t1);
+      sched_chain12_i8<FHEVC_PIPE_SCHED_X>();
+      pool_v_i8(t0, a0, a1);
+      conv2_half_i8<false, false>(h10, h10 + A1_ROW, wA2, ring, b2t, h, t1, a0);
+      conv2_requant_store_i8m<FASTRQ ? 1 : 0>(t0, a2dst + (2 * u0) * A2_PITCH * 16, shift2);
+      sched_chain12_i8<FHEVC_PIPE_SCHED_X>();
+      conv2_half_i8<false, true>(h10 + A1_ROW, h10 + A1_ROW, wA2, ring, b2t, h, a1, t0);
+      pool_h_i8(t1, a0);
+      sched_chain12_i8<FHEVC_PIPE_SCHED_X>();
+      pool_v_i8(t1, a1, t0);
+      conv2_requant_store_i8m<FASTRQ ? 1 : 0>(t1, a2dst + (2 * u1) * A2_PITCH * 16, shift2);
+      // the heads' partial sums join the logits of set (k - 1) & 1
+      {
+        const int n = lane & 15, rg = lane >> 4, subn = (n - 2) >> 1;
+        const bool is16 = n < 2, is32 = n >= 2 && n < 10 && ((rg & 1) == (subn >> 1));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const bool act = is16 || (is32 && ((i & 1) == (subn & 1)));
+          const int idx = is16 ? 2 * (5 + 4 * rg + i) + n : 2 * (1 + (rg >> 1) * 2 + (i >> 1)) + (n & 1);
+          if (act) atomicAdd(logit_prev + idx, hacc[i]);
+        }
+      }
+      const int r64a = dpp_row_sum(s64a), r64b = dpp_row_sum(s64b);
+      const int q64a = __builtin_amdgcn_readlane(r64a, 0) + __builtin_amdgcn_readlane(r64a, 16) + __builtin_amdgcn_readlane(r64a, 32) + __builtin_amdgcn_readlane(r64a, 48);
+      const int q64b = __builtin_amdgcn_readlane(r64b, 0) + __builtin_amdgcn_readlane(r64b, 16) + __builtin_amdgcn_readlane(r64b, 32) + __builtin_amdgcn_readlane(r64b, 48);
+      if (lane == 0) *reinterpret_cast<int2*>(logit_prev + 44 + 2 * wave) = make_int2(q64a, q64b);
+    }
+    __syncthreads();
+    // ================= Y(k): depth map(k-1), prefetch(k+2), then conv3(k) with conv1(k+1) in its shadow =================
+    if (k >= 1)
+      depth_map_of_ctu(F, logit_prev, hadsL + 4 * ((k - 1) & 3), tid, lane, wave, p_prev.f, F.row_begin + p_prev.ry, p_prev.cx, band_rows, hb64a, hb64b,
+                       margin_split, margin_stop, d_depth, d_depth_max, d_logits, d_flags, d_had, HAD == 1);
+    if (tid < 40) logit_cur[2 + tid] = tid < 8 ? ((tid & 1) ? hb32b : hb32a) : ((tid & 1) ? hb16b : hb16a);
+    pre = prefetch_ctu<HAD == 1>(F, work + 2 * grid < total, p_next2, ld_row, ld_seg);
+    {
+      // conv3(k)'s 36 MFMAs in program order j = 0..35 (super-chain j / 18: accumulators p0 / p1, then q0 / q1; tap (j % 18) / 2), one
+      // fragment read ahead per MFMA.  conv1(k+1)'s eight units are cut into slices and dealt over those steps so that every MFMA has
+      // a few VALU instructions behind it: unit u's two MFMAs go out before step 9u / 2, its pooling (2 x 8 v_max3 / v_max) after the
+      // next two steps, requant + store after the third.  The requant of p0 / p1 (four 5-instruction groups each) follows their chain
+      // in the same way; only q0 / q1's requant is left for the tail of the interval.
+      bf16x8 ring[RING3P];
+      i32x16 p0, p1, q0, q1;
+      f32x16 c1a, c1b;
+      float c1m[8];
+#pragma unroll
+      for (int g = 0; g < RING3P; ++g) ring[g] = lds_frag(a2 + conv3_frag_off_i8(g));
+      static_for<0, 36>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        constexpr int t = (j % 18) >> 1;
+        if constexpr (j == 0) { const i32x16 binit = bias_tile_i8(b3p, h); p0 = binit; p1 = binit; }
+        if constexpr (j == 18) { const i32x16 binit = bias_tile_i8(b3p, h); q0 = binit; q1 = binit; }
+        static_for<0, 8>([&](auto U) {
+          constexpr int u = decltype(U)::value;
+          if constexpr (j == (9 * u) / 2) {
+            const bf16x8 bq_ = frag1(c1_in + u * (4 * IN_PITCH * 4));
+            c1a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA1a, bq_, bias1, 0, 0, 0);
+            c1b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA1b, bq_, bias1, 0, 0, 0);
+          }
+        });
+        if constexpr (j < 18) { if constexpr (j & 1) p1 = mfma_i8(wA3[t], ring[j % RING3P], p1); else p0 = mfma_i8(wA3[t], ring[j % RING3P], p0); }
+        else { if constexpr (j & 1) q1 = mfma_i8(wA3[t], ring[j % RING3P], q1); else q0 = mfma_i8(wA3[t], ring[j % RING3P], q0); }
+        if constexpr (j + RING3P < 36) ring[j % RING3P] = lds_frag(a2 + conv3_frag_off_i8(j + RING3P));
+        static_for<0, 8>([&](auto U) {
+          constexpr int u = decltype(U)::value;
+          constexpr int j0 = (9 * u) / 2;
+          if constexpr (j == j0 + 1) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) c1m[c] = fmaxf(fmaxf(c1a[c], c1a[c + 8]), fmaxf(c1b[c], c1b[c + 8]));
+          }
+          if constexpr (j == j0 + 2) {
+#pragma unroll
+            for (int c = 4; c < 8; ++c) c1m[c] = fmaxf(fmaxf(c1a[c], c1a[c + 8]), fmaxf(c1b[c], c1b[c + 8]));
+          }
+          if constexpr (j == j0 + 3)
+            *reinterpret_cast<uint2*>(c1_out + u * (4 * A1_ROW)) = make_uint2(u8x4_floor_clamp(c1m[0], c1m[1], c1m[2], c1m[3]) ^ 0x80808080u,
+                                                                               u8x4_floor_clamp(c1m[4], c1m[5], c1m[6], c1m[7]) ^ 0x80808080u);
+        });
+        // requant of super-chain 0's accumulators, one group of four channels per step: p0 after steps 19..22, p1 after 23..26
+        if constexpr (j >= 19 && j < 27) {
+          constexpr int g = (j - 19) & 3;
+          const i32x16& acc = j < 23 ? p0 : p1;
+          unsigned char* dst = a3dst + conv3_pair_row_i8(j < 23 ? 0 : 1) * 1024;
+          *reinterpret_cast<unsigned*>(dst + (((2 * tile3 + (g >> 1)) ^ psw3) << 4) + 8 * (g & 1)) =
+              requant4_i8(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3], shift3, FASTRQ ? 2 : 0);
+        }
+        // the pipeline description of this step: its MFMA(s) and fragment read(s), then the slices' VALU work and their one LDS store
+        if (FHEVC_PIPE_SCHED_Y) {
+          constexpr bool issue = (j % 9 == 0) || (j % 9 == 4);  // steps 0, 4, 9, 13, 18, 22, 27, 31: a conv1 unit's two MFMAs and two ds_read_b64 go out first
+          __builtin_amdgcn_sched_group_barrier(0x100, issue ? 3 : 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, issue ? 3 : 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, FHEVC_PIPE_SCHED_Y, 0);
+          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+      });
+      conv3_store_i8m<FASTRQ ? 2 : 0>(q0, a3dst + conv3_pair_row_i8(2) * 1024, tile3, psw3, shift3);
+      conv3_store_i8m<FASTRQ ? 2 : 0>(q1, a3dst + conv3_pair_row_i8(3) * 1024, tile3, psw3, shift3);
+    }
+    __syncthreads();
+    p_prev = p_cur; p_cur = p_next; p_next = p_next2;
+  }
+  // ================= drain: heads and depth map of the last CTU =================
+  if (k >= 1) {
+    int* logit_prev = logit0 + 64 * ((k + 1) & 1);
+    {
+      const unsigned char* hw = lds + P::HEADW_OFF;
+      const unsigned char* ap = lds + P::A3_OFF + (headm_addr & 0xFFFFu);
+      const unsigned char* bp = hw + (headm_addr >> 16);
+      i32x4 hacc = { 0, 0, 0, 0 };
+#pragma unroll
+      for (int px = 0; px < 4; ++px)
+        hacc = __builtin_amdgcn_mfma_i32_16x16x64_i8(*reinterpret_cast<const i32x4*>(ap + px * 64), *reinterpret_cast<const i32x4*>(bp + px * HEADM_STEP), hacc, 0, 0, 0);
+      int s64a = 0, s64b = 0;
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        const uint4 a = *reinterpret_cast<const uint4*>(lds + P::A3_OFF + (head_addr.x ^ (qq << 4)));
+        const unsigned char* w64 = hw + HEAD64_OFF + (head_addr.y ^ (qq << 4));
+        const uint4 d0 = *reinterpret_cast<const uint4*>(w64), d1 = *reinterpret_cast<const uint4*>(w64 + 4096);
+        s64a = sdot4(a.x, d0.x, s64a); s64a = sdot4(a.y, d0.y, s64a); s64a = sdot4(a.z, d0.z, s64a); s64a = sdot4(a.w, d0.w, s64a);
+        s64b = sdot4(a.x, d1.x, s64b); s64b = sdot4(a.y, d1.y, s64b); s64b = sdot4(a.z, d1.z, s64b); s64b = sdot4(a.w, d1.w, s64b);
+      }
+      {
+        const int n = lane & 15, rg = lane >> 4, subn = (n - 2) >> 1;
+        const bool is16 = n < 2, is32 = n >= 2 && n < 10 && ((rg & 1) == (subn >> 1));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const bool act = is16 || (is32 && ((i & 1) == (subn & 1)));
+          const int idx = is16 ? 2 * (5 + 4 * rg + i) + n : 2 * (1 + (rg >> 1) * 2 + (i >> 1)) + (n & 1);
+          if (act) atomicAdd(logit_prev + idx, hacc[i]);
+        }
+      }
+      const int r64a = dpp_row_sum(s64a), r64b = dpp_row_sum(s64b);
+      const int q64a = __builtin_amdgcn_readlane(r64a, 0) + __builtin_amdgcn_readlane(r64a, 16) + __builtin_amdgcn_readlane(r64a, 32) + __builtin_amdgcn_readlane(r64a, 48);
+      const int q64b = __builtin_amdgcn_readlane(r64b, 0) + __builtin_amdgcn_readlane(r64b, 16) + __builtin_amdgcn_readlane(r64b, 32) + __builtin_amdgcn_readlane(r64b, 48);
+      if (lane == 0) *reinterpret_cast<int2*>(logit_prev + 44 + 2 * wave) = make_int2(q64a, q64b);
+    }
+    __syncthreads();
+    depth_map_of_ctu(F, logit_prev, hadsL + 4 * ((k - 1) & 3), tid, lane, wave, p_prev.f, F.row_begin + p_prev.ry, p_prev.cx, band_rows, hb64a, hb64b,
+                     margin_split, margin_stop, d_depth, d_depth_max, d_logits, d_flags, d_had, HAD == 1);
+  }
+#undef FHEVC_PIPE_CONV1_UNIT
+}
+
 // split-flag words -> depth maps (whole pictures, CTU raster order): one thread per row of 16 units = one 16-byte store,
 // 16 threads per CTU, 16 CTUs per workgroup and sweep (HBM-write-bound: 256 B per CTU)
 __global__ __launch_bounds__(256) void fhevc_expand_flags_kernel(FhevcFrames F, const uint32_t* __restrict__ flags,
@@ -1526,7 +1977,12 @@ hipError_t fhevc_cnn_prepare_device()
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_kernel<false, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, Lds<false>::LDS_BYTES);
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_kernel<false, 1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, Lds<false>::LDS_BYTES);
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_kernel<false, 2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, Lds<false>::LDS_BYTES);
-  return e;  // (the i8 variant's 51 072 B need no opt-in)
+  // (the i8 variant's 51 072 B need no opt-in; its pipelined form's 76 816 B do)
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_pipe_kernel<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LdsPipe::LDS_BYTES);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_pipe_kernel<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LdsPipe::LDS_BYTES);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_pipe_kernel<0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LdsPipe::LDS_BYTES);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_pipe_kernel<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LdsPipe::LDS_BYTES);
+  return e;
 }
 
 // d_had != nullptr: the fused source Hadamard (only where fhevc_cnn_can_fuse_hadamard says so)
@@ -1572,6 +2028,17 @@ hipError_t fhevc_launch_cnn(const FhevcFrames& fr, const FhevcCnnWeights& w, uin
   // the fused source Hadamard's form: on the MFMA from the staged tile for 8-bit content (the tile IS the samples), on packed
   // 16-bit VALU from the prefetched samples otherwise (the tile is rounded to 8 bits); w.had_valu forces the latter (A/B, tests)
   const int had = d_had == nullptr ? 0 : (fr.bit_depth == 8 && !w.had_valu) ? 2 : 1;
+  if (w.i8 && w.pipe && had != 2) {  // the software-pipelined form of the i8 kernel: two workgroups per CU
+    int pgrid = 2 * num_cus;
+    if (const char* e = getenv("FHEVC_CNN_WG_PER_CU")) if (e[0] == '1') pgrid = num_cus;
+    if (total < pgrid) pgrid = (int)total;
+#define FHEVC_LAUNCH_PIPE(HAD, ARITH) hipLaunchKernelGGL((fhevc_cnn_depth_pipe_kernel<HAD, ARITH>), dim3(pgrid), dim3(256), LdsPipe::LDS_BYTES, stream, fr, w, d_depth, d_had, \
+                                                         d_logits, d_flags, d_depth_max, margin_split, margin_stop)
+    if (cnn_arith(w) == 2) { if (had) FHEVC_LAUNCH_PIPE(1, 2); else FHEVC_LAUNCH_PIPE(0, 2); }
+    else { if (had) FHEVC_LAUNCH_PIPE(1, 1); else FHEVC_LAUNCH_PIPE(0, 1); }
+#undef FHEVC_LAUNCH_PIPE
+    return hipGetLastError();
+  }
 #define FHEVC_LAUNCH_HAD(ARITH) do { if (had == 2) FHEVC_LAUNCH(2, ARITH); else if (had == 1) FHEVC_LAUNCH(1, ARITH); else FHEVC_LAUNCH(0, ARITH); } while (0)
   switch (cnn_arith(w)) {
     case 2: FHEVC_LAUNCH_HAD(2); break;
