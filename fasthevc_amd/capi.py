@@ -48,7 +48,7 @@ class Stats(C.Structure):
     _fields_ = [("frames", C.c_uint64), ("ctus", C.c_uint64), ("bytes_h2d", C.c_uint64), ("bytes_d2h", C.c_uint64),
                 ("kernels_launched", C.c_uint64), ("ms_h2d", C.c_double), ("ms_kernels", C.c_double),
                 ("ms_d2h", C.c_double), ("last_cnn_ms", C.c_double), ("last_hadamard_ms", C.c_double),
-                ("last_first_pass_ms", C.c_double)]
+                ("last_first_pass_ms", C.c_double), ("devices", C.c_uint64), ("devices_failed", C.c_uint64)]
 
 
 NODE_DTYPE = np.dtype([("satd", np.uint32), ("mode", np.uint32), ("cost", np.float64)])
@@ -176,13 +176,15 @@ def band(ctu_rows, rank, world):
 class Context:
     """One fhevc_ctx: one picture geometry on one MI355X."""
 
-    def __init__(self, width, height, bit_depth=8, weights=None, device=0, max_frames=1, arith=None, lib_path=None):
+    def __init__(self, width, height, bit_depth=8, weights=None, device=0, max_frames=1, arith=None, lib_path=None, devices=None):
+        """devices: list of HIP ordinals for a multi-device context (the host-buffer entry points shard over them); default [device]"""
         self.lib = load_library(lib_path)
         self.width, self.height, self.bit_depth = width, height, bit_depth
         self.ctus_x, self.ctus_y = (width + 63) // 64, (height + 63) // 64
         self.num_ctus = self.ctus_x * self.ctus_y
-        dev = (C.c_int * 1)(device)
-        cfg = Cfg(width, height, bit_depth, 64, 3, 1, dev, None, BACKEND_HIP, max_frames)
+        ids = list(devices) if devices else [device]
+        dev = (C.c_int * len(ids))(*ids)
+        cfg = Cfg(width, height, bit_depth, 64, 3, len(ids), dev, None, BACKEND_HIP, max_frames)
         h = C.c_void_p()
         rc = self.lib.fhevc_create(C.byref(h), C.byref(cfg))
         if rc != OK:
@@ -252,17 +254,19 @@ class Context:
         self._check(self.lib.fhevc_predict_frames(self.h, ptr, sb, st, fst, nf, qp, depth.ctypes.data, had.ctypes.data if had is not None else None))
         return depth, had
 
-    def predict_frame_range(self, plane, origin=0, stride=None, qp=32, margin=0, slice_type=2, margin_stop=None):
-        """Soft decisions: (depth_min, depth_max), each [numCtus, 256]."""
+    def predict_frame_range(self, plane, origin=0, stride=None, qp=32, margin=0, slice_type=2, margin_stop=None, with_hadamard=False):
+        """Soft decisions: (depth_min, depth_max), each [numCtus, 256] (and the per-CTU source Hadamard when asked for)."""
         flat = np.ascontiguousarray(plane).reshape(-1)
         assert flat.dtype == np.int16
         stride = stride if stride is not None else plane.shape[-1]
         dmin = np.zeros(self.num_ctus * 256, np.uint8)
         dmax = np.zeros(self.num_ctus * 256, np.uint8)
+        had = np.zeros(self.num_ctus, np.int32) if with_hadamard else None
         self._check(self.lib.fhevc_predict_frame_range(self.h, flat.ctypes.data + 2 * origin, stride, qp, slice_type, margin,
                                                        margin if margin_stop is None else margin_stop,
-                                                       dmin.ctypes.data, dmax.ctypes.data, None))
-        return dmin.reshape(self.num_ctus, 256), dmax.reshape(self.num_ctus, 256)
+                                                       dmin.ctypes.data, dmax.ctypes.data, had.ctypes.data if with_hadamard else None))
+        out = (dmin.reshape(self.num_ctus, 256), dmax.reshape(self.num_ctus, 256))
+        return out + (had,) if with_hadamard else out
 
     def satd(self, org, cur, w, h, bit_depth=8, org_stride=None, cur_stride=None):
         org = np.ascontiguousarray(org, np.int16)

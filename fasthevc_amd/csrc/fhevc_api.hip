@@ -8,8 +8,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -61,6 +63,11 @@ struct fhevc_ctx {
   uint8_t* d_depth_max = nullptr;
   fhevc_stats stats{};
   std::string err;
+  // cfg.num_devices > 1: this context is the PRIMARY (device_ids[0]); the other devices are full single-device contexts of their own.
+  // The host-buffer entry points shard over them (CTU-row bands of a picture, runs of pictures of a batch); a device that fails is
+  // dropped for the rest of the context's life and its share is redone on a device that works (devices_failed counts them)
+  std::vector<fhevc_ctx*> peers;
+  int fail_peer_for_test = -1;   // FHEVC_TEST_FAIL_DEVICE=<index >= 1>: that device reports a failure on its next share (tests)
 };
 
 namespace {
@@ -366,7 +373,7 @@ int fhevc_create(fhevc_ctx** out, const fhevc_cfg* cfg)
   if (cfg->ctu_size != FHEVC_CTU || cfg->max_depth != 3) return FHEVC_E_INVALID;
   if (cfg->bit_depth < 8 || cfg->bit_depth > 12) return FHEVC_E_INVALID;
   if (cfg->backend != FHEVC_BACKEND_HIP) return FHEVC_E_INVALID;  // there is no CPU backend
-  if (cfg->num_devices > 1) return FHEVC_E_INVALID;               // one device per context / process
+  if (cfg->num_devices > 16 || (cfg->num_devices > 1 && !cfg->device_ids)) return FHEVC_E_INVALID;
   fhevc_ctx* c = new (std::nothrow) fhevc_ctx();
   if (!c) return FHEVC_E_NOMEM;
   c->cfg = *cfg;
@@ -413,6 +420,20 @@ int fhevc_create(fhevc_ctx** out, const fhevc_cfg* cfg)
     const int rc = fhevc_set_weights(c, buf.data(), n);
     if (rc != FHEVC_OK) { fhevc_destroy(c); return rc; }
   }
+  // the other devices of a multi-device context: one single-device context each (the same picture geometry and weights).  A device
+  // that cannot be brought up is left out -- the context works with the ones that can -- and counted in stats.devices_failed
+  c->stats.devices = 1;
+  for (int d = 1; d < cfg->num_devices; ++d) {
+    fhevc_cfg sub = *cfg;
+    int id = cfg->device_ids[d];
+    sub.num_devices = 1;
+    sub.device_ids = &id;
+    fhevc_ctx* peer = nullptr;
+    if (fhevc_create(&peer, &sub) == FHEVC_OK) { c->peers.push_back(peer); c->stats.devices++; }
+    else c->stats.devices_failed++;
+  }
+  if (const char* ft = std::getenv("FHEVC_TEST_FAIL_DEVICE")) c->fail_peer_for_test = std::atoi(ft);
+  (void)hipSetDevice(c->device);
   *out = c;
   return FHEVC_OK;
 }
@@ -420,6 +441,8 @@ int fhevc_create(fhevc_ctx** out, const fhevc_cfg* cfg)
 void fhevc_destroy(fhevc_ctx* c)
 {
   if (!c) return;
+  for (fhevc_ctx* peer : c->peers) fhevc_destroy(peer);
+  c->peers.clear();
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   time_resolve(c);
@@ -448,6 +471,10 @@ int fhevc_set_weights(fhevc_ctx* c, const void* blob, size_t bytes)
   const struct { const int8_t* p; size_t n; } i8s[6] = { { v.w1, 144 }, { v.w2, 4608 }, { v.w3, 18432 }, { v.wh64, 8192 }, { v.wh32, 8192 }, { v.wh16, 2048 } };
   for (const auto& a : i8s)
     for (size_t i = 0; i < a.n; ++i) if (a.p[i] == -128) return fail(c, FHEVC_E_WEIGHTS, "weight -128 not allowed");
+  for (fhevc_ctx* peer : c->peers) {
+    const int rc = fhevc_set_weights(peer, blob, bytes);
+    if (rc != FHEVC_OK) return fail(c, rc, "weights rejected by a peer device");
+  }
   (void)hipSetDevice(c->device);
   return build_weight_image(c, v);
 }
@@ -534,29 +561,111 @@ static int upload_frame(fhevc_ctx* c, const int16_t* luma, int stride_samples)
   return FHEVC_OK;
 }
 
-int fhevc_predict_frame(fhevc_ctx* c, const int16_t* luma, int stride_samples, int qp, int slice_type,
-                        uint8_t* depth_map, int32_t* ctu_src_hadamard)
+// One picture's CTU rows [rb, re) on ONE device: upload those rows, run the depth kernel over the band, bring the band's maps back
+// into the caller's whole-picture buffers at the band's place.  depth_max (with its margins) is optional.  Synchronous.
+static int predict_band_host(fhevc_ctx* c, const int16_t* luma, int stride_samples, int qp, int rb, int re, int margin_split, int margin_stop,
+                             uint8_t* depth_min, uint8_t* depth_max, int32_t* ctu_src_hadamard)
 {
-  (void)slice_type;
-  if (!c || !luma || !depth_map || stride_samples < c->cfg.width) return FHEVC_E_INVALID;
+  if (rb >= re) return FHEVC_OK;
   if (!c->have_weights) return fail(c, FHEVC_E_STATE, "weights not set");
   (void)hipSetDevice(c->device);
-  int rc = upload_frame(c, luma, stride_samples);
-  if (rc != FHEVC_OK) return rc;
-  rc = fhevc_predict_frames_device(c, c->d_luma, 2, c->dev_stride, 0, 1, 0, c->ctus_y, qp, c->d_depth,
-                                   ctu_src_hadamard ? c->d_had : nullptr, nullptr, nullptr, c->stream);
+  if (depth_max && !c->d_depth_max) HIP_TRY(c, hipMalloc(&c->d_depth_max, (size_t)c->num_ctus * 256));
+  const int y0 = rb * 64, y1 = std::min(c->cfg.height, re * 64);
+  const size_t band_ctus = (size_t)(re - rb) * c->ctus_x, first = (size_t)rb * c->ctus_x;
+  HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+  HIP_TRY(c, hipMemcpy2DAsync(c->d_luma + (size_t)y0 * c->dev_stride, (size_t)c->dev_stride * 2, luma + (size_t)y0 * stride_samples, (size_t)stride_samples * 2,
+                              (size_t)c->cfg.width * 2, (size_t)(y1 - y0), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+  c->stats.bytes_h2d += (uint64_t)c->cfg.width * (y1 - y0) * 2;
+  // the kernel writes a band's results compactly from the start of its output buffers
+  int rc = fhevc_predict_frames_device_range(c, c->d_luma, 2, c->dev_stride, 0, 1, rb, re, qp, margin_split, margin_stop, c->d_depth, depth_max ? c->d_depth_max : nullptr,
+                                             ctu_src_hadamard ? c->d_had : nullptr, nullptr, nullptr, c->stream);
   if (rc != FHEVC_OK) return rc;
   HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
-  HIP_TRY(c, hipMemcpyAsync(depth_map, c->d_depth, (size_t)c->num_ctus * 256, hipMemcpyDeviceToHost, c->stream));
-  if (ctu_src_hadamard) HIP_TRY(c, hipMemcpyAsync(ctu_src_hadamard, c->d_had, (size_t)c->num_ctus * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(depth_min + first * 256, c->d_depth, band_ctus * 256, hipMemcpyDeviceToHost, c->stream));
+  if (depth_max) HIP_TRY(c, hipMemcpyAsync(depth_max + first * 256, c->d_depth_max, band_ctus * 256, hipMemcpyDeviceToHost, c->stream));
+  if (ctu_src_hadamard) HIP_TRY(c, hipMemcpyAsync(ctu_src_hadamard + first, c->d_had, band_ctus * 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipEventRecord(c->ev[3], c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   float ms = 0;
   if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->stats.ms_h2d += ms;
   if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) c->stats.ms_kernels += ms;
   if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) c->stats.ms_d2h += ms;
-  c->stats.bytes_d2h += (uint64_t)c->num_ctus * (256 + (ctu_src_hadamard ? 4 : 0));
+  c->stats.bytes_d2h += (uint64_t)band_ctus * ((depth_max ? 512 : 256) + (ctu_src_hadamard ? 4 : 0));
   return FHEVC_OK;
+}
+
+// The devices of a context that still work: the primary first.  (A failed peer is destroyed and forgotten: drop_peer.)
+static std::vector<fhevc_ctx*> live_devices(fhevc_ctx* c)
+{
+  std::vector<fhevc_ctx*> v{ c };
+  v.insert(v.end(), c->peers.begin(), c->peers.end());
+  return v;
+}
+static void drop_peer(fhevc_ctx* c, fhevc_ctx* peer, const char* what)
+{
+  for (size_t i = 0; i < c->peers.size(); ++i)
+    if (c->peers[i] == peer) {
+      c->err = std::string("device ") + std::to_string(peer->device) + " dropped (" + what + "): " + peer->err;
+      fhevc_destroy(peer);
+      c->peers.erase(c->peers.begin() + (long)i);
+      c->stats.devices_failed++;
+      c->stats.devices = 1 + c->peers.size();
+      return;
+    }
+}
+// run share(i, device_i) for every live device concurrently (one host thread per device beyond the caller's own); a share that fails
+// on a PEER is redone on the primary and the peer is dropped: the call fails only if the primary itself fails
+static int run_sharded(fhevc_ctx* c, const std::function<int(int, int, fhevc_ctx*)>& share)
+{
+  const std::vector<fhevc_ctx*> dev = live_devices(c);
+  const int n = (int)dev.size();
+  std::vector<int> rc((size_t)n, FHEVC_OK);
+  std::vector<std::thread> th;
+  for (int i = 1; i < n; ++i)
+    th.emplace_back([&, i] {
+      rc[(size_t)i] = (c->fail_peer_for_test == i) ? fail(dev[(size_t)i], FHEVC_E_HIP, "failure injected by FHEVC_TEST_FAIL_DEVICE") : share(i, n, dev[(size_t)i]);
+    });
+  rc[0] = share(0, n, c);
+  for (auto& t : th) t.join();
+  if (c->fail_peer_for_test >= 1) c->fail_peer_for_test = -1;  // once
+  (void)hipSetDevice(c->device);
+  if (rc[0] != FHEVC_OK) return rc[0];
+  for (int i = 1; i < n; ++i) {
+    // statistics of a multi-device context are the sums over its devices
+    c->stats.frames += dev[(size_t)i]->stats.frames; c->stats.ctus += dev[(size_t)i]->stats.ctus;
+    c->stats.bytes_h2d += dev[(size_t)i]->stats.bytes_h2d; c->stats.bytes_d2h += dev[(size_t)i]->stats.bytes_d2h;
+    c->stats.kernels_launched += dev[(size_t)i]->stats.kernels_launched;
+    dev[(size_t)i]->stats = fhevc_stats{};
+    if (rc[(size_t)i] != FHEVC_OK) {
+      const int redo = share(i, n, c);   // the failed device's share, on the primary
+      drop_peer(c, dev[(size_t)i], "its share was redone on the primary device");
+      if (redo != FHEVC_OK) return redo;
+    }
+  }
+  return FHEVC_OK;
+}
+
+int fhevc_predict_frame(fhevc_ctx* c, const int16_t* luma, int stride_samples, int qp, int slice_type,
+                        uint8_t* depth_map, int32_t* ctu_src_hadamard)
+{
+  (void)slice_type;
+  if (!c || !luma || !depth_map || stride_samples < c->cfg.width) return FHEVC_E_INVALID;
+  if (!c->have_weights) return fail(c, FHEVC_E_STATE, "weights not set");
+  if (c->peers.empty()) {
+    const int rc = predict_band_host(c, luma, stride_samples, qp, 0, c->ctus_y, 0, 0, depth_map, nullptr, ctu_src_hadamard);
+    // one picture = one frame in the statistics whatever the number of bands
+    return rc;
+  }
+  // CTU-row bands over the devices (fhevc_band): rows [i * rows / n, (i + 1) * rows / n) on device i
+  const uint64_t frames0 = c->stats.frames;
+  const int rc = run_sharded(c, [&](int i, int n, fhevc_ctx* d) {
+    int rb = 0, re = 0;
+    (void)fhevc_band(c->ctus_y, i, n, &rb, &re);
+    return predict_band_host(d, luma, stride_samples, qp, rb, re, 0, 0, depth_map, nullptr, ctu_src_hadamard);
+  });
+  c->stats.frames = frames0 + 1;
+  return rc;
 }
 
 void* fhevc_alloc_host(fhevc_ctx* c, size_t bytes)
@@ -595,8 +704,28 @@ static int drain_slot(fhevc_ctx* c, fhevc_ctx::Slot& sl)
   return FHEVC_OK;
 }
 
+static int predict_frames_one_device(fhevc_ctx* c, const void* luma, int sample_bytes, int stride_samples, long long frame_stride_samples, int num_frames,
+                                     int qp, uint8_t* depth_map, int32_t* ctu_src_hadamard);
+
 int fhevc_predict_frames(fhevc_ctx* c, const void* luma, int sample_bytes, int stride_samples, long long frame_stride_samples, int num_frames,
                          int qp, uint8_t* depth_map, int32_t* ctu_src_hadamard)
+{
+  if (!c || !luma || !depth_map) return FHEVC_E_INVALID;
+  if (c->peers.empty() || num_frames < 2) return predict_frames_one_device(c, luma, sample_bytes, stride_samples, frame_stride_samples, num_frames, qp, depth_map, ctu_src_hadamard);
+  // a batch over several devices: contiguous runs of pictures, frames [i * F / n, (i + 1) * F / n) on device i ("frames can
+  // instead be dealt round-robin -- strictly simpler"); every device runs its own two-stream host batch, all at the same time
+  return run_sharded(c, [&](int i, int n, fhevc_ctx* d) {
+    int fb = 0, fe = 0;
+    (void)fhevc_band(num_frames, i, n, &fb, &fe);
+    if (fb >= fe) return (int)FHEVC_OK;
+    return predict_frames_one_device(d, static_cast<const uint8_t*>(luma) + (size_t)fb * (size_t)frame_stride_samples * sample_bytes, sample_bytes, stride_samples,
+                                     frame_stride_samples, fe - fb, qp, depth_map + (size_t)fb * c->num_ctus * 256,
+                                     ctu_src_hadamard ? ctu_src_hadamard + (size_t)fb * c->num_ctus : nullptr);
+  });
+}
+
+static int predict_frames_one_device(fhevc_ctx* c, const void* luma, int sample_bytes, int stride_samples, long long frame_stride_samples, int num_frames,
+                                     int qp, uint8_t* depth_map, int32_t* ctu_src_hadamard)
 {
   if (!c || !luma || !depth_map) return FHEVC_E_INVALID;
   if (!c->have_weights) return fail(c, FHEVC_E_STATE, "weights not set");
@@ -688,19 +817,15 @@ int fhevc_predict_frame_range(fhevc_ctx* c, const int16_t* luma, int stride_samp
   (void)slice_type;
   if (!c || !luma || !depth_min || !depth_max || stride_samples < c->cfg.width) return FHEVC_E_INVALID;
   if (!c->have_weights) return fail(c, FHEVC_E_STATE, "weights not set");
-  (void)hipSetDevice(c->device);
-  if (!c->d_depth_max) HIP_TRY(c, hipMalloc(&c->d_depth_max, (size_t)c->num_ctus * 256));
-  int rc = upload_frame(c, luma, stride_samples);
-  if (rc != FHEVC_OK) return rc;
-  rc = fhevc_predict_frames_device_range(c, c->d_luma, 2, c->dev_stride, 0, 1, 0, c->ctus_y, qp, margin_split, margin_stop, c->d_depth, c->d_depth_max,
-                                         ctu_src_hadamard ? c->d_had : nullptr, nullptr, nullptr, c->stream);
-  if (rc != FHEVC_OK) return rc;
-  HIP_TRY(c, hipMemcpyAsync(depth_min, c->d_depth, (size_t)c->num_ctus * 256, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(depth_max, c->d_depth_max, (size_t)c->num_ctus * 256, hipMemcpyDeviceToHost, c->stream));
-  if (ctu_src_hadamard) HIP_TRY(c, hipMemcpyAsync(ctu_src_hadamard, c->d_had, (size_t)c->num_ctus * 4, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  c->stats.bytes_d2h += (uint64_t)c->num_ctus * (512 + (ctu_src_hadamard ? 4 : 0));
-  return FHEVC_OK;
+  if (c->peers.empty()) return predict_band_host(c, luma, stride_samples, qp, 0, c->ctus_y, margin_split, margin_stop, depth_min, depth_max, ctu_src_hadamard);
+  const uint64_t frames0 = c->stats.frames;
+  const int rc = run_sharded(c, [&](int i, int n, fhevc_ctx* d) {
+    int rb = 0, re = 0;
+    (void)fhevc_band(c->ctus_y, i, n, &rb, &re);
+    return predict_band_host(d, luma, stride_samples, qp, rb, re, margin_split, margin_stop, depth_min, depth_max, ctu_src_hadamard);
+  });
+  c->stats.frames = frames0 + 1;
+  return rc;
 }
 
 int fhevc_satd(fhevc_ctx* c, const int16_t* org, int org_stride, const int16_t* cur, int cur_stride,
@@ -1046,6 +1171,7 @@ int fhevc_set_cnn_arith(fhevc_ctx* c, int arith)
   if (!c) return FHEVC_E_INVALID;
   if (arith != FHEVC_CNN_ARITH_I8 && arith != FHEVC_CNN_ARITH_F16) return fail(c, FHEVC_E_INVALID, "arith: FHEVC_CNN_ARITH_I8 or FHEVC_CNN_ARITH_F16");
   c->cnn_i8 = arith == FHEVC_CNN_ARITH_I8;
+  for (fhevc_ctx* peer : c->peers) peer->cnn_i8 = c->cnn_i8;
   return FHEVC_OK;
 }
 

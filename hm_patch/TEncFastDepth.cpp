@@ -197,11 +197,29 @@ bool TEncFastDepth::ensureContext(TComPic* pcPic)
   const int bd = pcPic->getPicSym()->getSPS().getBitDepth(CHANNEL_TYPE_LUMA);
   if (m_ctx != NULL && w == m_width && h == m_height && bd == m_bitDepth) return true;
   if (m_ctx != NULL) { fhevc_destroy(m_ctx); m_ctx = NULL; }
-  const char* dev = std::getenv("FHEVC_DEVICE");
-  int device = dev ? std::atoi(dev) : 0;
+  // FHEVC_DEVICES=0,1,2,...: the MI355X devices this (single-threaded, single-process) encoder may use; the library shards the
+  // CTU rows of every picture over them and gathers the maps into m_depth (fasthevc.h: fhevc_cfg.num_devices).  FHEVC_DEVICE=<n>: one device
+  int devices[16];
+  int numDevices = 0;
+  if (const char* list = std::getenv("FHEVC_DEVICES"))
+  {
+    for (const char* p = list; *p != 0 && numDevices < 16;)
+    {
+      char* end = NULL;
+      const long v = std::strtol(p, &end, 10);
+      if (end == p) break;
+      devices[numDevices++] = (int)v;
+      p = (*end == ',') ? end + 1 : end;
+    }
+  }
+  if (numDevices == 0)
+  {
+    const char* dev = std::getenv("FHEVC_DEVICE");
+    devices[numDevices++] = dev ? std::atoi(dev) : 0;
+  }
   fhevc_cfg cfg;
   cfg.width = w; cfg.height = h; cfg.bit_depth = bd; cfg.ctu_size = 64; cfg.max_depth = 3;
-  cfg.num_devices = 1; cfg.device_ids = &device; cfg.weights_path = std::getenv("FHEVC_WEIGHTS");
+  cfg.num_devices = numDevices; cfg.device_ids = devices; cfg.weights_path = std::getenv("FHEVC_WEIGHTS");
   cfg.backend = FHEVC_BACKEND_HIP; cfg.max_frames = 1;
   if (cfg.weights_path == NULL || fhevc_create(&m_ctx, &cfg) != FHEVC_OK)
   {

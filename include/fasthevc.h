@@ -50,8 +50,11 @@ typedef struct {
   int bit_depth;            /* sps.getBitDepth(CHANNEL_TYPE_LUMA): 8..12 */
   int ctu_size;             /* 64 (the reference's dumper hard-codes it: HARP_Defines.h:28-29) */
   int max_depth;            /* 3: 8x8 leaves (MaxPartitionDepth 4) */
-  int num_devices;          /* 1 per process; ranks of a node shard CTU-row bands (see fhevc_band) */
-  const int* device_ids;    /* HIP device ordinals, NULL = {0} */
+  int num_devices;          /* devices of THIS process (<= 16): > 1 makes the host-buffer entry points (fhevc_predict_frame[_range], fhevc_predict_frames)
+                               shard CTU-row bands / runs of pictures over them (fhevc_band) and gather the maps into the caller's buffer;
+                               a device that fails is dropped and its share redone on another (fhevc_stats.devices_failed), never an abort.
+                               Entry points that take DEVICE pointers, and the parity / feature entry points, run on device_ids[0] */
+  const int* device_ids;    /* HIP device ordinals, NULL = {0}; an ordinal may repeat (two queues on one device: tests) */
   const char* weights_path; /* FHW1 blob (fasthevc_amd/weights.py), or NULL and call fhevc_set_weights */
   int backend;              /* FHEVC_BACKEND_HIP */
   int max_frames;           /* frames per batched call the context sizes its staging buffers for (>= 1) */
@@ -72,6 +75,8 @@ typedef struct {
   uint64_t kernels_launched;
   double   ms_h2d, ms_kernels, ms_d2h;   /* accumulated, HIP-event timed (host-buffer entry points only) */
   double   last_cnn_ms, last_hadamard_ms, last_first_pass_ms; /* last launch of each kernel */
+  uint64_t devices;         /* devices this context works with right now (cfg.num_devices minus the failed ones) */
+  uint64_t devices_failed;  /* devices that could not be brought up at fhevc_create or were dropped after a failed call */
 } fhevc_stats;
 
 int  fhevc_create(fhevc_ctx** out, const fhevc_cfg* cfg);

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BLOB = os.path.join(ROOT, "fasthevc_amd", "weights", "depthnet_v1.fhw")
 GPU_SO = os.path.join(ROOT, "oracle", "_ref", "libhmref_hookgpu.so")
-KNOBS = ("FHEVC_ENABLE", "FHEVC_WEIGHTS", "FHEVC_MARGIN", "FHEVC_MARGIN_SPLIT", "FHEVC_MARGIN_STOP", "FHEVC_DEVICE")
+KNOBS = ("FHEVC_ENABLE", "FHEVC_WEIGHTS", "FHEVC_MARGIN", "FHEVC_MARGIN_SPLIT", "FHEVC_MARGIN_STOP", "FHEVC_DEVICE", "FHEVC_DEVICES")
 QP = 32
 
 
@@ -50,7 +50,9 @@ def test_reference_encoder_driven_by_the_gpu_library(oracle):
                                     ((832, 448), {"FHEVC_ENABLE": "1", "FHEVC_WEIGHTS": BLOB}, (100000, 48000)),   # the hook's defaults
                                     ((704, 512), {"FHEVC_ENABLE": "1", "FHEVC_WEIGHTS": BLOB, "FHEVC_MARGIN_SPLIT": "32000"}, (32000, 48000)),   # the other side keeps its default
                                     ((576, 512), {"FHEVC_ENABLE": "1", "FHEVC_WEIGHTS": BLOB, "FHEVC_MARGIN_SPLIT": "32000", "FHEVC_MARGIN_STOP": "0"}, (32000, 0)),
-                                    ((640, 448), {"FHEVC_ENABLE": "1", "FHEVC_WEIGHTS": BLOB, "FHEVC_MARGIN": "8000"}, (8000, 8000))):
+                                    ((640, 448), {"FHEVC_ENABLE": "1", "FHEVC_WEIGHTS": BLOB, "FHEVC_MARGIN": "8000"}, (8000, 8000)),
+                                    # a multi-device context behind the hook (FHEVC_DEVICES): CTU-row bands over two queues of the one MI355X here
+                                    ((896, 448), {"FHEVC_ENABLE": "1", "FHEVC_WEIGHTS": BLOB, "FHEVC_MARGIN": "8000", "FHEVC_DEVICES": "0,0"}, (8000, 8000))):
             buf, org, stride, chroma = _picture(W, H)
             dmin, dmax = _oracle_maps(oracle, buf, org, stride, W, H, *margins)
             d_ref, s_ref = op.rdo_encode(hook, buf, org, stride, W, H, 8, QP, forced_depth=dmin, forced_depth_max=dmax, chroma=chroma)
