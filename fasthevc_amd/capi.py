@@ -25,7 +25,7 @@ SYMBOLS = [
     "fhevc_expand_depth_flags_device", "fhevc_aq_parts", "fhevc_preanalyze", "fhevc_preanalyze_frames_device", "fhevc_aq_qp", "fhevc_intra_first_pass_device",
     "fhevc_predict_frame_range", "fhevc_predict_frames_device_range",
     "fhevc_motion_search", "fhevc_motion_search_device", "fhevc_intra_first_pass_all", "fhevc_p_rule_default", "fhevc_p_depth_range",
-    "fhevc_predict_frames", "fhevc_alloc_host", "fhevc_free_host", "fhevc_set_cnn_arith", "fhevc_get_cnn_arith",
+    "fhevc_predict_frames", "fhevc_alloc_host", "fhevc_free_host", "fhevc_set_cnn_arith", "fhevc_get_cnn_arith", "fhevc_set_motion_distortion",
 ]
 CNN_ARITH = {"i8": 8, "f16": 16}
 
@@ -119,6 +119,7 @@ def load_library(path=None):
     lib.fhevc_preanalyze_frames_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_int,
                                                    C.c_int, vp, vp]
     lib.fhevc_set_cnn_arith.argtypes = [vp, C.c_int]
+    lib.fhevc_set_motion_distortion.argtypes = [vp, C.c_int]
     lib.fhevc_get_cnn_arith.argtypes = [vp]
     lib.fhevc_motion_search.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]
     lib.fhevc_motion_search_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
@@ -360,6 +361,10 @@ class Context:
 
     def expand_depth_flags_device(self, d_flags, num_frames, d_depth, stream=None):
         self._check(self.lib.fhevc_expand_depth_flags_device(self.h, d_flags, num_frames, d_depth, stream))
+
+    def set_motion_distortion(self, mode):
+        """"satd" (default) or "sad" (HM's integer-search distortion: results equal the reference's xPatternSearch)"""
+        self._check(self.lib.fhevc_set_motion_distortion(self.h, {"satd": 0, "sad": 1}[mode]))
 
     def set_cnn_arith(self, arith):
         """"i8" (default) or "f16": the arithmetic of the classifier's conv2 / conv3; the results are the same integers"""

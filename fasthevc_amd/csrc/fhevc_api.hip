@@ -40,6 +40,7 @@ struct fhevc_ctx {
   hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
   // kernel timing
   bool fuse_hadamard = true;  // FHEVC_FUSE_HADAMARD=0 keeps the stand-alone Hadamard launch (A/B measurements)
+  bool motion_sad = false;    // fhevc_set_motion_distortion: SAD (HM's integer-search distortion) instead of Hadamard SATD
   bool cnn_pipe = false;      // FHEVC_CNN_PIPE=1: the i8 form as the two-stage software pipeline over CTUs (k_cnn.hip: fhevc_cnn_depth_pipe_kernel)
   bool had_valu = true;       // FHEVC_HADAMARD_FORM=mfma: the fused Hadamard of 8-bit content on the bf16 MFMA from the staged tile instead of packed
                               // 16-bit VALU (parity-green, and measured 7 % SLOWER in round 3: profiles/r03_ab_hadamard_forms.log) -- kept for A/B and tests
@@ -1013,7 +1014,7 @@ int fhevc_motion_search_device(fhevc_ctx* c, const void* d_luma, int sample_byte
   const FhevcFrames fr = frames_of(c, d_luma, sample_bytes, stride_samples, frame_stride_samples, num_frames, ctu_row_begin, ctu_row_end, qp);
   static_assert(sizeof(fhevc_motion_node) == sizeof(FhevcMotionNode), "motion node layout");
   time_begin(c, st, 4);
-  HIP_TRY(c, fhevc_launch_motion(fr, search_range, mv_cost_table(qp, search_range), reinterpret_cast<FhevcMotionNode*>(d_out), c->num_cus, st));
+  HIP_TRY(c, fhevc_launch_motion(fr, search_range, mv_cost_table(qp, search_range), reinterpret_cast<FhevcMotionNode*>(d_out), c->num_cus, c->motion_sad, st));
   time_end(c, st);
   c->stats.kernels_launched++;
   return FHEVC_OK;
@@ -1172,6 +1173,14 @@ int fhevc_set_cnn_arith(fhevc_ctx* c, int arith)
   if (arith != FHEVC_CNN_ARITH_I8 && arith != FHEVC_CNN_ARITH_F16) return fail(c, FHEVC_E_INVALID, "arith: FHEVC_CNN_ARITH_I8 or FHEVC_CNN_ARITH_F16");
   c->cnn_i8 = arith == FHEVC_CNN_ARITH_I8;
   for (fhevc_ctx* peer : c->peers) peer->cnn_i8 = c->cnn_i8;
+  return FHEVC_OK;
+}
+
+int fhevc_set_motion_distortion(fhevc_ctx* c, int mode)
+{
+  if (!c) return FHEVC_E_INVALID;
+  if (mode != FHEVC_MOTION_SATD && mode != FHEVC_MOTION_SAD) return fail(c, FHEVC_E_INVALID, "mode: FHEVC_MOTION_SATD or FHEVC_MOTION_SAD");
+  c->motion_sad = mode == FHEVC_MOTION_SAD;
   return FHEVC_OK;
 }
 

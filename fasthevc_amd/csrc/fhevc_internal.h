@@ -85,7 +85,8 @@ hipError_t fhevc_launch_first_pass(const FhevcFrames& fr, double sqrt_lambda, Fh
 struct FhevcMotionNode { uint32_t satd_zero, satd_best, cost_best; int16_t mvx, mvy; };
 struct FhevcMvCost { uint32_t c[(2 * FHEVC_MOTION_MAX_RANGE + 1) * (2 * FHEVC_MOTION_MAX_RANGE + 1)]; };  // [dy + R][dx + R] of the window in use
 // frames 1 .. num_frames-1 of fr, each searched in the frame before it; d_out: (num_frames - 1) * band CTUs * 85 nodes
-hipError_t fhevc_launch_motion(const FhevcFrames& fr, int range, const FhevcMvCost& mvc, FhevcMotionNode* d_out, int num_cus, hipStream_t stream);
+// sad: SAD (HM's integer-search distortion, pinned to the reference's xPatternSearch) instead of Hadamard SATD
+hipError_t fhevc_launch_motion(const FhevcFrames& fr, int range, const FhevcMvCost& mvc, FhevcMotionNode* d_out, int num_cus, bool sad, hipStream_t stream);
 
 // the shipped P-picture rule (fhevc_p_rule_default): see fasthevc.h; regenerate with tests/quality/fit_p_rule.py
 #define FHEVC_P_RULE_WEIGHTS { { 3101, 188, -94, 80, 1149, 1149, 3174, -138, 15748, -351620 }, \

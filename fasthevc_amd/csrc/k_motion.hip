@@ -1,13 +1,19 @@
 // k_motion.hip -- source-only integer motion search per CU node (config 4: P slices), gfx950 only.
 //
-// Bit-exact twin of oracle/fhevc_oracle.c: fho_motion_ctu.  For every CU node (64x64, 32x32, 16x16, 8x8: 85 per CTU) of a
-// picture: full search over [-R, R]^2 integer vectors in the PREVIOUS ORIGINAL picture, cost = Hadamard SATD + vector cost,
-// raster order over the window and strict "<" as TEncSearch::xPatternSearch (TEncSearch.cpp:3786-3848), distortion as
-// TComRdCost::xGetHADs (TComRdCost.cpp:1753-1824; HM's HADME distortion, TEncSearch.cpp:836), vector cost as
+// Bit-exact twin of oracle/fhevc_oracle.c: fho_motion_ctu_dist.  For every CU node (64x64, 32x32, 16x16, 8x8: 85 per CTU) of a
+// picture: full search over [-R, R]^2 integer vectors in the PREVIOUS ORIGINAL picture, cost = distortion + vector cost, raster
+// order over the window and strict "<" as TEncSearch::xPatternSearch (TEncSearch.cpp:3786-3848), vector cost as
 // TComRdCost::getCostOfVectorWithPredictor (TComRdCost.h:166-174; the host tabulates it with HM's double arithmetic),
 // reference samples outside the picture replicated from the border (TComPicYuv::extendPicBorder, TComPicYuv.cpp:229-270).
-// The SATD of a node is the sum of its 8x8 tile SATDs (xGetHADs tiles every block of these sizes in 8x8), so ONE pass over
-// the 64 tiles of a CTU per vector serves all four levels.
+// Two distortions (template argument SAD):
+//   SAD  -- what HM's integer search uses: xPatternSearch's setDistParam selects DF_SAD (TComRdCost.cpp:205-236, xGetSAD* :518-..).
+//           In this mode the kernel reproduces the reference's own xPatternSearch bit for bit (vector, SAD, cost): the oracle is pinned
+//           to tests/golden/ref_pattern_search.npz, the kernel to the oracle.  One v_sad_u16 per pair of samples.
+//   SATD -- TComRdCost::xGetHADs (TComRdCost.cpp:1753-1824) at integer positions.  HM applies Hadamard to the FRACTIONAL refinement
+//           only (HadamardME, TEncSearch.cpp:836; cfg/encoder_lowdelay_P_main.cfg:37): at integer positions it is this build's own
+//           choice (the P-picture rule's features are fitted on it), the default of fhevc_motion_search.
+// Either distortion of a node is the sum of its 8x8 tiles' (both shift the block's sum once), so ONE pass over the 64 tiles of a
+// CTU per vector serves all four levels.
 //
 // Mapping: workgroup (4 waves) = one CTU at a time, grid-stride; lane = one 8x8 tile (its 64 original samples stay in
 // registers as 32 packed pairs); the four waves split the vectors of the window; the reference window ((64 + 2R)^2
@@ -104,8 +110,8 @@ __device__ __forceinline__ unsigned had8x8_wide(int (&v)[64])
 template <typename T>
 __device__ __forceinline__ int sample_at(const T* plane, long long off) { return (int)plane[off]; }
 
-// T = int16_t (HM Pel planes) or uint8_t; PACKED = bit depth <= 10
-template <typename T, bool PACKED>
+// T = int16_t (HM Pel planes) or uint8_t; PACKED = bit depth <= 10; SAD: see the header
+template <typename T, bool PACKED, bool SAD>
 __global__ __launch_bounds__(256) void fhevc_motion_kernel(FhevcFrames F, int range, FhevcMvCost mvc, FhevcMotionNode* __restrict__ out)
 {
   __shared__ __attribute__((aligned(16))) short s_ref[WIN_ROWS * RP + 8];
@@ -118,6 +124,7 @@ __global__ __launch_bounds__(256) void fhevc_motion_kernel(FhevcFrames F, int ra
   const int side = 2 * range + 1, nmv = side * side, centre = (nmv - 1) >> 1;
   const int win = 64 + 2 * range;
   const int shift = F.bit_depth - 8;
+  const int delta = (8 - (range & 7)) & 7;  // the window starts at column 64 cx - range: delta samples after a multiple of 8
   const T* plane = reinterpret_cast<const T*>(F.luma);
 
   for (int work = blockIdx.x; work < total; work += gridDim.x) {
@@ -128,14 +135,27 @@ __global__ __launch_bounds__(256) void fhevc_motion_kernel(FhevcFrames F, int ra
     // ---- stage the reference window: rows cy*64 - R .. + win, columns cx*64 - R .. + win, coordinates clamped to the picture ----
     __syncthreads();  // the previous CTU's readers are done
     {
-      const int chunks = (win + 7) >> 3;
+      // chunks of 8 samples starting at a column that is a multiple of 8 (delta = what the window's first column lacks to one): a chunk
+      // inside the picture is ONE 16-byte (uint8 planes: 8-byte) load where the plane allows it, and one 16-byte LDS store
+      const int chunks = (win + delta + 7) >> 3;
       for (int it = tid; it < win * chunks; it += 256) {
         const int wr = it / chunks, wc = (it - wr * chunks) * 8;
         const int py = min(max(cy * 64 - range + wr, 0), F.height - 1);
-        const int px0 = cx * 64 - range + wc;
+        const int px0 = cx * 64 - range - delta + wc;
         short v[8];
         const long long row = ref_base + (long long)py * F.stride;
-        if (px0 >= 0 && px0 + 8 <= F.width) {
+        const T* src = plane + row + px0;
+        if (px0 >= 0 && px0 + 8 <= F.width && (reinterpret_cast<uintptr_t>(src) & (8 * sizeof(T) - 1)) == 0) {
+          if (sizeof(T) == 2) {
+            const uint4 q = *reinterpret_cast<const uint4*>(src);
+            *reinterpret_cast<uint4*>(s_ref + wr * RP + wc) = q;
+            continue;
+          } else {
+            const uint2 q = *reinterpret_cast<const uint2*>(src);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v[k] = (short)((q.x >> (8 * k)) & 0xFF); v[4 + k] = (short)((q.y >> (8 * k)) & 0xFF); }
+          }
+        } else if (px0 >= 0 && px0 + 8 <= F.width) {
 #pragma unroll
           for (int k = 0; k < 8; ++k) v[k] = (short)sample_at(plane, row + px0 + k);
         } else {
@@ -172,10 +192,21 @@ __global__ __launch_bounds__(256) void fhevc_motion_kernel(FhevcFrames F, int ra
     (void)zero8;
     for (int m = wave; m < nmv; m += 4) {  // raster order inside a wave; the waves interleave and are merged by (cost, index)
       const int dy = m / side - range, dx = m % side - range;
-      const int col = tx * 8 + range + dx, row0 = ty * 8 + range + dy;
+      const int col = tx * 8 + range + dx + delta, row0 = ty * 8 + range + dy;
       const unsigned sh = (unsigned)(col & 1) * 16u;  // uniform: R + dx
       unsigned t8;
-      if (PACKED) {
+      if (PACKED && SAD) {  // sum |org - ref| on pairs of unsigned 16-bit samples: v_sad_u16
+        t8 = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const unsigned* q = reinterpret_cast<const unsigned*>(s_ref) + (((row0 + j) * RP + col) >> 1);
+          const unsigned d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
+          t8 = __builtin_amdgcn_sad_u16(O[4 * j + 0], __builtin_amdgcn_alignbit(d1, d0, sh), t8);
+          t8 = __builtin_amdgcn_sad_u16(O[4 * j + 1], __builtin_amdgcn_alignbit(d2, d1, sh), t8);
+          t8 = __builtin_amdgcn_sad_u16(O[4 * j + 2], __builtin_amdgcn_alignbit(d3, d2, sh), t8);
+          t8 = __builtin_amdgcn_sad_u16(O[4 * j + 3], __builtin_amdgcn_alignbit(d4, d3, sh), t8);
+        }
+      } else if (PACKED) {
         unsigned D[32];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -197,9 +228,14 @@ __global__ __launch_bounds__(256) void fhevc_motion_kernel(FhevcFrames F, int ra
             const int os = (k & 1) ? (int)(short)(o >> 16) : (int)(short)(o & 0xFFFFu);
             v[8 * j + k] = os - (int)s_ref[(row0 + j) * RP + col + k];
           }
-        t8 = had8x8_wide(v);
+        if (SAD) {
+          t8 = 0;
+#pragma unroll
+          for (int i = 0; i < 64; ++i) t8 += (unsigned)abs(v[i]);
+        } else t8 = had8x8_wide(v);
       }
-      t8 = inside ? ((t8 + 2) >> 2) : 0u;  // xCalcHADs8x8: (sum + 2) >> 2 (TComRdCost.cpp:1747)
+      if (SAD) t8 = inside ? t8 : 0u;
+      else t8 = inside ? ((t8 + 2) >> 2) : 0u;  // xCalcHADs8x8: (sum + 2) >> 2 (TComRdCost.cpp:1747)
       // node sums: 16x16 = tiles (tx ^ 1, ty ^ 1), 32x32 = + bits 1, 64x64 = + bits 2
       unsigned s[4];
       s[3] = t8;
@@ -251,16 +287,16 @@ __global__ __launch_bounds__(256) void fhevc_motion_kernel(FhevcFrames F, int ra
 
 }  // namespace
 
-hipError_t fhevc_launch_motion(const FhevcFrames& fr, int range, const FhevcMvCost& mvc, FhevcMotionNode* d_out, int num_cus, hipStream_t stream)
+hipError_t fhevc_launch_motion(const FhevcFrames& fr, int range, const FhevcMvCost& mvc, FhevcMotionNode* d_out, int num_cus, bool sad, hipStream_t stream)
 {
   const long long total = (long long)(fr.row_end - fr.row_begin) * fr.ctus_x * (fr.num_frames - 1);
   if (total <= 0) return hipSuccess;
   const int grid = (int)(total < 4LL * num_cus ? total : 4LL * num_cus);
-  if (fr.sample_bytes == 2 && fr.bit_depth <= 10)
-    hipLaunchKernelGGL((fhevc_motion_kernel<int16_t, true>), dim3(grid), dim3(256), 0, stream, fr, range, mvc, d_out);
-  else if (fr.sample_bytes == 2)
-    hipLaunchKernelGGL((fhevc_motion_kernel<int16_t, false>), dim3(grid), dim3(256), 0, stream, fr, range, mvc, d_out);
-  else
-    hipLaunchKernelGGL((fhevc_motion_kernel<uint8_t, true>), dim3(grid), dim3(256), 0, stream, fr, range, mvc, d_out);
+#define FHEVC_MOTION(T, P) do { if (sad) hipLaunchKernelGGL((fhevc_motion_kernel<T, P, true>), dim3(grid), dim3(256), 0, stream, fr, range, mvc, d_out); \
+                                else hipLaunchKernelGGL((fhevc_motion_kernel<T, P, false>), dim3(grid), dim3(256), 0, stream, fr, range, mvc, d_out); } while (0)
+  if (fr.sample_bytes == 2 && fr.bit_depth <= 10) FHEVC_MOTION(int16_t, true);
+  else if (fr.sample_bytes == 2) FHEVC_MOTION(int16_t, false);
+  else FHEVC_MOTION(uint8_t, true);
+#undef FHEVC_MOTION
   return hipGetLastError();
 }

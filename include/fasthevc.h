@@ -188,15 +188,24 @@ int  fhevc_preanalyze_frames_device(fhevc_ctx* ctx, const void* d_luma, int samp
 /* ---- config 4 (P slices): source-only motion search per CU node ----------------------------------------------------
  * For every CU node of every CTU (node order as fhevc_node_cost): integer full search over [-search_range, search_range]^2
  * in the PREVIOUS ORIGINAL picture, raster order and strict "<" as TEncSearch::xPatternSearch (TEncSearch.cpp:3786-3848),
- * cost = Hadamard SATD (TComRdCost::xGetHADs, the distortion HM uses under HADME) + TComRdCost::getCostOfVectorWithPredictor
- * (TComRdCost.h:166-174; zero predictor, lambda of slice QP qp), samples outside the picture replicated from the border
- * (TComPicYuv::extendPicBorder).  HM's own search runs on reconstructed references inside its serial CTU loop; this is
- * its source-only twin, available for the whole picture before that loop starts.  search_range 1..8. */
+ * cost = distortion + TComRdCost::getCostOfVectorWithPredictor (TComRdCost.h:166-174; zero predictor, iCostScale 2, lambda of
+ * slice QP qp), samples outside the picture replicated from the border (TComPicYuv::extendPicBorder).  Distortion
+ * (fhevc_set_motion_distortion):
+ *   FHEVC_MOTION_SAD   what HM's integer search uses (xPatternSearch's setDistParam selects DF_SAD, TComRdCost.cpp:205-236): in this
+ *                      mode vector, distortion and cost equal what the reference's own xPatternSearch returns on the same planes;
+ *   FHEVC_MOTION_SATD  (default) Hadamard SATD (TComRdCost::xGetHADs) at integer positions.  HM applies Hadamard to the fractional
+ *                      refinement only (HadamardME, TEncSearch.cpp:836): this is the library's own choice, the one the P-picture
+ *                      rule of fhevc_p_depth_range was fitted on.
+ * HM's own search runs on reconstructed references inside its serial CTU loop; this is its source-only twin, available for
+ * the whole picture before that loop starts.  search_range 1..8 (HM's cfg: 64 with a TZ search). */
+#define FHEVC_MOTION_SATD 0
+#define FHEVC_MOTION_SAD  1
+int  fhevc_set_motion_distortion(fhevc_ctx* ctx, int mode);
 #define FHEVC_MOTION_MAX_RANGE 8
 typedef struct {
-  uint32_t satd_zero;       /* SATD at vector (0, 0) */
-  uint32_t satd_best;       /* SATD at the cheapest vector */
-  uint32_t cost_best;       /* its SATD + vector cost; 0xFFFFFFFF in all three for nodes crossing the picture edge */
+  uint32_t satd_zero;       /* distortion (SATD or SAD) at vector (0, 0) */
+  uint32_t satd_best;       /* distortion at the cheapest vector */
+  uint32_t cost_best;       /* its distortion + vector cost; 0xFFFFFFFF in all three for nodes crossing the picture edge */
   int16_t  mvx, mvy;        /* the cheapest vector, integer samples */
 } fhevc_motion_node;
 /* one picture pair, host buffers (both planes with the same stride), synchronous; out: numCtus * 85 */

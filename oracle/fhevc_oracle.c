@@ -492,7 +492,14 @@ void fho_first_pass_ctu(const int16_t* luma, int stride, int width, int height,
 /* ------------------------------------------------------------------------------------------
  * A13 / N4: source-only integer motion search per CU node (config 4).  Search loop as TEncSearch::xPatternSearch
  * (TEncSearch.cpp:3786-3848): y outer, x inner, strict "<"; vector cost as TComRdCost::getCostOfVectorWithPredictor
- * (TComRdCost.h:166-174) with a zero predictor and iCostScale 2; distortion = xGetHADs (8x8 tiles).
+ * (TComRdCost.h:166-174) with a zero predictor and iCostScale 2.  Distortion, two modes:
+ *   dist = 1 (FHO_MOTION_SAD):  the distortion HM's integer search really uses -- xPatternSearch calls the 4-argument
+ *            setDistParam, which selects DF_SAD (TComRdCost.cpp:205-236, xGetSAD* :518-..): sum |org - ref| over the block,
+ *            >> (bitDepth - 8) once at the end.  PINNED: tests/golden/ref_pattern_search.npz holds what the reference's own
+ *            xPatternSearch returned (vector, SAD, cost) for the nodes of whole CTUs incl. picture-edge ones.
+ *   dist = 0 (FHO_MOTION_SATD): Hadamard distortion (xGetHADs over 8x8 tiles).  HM applies Hadamard only to the FRACTIONAL
+ *            refinement (HadamardME, TEncSearch.cpp:836; cfg/encoder_lowdelay_P_main.cfg:37), so at integer positions this is
+ *            THIS build's choice, not HM's: the P-picture rule's features were fitted on it (tests/quality/fit_p_rule.py).
  * ------------------------------------------------------------------------------------------ */
 static unsigned exp_golomb_bits(int v) /* TComRdCost.cpp:177-190 */
 {
@@ -507,10 +514,17 @@ uint32_t fho_mv_cost(int x, int y, double sqrt_lambda)
   const unsigned bits = exp_golomb_bits(x << 2) + exp_golomb_bits(y << 2);
   return (uint32_t)((motion_lambda * bits) / 65536.0);
 }
-void fho_motion_ctu(const int16_t* cur, int cs, const int16_t* ref, int rs, int width, int height,
-                    int ctu_x, int ctu_y, int bit_depth, int range, double sqrt_lambda, fho_motion_node out[85])
+static uint32_t sad8x8(const int16_t* org, int so, const int16_t* cur, int sc)
 {
-  static uint32_t tile[17 * 17][64]; /* [mv][tile], not re-entrant: test infrastructure */
+  uint32_t s = 0;
+  for (int y = 0; y < 8; y++)
+    for (int x = 0; x < 8; x++) s += (uint32_t)abs((int)org[y * so + x] - (int)cur[y * sc + x]);
+  return s;
+}
+void fho_motion_ctu_dist(const int16_t* cur, int cs, const int16_t* ref, int rs, int width, int height,
+                         int ctu_x, int ctu_y, int bit_depth, int range, double sqrt_lambda, int dist, fho_motion_node out[85])
+{
+  static uint32_t tile[(2 * 64 + 1) * (2 * 64 + 1)][64]; /* [mv][tile], not re-entrant: test infrastructure */
   const int side = 2 * range + 1, x0 = ctu_x * CTU, y0 = ctu_y * CTU;
   for (int m = 0; m < side * side; m++) {
     const int dy = m / side - range, dx = m % side - range;
@@ -521,7 +535,7 @@ void fho_motion_ctu(const int16_t* cur, int cs, const int16_t* ref, int rs, int 
       for (int y = 0; y < 8; y++)
         for (int x = 0; x < 8; x++)
           blk[y * 8 + x] = ref[clip3(0, height - 1, ty + y + dy) * rs + clip3(0, width - 1, tx + x + dx)];
-      tile[m][t] = fho_had8x8(cur + ty * cs + tx, cs, blk, 8);
+      tile[m][t] = dist ? sad8x8(cur + ty * cs + tx, cs, blk, 8) : fho_had8x8(cur + ty * cs + tx, cs, blk, 8);
     }
   }
   int idx = 0;
@@ -540,13 +554,18 @@ void fho_motion_ctu(const int16_t* cur, int cs, const int16_t* ref, int rs, int 
           uint32_t s = 0;
           for (int j = 0; j < tn; j++)
             for (int i = 0; i < tn; i++) s += tile[m][(by * tn + j) * 8 + bx * tn + i];
-          s >>= (bit_depth - 8);
+          s >>= (bit_depth - 8);   /* both distortions shift the block's sum once (DISTORTION_PRECISION_ADJUSTMENT) */
           if (dx == 0 && dy == 0) o->satd_zero = s;
           const uint32_t c = s + fho_mv_cost(dx, dy, sqrt_lambda);
           if (c < best) { best = c; o->cost_best = c; o->satd_best = s; o->mvx = (int16_t)dx; o->mvy = (int16_t)dy; }
         }
       }
   }
+}
+void fho_motion_ctu(const int16_t* cur, int cs, const int16_t* ref, int rs, int width, int height,
+                    int ctu_x, int ctu_y, int bit_depth, int range, double sqrt_lambda, fho_motion_node out[85])
+{
+  fho_motion_ctu_dist(cur, cs, ref, rs, width, height, ctu_x, ctu_y, bit_depth, range, sqrt_lambda, 0, out);
 }
 
 /* P-picture depth range (include/fasthevc.h: fhevc_p_depth_range) */

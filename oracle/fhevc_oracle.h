@@ -115,6 +115,11 @@ typedef struct { uint32_t satd_zero, satd_best, cost_best; int16_t mvx, mvy; } f
 uint32_t fho_mv_cost(int x, int y, double sqrt_lambda);
 /* one CTU: out[85] in the node order of fho_first_pass_ctu; nodes crossing the picture edge get 0xFFFFFFFF / mv 0.
  * range <= 8.  cost of a node at mv = (sum of its 8x8 tile SATDs >> (bit_depth - 8)) + fho_mv_cost(mv). */
+#define FHO_MOTION_SATD 0
+#define FHO_MOTION_SAD 1
+/* dist: FHO_MOTION_SAD = HM's integer-search distortion (pinned to the reference's xPatternSearch), FHO_MOTION_SATD = Hadamard */
+void fho_motion_ctu_dist(const int16_t* cur, int cur_stride, const int16_t* ref, int ref_stride, int width, int height,
+                         int ctu_x, int ctu_y, int bit_depth, int range, double sqrt_lambda, int dist, fho_motion_node out[85]);
 void fho_motion_ctu(const int16_t* cur, int cur_stride, const int16_t* ref, int ref_stride, int width, int height,
                     int ctu_x, int ctu_y, int bit_depth, int range, double sqrt_lambda, fho_motion_node out[85]);
 /* Depth range of a P picture's CTU from its motion nodes and the co-located depths of the reference picture: the integer rule

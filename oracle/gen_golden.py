@@ -113,6 +113,7 @@ def main():
     print("wrote", dst, os.path.getsize(dst), "bytes")
     preanalyze_golden(ref)
     intra_lines_golden(ref)
+    pattern_search_golden(ref)
 
 
 PREANALYZE_CASES = (("texture16", 416, 240, 8, 3), ("hetero", 1000, 568, 10, 4), ("hetero", 64, 64, 8, 1))
@@ -193,3 +194,53 @@ if __name__ == "__main__":
         preanalyze_golden(op.load_ref())
     else:
         main()
+
+
+PATTERN_SEARCH_CASES = (  # (bit depth, qp, range, clip seed, CTUs of the 7 x 4 grid of 416x240: corners, edges (32 wide / 48 tall), interior)
+    (8, 38, 4, 15, (0, 3, 6, 10, 21, 27)),
+    (10, 33, 3, 16, (8, 13, 20)),
+    (8, 22, 8, 17, (9, 26)))
+
+
+def pattern_search_golden(ref):
+    """Config 4: what the reference's OWN TEncSearch::xPatternSearch (TEncSearch.cpp:3786-3848: SAD + vector cost, raster order, strict <)
+    returns for every in-picture CU node of whole CTUs -- vector, SAD, cost -- on the seeded pan clip (original planes, zero predictor).
+    The planes are stored with the expected outputs (data only)."""
+    import ctypes as C
+    oracle = op.load_oracle()
+    ref.href_pattern_search.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    W, H = 416, 240
+    out = {"cases": np.array([list(c[:4]) for c in PATTERN_SEARCH_CASES], np.int32)}
+    total = 0
+    for k, (bd, qp, rng, seed, ctus) in enumerate(PATTERN_SEARCH_CASES):
+        ys = frames.pan_clip(W, H, 2, seed=seed)
+        (rb, org, stride), (cb, _, _) = [frames.to_pel_plane(y, bd) for y in ys]
+        if bd > 8:  # use the low bits too
+            cb = (cb + np.random.default_rng(bd).integers(0, 1 << (bd - 8), size=cb.shape, dtype=np.int16)).astype(np.int16)
+            rb = (rb + np.random.default_rng(bd + 1).integers(0, 1 << (bd - 8), size=rb.shape, dtype=np.int16)).astype(np.int16)
+        cur = np.ascontiguousarray(cb.reshape(-1)[org:].copy()[: (H - 1) * stride + W])  # from sample (0, 0) on, HM stride
+        refp = np.ascontiguousarray(rb.reshape(-1)[org:].copy()[: (H - 1) * stride + W])
+        lam = oracle.fho_lambda_intra(qp, bd)
+        res = np.full((len(ctus), 85, 4), -1, np.int32)
+        for ci, c in enumerate(ctus):
+            cx, cy = c % 7, c // 7
+            blocks, where = [], []
+            idx = 0
+            for lvl in range(4):
+                n, cnt = 64 >> lvl, 1 << lvl
+                for by in range(cnt):
+                    for bx in range(cnt):
+                        x0, y0 = cx * 64 + bx * n, cy * 64 + by * n
+                        if x0 + n <= W and y0 + n <= H:
+                            blocks.append((x0, y0, n)); where.append(idx)
+                        idx += 1
+            b = np.array(blocks, np.int32)
+            o = np.zeros((len(blocks), 4), np.int32)
+            assert ref.href_pattern_search(cur.ctypes.data, refp.ctypes.data, stride, W, H, bd, C.c_double(lam), rng, len(blocks), b.ctypes.data, o.ctypes.data) == len(blocks)
+            res[ci, where] = o
+            total += len(blocks)
+        out[f"cur{k}"], out[f"ref{k}"], out[f"stride{k}"] = cur, refp, np.int32(stride)
+        out[f"ctus{k}"], out[f"nodes{k}"] = np.array(ctus, np.int32), res
+    dst = os.path.join(os.path.dirname(HERE), "tests", "golden", "ref_pattern_search.npz")
+    np.savez_compressed(dst, **out)
+    print("wrote", dst, os.path.getsize(dst), "bytes;", total, "nodes searched by the reference's xPatternSearch")

@@ -84,6 +84,9 @@ def load_oracle():
     lib.fho_motion_ctu.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_double, C.c_void_p]
     lib.fho_motion_ctu.restype = None
+    lib.fho_motion_ctu_dist.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_double, C.c_int, C.c_void_p]
+    lib.fho_motion_ctu_dist.restype = None
     lib.fho_ilog2_q8.argtypes = [C.c_uint32]
     lib.fho_ilog2_q8.restype = C.c_int32
     lib.fho_p_depth_range.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(PRule), C.c_void_p, C.c_void_p]

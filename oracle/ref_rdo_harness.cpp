@@ -589,6 +589,43 @@ int href_mode_bits_origin(int width, int height, int bit_depth, int qp, int dept
   return 35;
 }
 
+// ---- config 4: the reference's OWN integer full search, TEncSearch::xPatternSearch (TEncSearch.cpp:3786-3848), on ORIGINAL planes.
+// cur / ref: luma planes (stride in samples); the reference plane is copied into a TComPicYuv with HM's margins and extended by the
+// reference's own TComPicYuv::extendPicBorder (TComPicYuv.cpp).  Per block (x0, y0, n): TComPattern on the current plane, the window
+// [-range, +range]^2 around zero handed over as xMotionEstimation would after xSetSearchRange, distortion set up by the 4-argument
+// TComRdCost::setDistParam (-> DF_SAD, TComRdCost.cpp:205-236), vector cost getCostOfVectorWithPredictor (TComRdCost.h:166-174) with a
+// zero predictor, iCostScale 2 and m_motionLambda = m_dLambdaMotionSAD[0] = 65536 sqrt(lambda) (setLambda, selectMotionLambda(true, ..)).
+// out per block: mvx, mvy, the SAD the function returns (ruiSAD: best cost minus its vector cost), and the best cost.
+int href_pattern_search(const int16_t* cur, const int16_t* ref, int stride, int width, int height, int bit_depth, double lambda, int range,
+                        int nblocks, const int* blocks /* x0, y0, n per block */, int* out /* mvx, mvy, sad, cost per block */)
+{
+  Encoder* e = get_encoder(width, height, bit_depth);
+  TComPicYuv refYuv;
+  refYuv.create(width, height, CHROMA_420, 64, 64, 4, true);
+  Pel* dst = refYuv.getAddr(COMPONENT_Y);
+  const int rs = refYuv.getStride(COMPONENT_Y);
+  for (int y = 0; y < height; y++) std::memcpy(dst + (size_t)y * rs, ref + (size_t)y * stride, (size_t)width * sizeof(Pel));
+  refYuv.extendPicBorder();
+  e->rd.setLambda(lambda, e->sps.getBitDepths());
+  e->rd.selectMotionLambda(true, 0, false);
+  TComMv zero(0, 0);
+  e->rd.setPredictor(zero);
+  e->rd.setCostScale(2);
+  for (int b = 0; b < nblocks; b++) {
+    const int x0 = blocks[3 * b], y0 = blocks[3 * b + 1], n = blocks[3 * b + 2];
+    if (x0 < 0 || y0 < 0 || x0 + n > width || y0 + n > height || range < 0 || range > 64) { refYuv.destroy(); return -1; }
+    TComPattern pattern;
+    pattern.initPattern(const_cast<Pel*>(cur) + (size_t)y0 * stride + x0, n, n, stride, bit_depth);
+    TComMv lt(-range, -range), rb(range, range), mv;
+    Distortion sad = 0;
+    e->search.xPatternSearch(&pattern, dst + (size_t)y0 * rs + x0, rs, &lt, &rb, mv, sad);
+    out[4 * b] = mv.getHor(); out[4 * b + 1] = mv.getVer(); out[4 * b + 2] = (int)sad;
+    out[4 * b + 3] = (int)(sad + e->rd.getCostOfVectorWithPredictor(mv.getHor(), mv.getVer()));
+  }
+  refYuv.destroy();
+  return nblocks;
+}
+
 // debugging aid: histograms of the decisions of the last encoded picture of that geometry
 int href_rdo_debug_hist(int width, int height, int bit_depth, int* modes35, int* part2, int* trdepth4, int* tskip2, int* cbf2)
 {

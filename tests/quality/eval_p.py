@@ -40,8 +40,11 @@ def load_p():
     return lib
 
 
+SPEED = 3  # px / frame of the clip's two overlaid motions (--speed; 3 = the pinned clip)
+
+
 def pan_clip(W, H, nframes=2, seed=1234):
-    return frames.pan_clip(W, H, nframes, seed)
+    return frames.pan_clip(W, H, nframes, seed, v_structure=SPEED, v_noise=SPEED)
 
 
 def cnn_ranges(oracle, ws, y, qp, margin_split, margin_stop):
@@ -96,7 +99,7 @@ def encode_seq(lib, ys, qp, window=None, cnn=None, motion=None):
             fmin, fmax = cnn_ranges(cnn[0], cnn[1], ys[f], qp + 6, cnn[2], cnn[3])
             fmin, fmax = np.ascontiguousarray(fmin), np.ascontiguousarray(fmax)
         elif motion is not None and f >= 2:  # (oracle, rule): motion features + the previous P picture's depths
-            fmin, fmax = motion_ranges(motion[0], motion[1], ys[f], ys[f - 1], out[-1][0], qp + 6)
+            fmin, fmax = motion_ranges(motion[0], motion[1], ys[f], ys[f - 1], out[-1][0], qp + 6, motion[2] if len(motion) > 2 else 4)
             fmin, fmax = np.ascontiguousarray(fmin), np.ascontiguousarray(fmax)
         elif window is not None and f >= 2:
             prev = out[-1][0].astype(int)
@@ -116,7 +119,8 @@ def encode_seq(lib, ys, qp, window=None, cnn=None, motion=None):
 
 def _run_qp(job):
     """one slice QP: the anchor (unrestricted search) and every variant; runs in its own process (HM is single-threaded)"""
-    qp, variants, (W, H), nframes = job
+    global SPEED
+    qp, variants, (W, H), nframes, SPEED = job
     from oracle import oracle_py as op
     from fasthevc_amd import capi
     lib, oracle = load_p(), op.load_oracle()
@@ -135,7 +139,7 @@ def _run_qp(job):
                 if "t_stop" in v:
                     rule.t_stop[l] = int(v["t_stop"][l] * (1 << 18))
             rule.window = v.get("window", rule.window)
-            seq = encode_seq(lib, ys, qp, motion=(oracle, rule))
+            seq = encode_seq(lib, ys, qp, motion=(oracle, rule, v.get("search_range", 4)))
         out[name] = tail(seq)
         out[name + ":agreement"] = [float((seq[f][0] == anchor[f][0]).mean()) for f in range(2, nframes)]
     return qp, out
@@ -155,16 +159,17 @@ def main():
     ap.add_argument("--json", default=None)
     ap.add_argument("--variants", default=None, help="JSON: {name: {kind: window|rule, window: ..., t_split: [3], t_stop: [3]}}")
     ap.add_argument("--workers", type=int, default=4)
+    ap.add_argument("--speed", type=int, default=3, help="px / frame of the clip's motions (beyond the search range: what the rule does when the source-only search cannot reach the true motion)")
     args = ap.parse_args()
     from multiprocessing import Pool
     W, H = (int(v) for v in args.size.split("x"))
     variants = json.loads(args.variants) if args.variants else DEFAULT_VARIANTS
     qps = (22, 27, 32, 37)
     with Pool(args.workers) as pool:
-        res = dict(pool.map(_run_qp, [(qp, variants, (W, H), args.frames) for qp in qps]))
+        res = dict(pool.map(_run_qp, [(qp, variants, (W, H), args.frames, args.speed) for qp in qps]))
     ra, pa = [res[q]["anchor"][0] for q in qps], [res[q]["anchor"][1] for q in qps]
     ta = sum(res[q]["anchor"][2] for q in qps)
-    report = {"clip": f"{W}x{H} pan clip (frames.pan_clip), {args.frames} frames I P P ..., P pictures at QP + 6; restricted pictures: POC >= 2 "
+    report = {"clip": f"{W}x{H} pan clip (frames.pan_clip, {args.speed} px / frame), {args.frames} frames I P P ..., P pictures at QP + 6; restricted pictures: POC >= 2 "
                       "(their reference picture is a P picture); decision stage: bits counted by encodeCtu, luma PSNR before the in-loop filters",
               "qp": list(qps), "anchor": [res[q]["anchor"] for q in qps], "pictures": [res[q]["pictures"] for q in qps], "variants": {}, "summary": {}}
     for name, v in variants.items():

@@ -10,14 +10,14 @@ from fasthevc_amd import capi, frames
 pytestmark = pytest.mark.gpu
 
 
-def oracle_motion(oracle, cur, ref, origin, stride, W, H, bd, qp, rng, ctus=None):
+def oracle_motion(oracle, cur, ref, origin, stride, W, H, bd, qp, rng, ctus=None, sad=False):
     cw, ch = (W + 63) // 64, (H + 63) // 64
     out = np.zeros((cw * ch, 85), capi.MOTION_DTYPE)
     sl = oracle.fho_lambda_intra(qp, bd) ** 0.5
     cp, rp = cur.reshape(-1).ctypes.data + 2 * origin, ref.reshape(-1).ctypes.data + 2 * origin
     for c in (range(cw * ch) if ctus is None else ctus):
-        oracle.fho_motion_ctu(C.c_void_p(cp), stride, C.c_void_p(rp), stride, W, H, c % cw, c // cw, bd, rng, C.c_double(sl),
-                              C.c_void_p(out[c].ctypes.data))
+        oracle.fho_motion_ctu_dist(C.c_void_p(cp), stride, C.c_void_p(rp), stride, W, H, c % cw, c // cw, bd, rng, C.c_double(sl), 1 if sad else 0,
+                                   C.c_void_p(out[c].ctypes.data))
     return out
 
 
@@ -25,8 +25,9 @@ def same(a, b):
     return all(np.array_equal(a[k], b[k]) for k in capi.MOTION_DTYPE.names)
 
 
-@pytest.mark.parametrize("bd,rng,qp", [(8, 4, 38), (8, 1, 22), (8, 8, 43), (10, 3, 33), (12, 2, 38)])
-def test_motion_search_vs_oracle_small(oracle, bd, rng, qp):
+@pytest.mark.parametrize("sad", [False, True])
+@pytest.mark.parametrize("bd,rng,qp", [(8, 4, 38), (8, 1, 22), (8, 8, 43), (10, 3, 33), (12, 2, 38), (8, 5, 30), (10, 7, 27)])
+def test_motion_search_vs_oracle_small(oracle, bd, rng, qp, sad):
     W, H = 416, 240  # ragged: last CTU column 32 wide, last row 48 tall
     ys = frames.pan_clip(W, H, 2, seed=7 + bd)
     planes = [frames.to_pel_plane(y, bd) for y in ys]
@@ -35,8 +36,10 @@ def test_motion_search_vs_oracle_small(oracle, bd, rng, qp):
         noise = np.random.default_rng(bd).integers(0, 1 << (bd - 8), size=cb.shape, dtype=np.int16)
         cb = (cb + noise).astype(np.int16)
     ctx = capi.Context(W, H, bd)
+    if sad:
+        ctx.set_motion_distortion("sad")
     got = ctx.motion_search(cb, rb, org, stride, qp=qp, search_range=rng)
-    exp = oracle_motion(oracle, cb, rb, org, stride, W, H, bd, qp, rng)
+    exp = oracle_motion(oracle, cb, rb, org, stride, W, H, bd, qp, rng, sad=sad)
     assert same(got, exp)
     # border nodes are flagged, interior ones are not
     assert got["cost_best"][6, 0] == 0xFFFFFFFF and got["cost_best"][0, 0] != 0xFFFFFFFF
@@ -116,3 +119,28 @@ def test_motion_search_1080p_device_batch(oracle):
     assert not (on_edge == -3).any() and (on_edge == 3).mean() > 0.25 and np.isin(on_edge, (0, 3)).all()
     assert (plain == 0).all()
     ctx.close()
+
+
+def test_sad_mode_reproduces_the_references_xPatternSearch():
+    """The HIP kernel in its SAD mode, through the C ABI, against what the reference's OWN TEncSearch::xPatternSearch returned
+    (tests/golden/ref_pattern_search.npz: 706 nodes of whole CTUs incl. picture corners and edges, 8 / 10 bit, ranges 3 / 4 / 8):
+    vector, SAD and cost, directly -- no oracle in between."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_pattern_search.npz"))
+    W, H = 416, 240
+    checked = 0
+    for k, (bd, qp, rng, _seed) in enumerate(g["cases"]):
+        cur, ref, stride = g[f"cur{k}"], g[f"ref{k}"], int(g[f"stride{k}"])
+        ctx = capi.Context(W, H, int(bd))
+        ctx.set_motion_distortion("sad")
+        got = ctx.motion_search(cur, ref, 0, stride, qp=int(qp), search_range=int(rng))
+        for ci, c in enumerate(g[f"ctus{k}"]):
+            exp = g[f"nodes{k}"][ci]
+            valid = exp[:, 3] >= 0
+            n = got[int(c)]
+            assert (n["cost_best"][~valid] == 0xFFFFFFFF).all()
+            assert np.array_equal(n["mvx"][valid], exp[valid, 0]) and np.array_equal(n["mvy"][valid], exp[valid, 1]), (k, c)
+            assert np.array_equal(n["satd_best"][valid], exp[valid, 2].astype(np.uint32)) and np.array_equal(n["cost_best"][valid], exp[valid, 3].astype(np.uint32)), (k, c)
+            checked += int(valid.sum())
+        ctx.close()
+    assert checked == 706
