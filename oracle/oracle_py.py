@@ -246,4 +246,11 @@ def rdo_encode(lib, plane, origin, stride, width, height, bit_depth, qp, forced_
         out["slice_data_bits"] = stats[8]
     if stats[7] > 0:  # FHREF_DEBLOCK=1: luma PSNR after the reference's own deblocking filter
         out["psnr_y_deblocked"] = 10 * np.log10(peak * peak / (stats[7] / (width * height)))
+    if stats[9] > 0:  # FHREF_SAO=1 (with FHREF_DEBLOCK=1): luma PSNR after both in-loop filters, SAO decided by the reference's own SAOProcess
+        out["psnr_y_filtered"] = 10 * np.log10(peak * peak / (stats[9] / (width * height)))
+    if stats[8] > 0:  # md5 of the slice-data bytes (SURVEY F11 at the byte level)
+        lib.href_slice_md5.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p]
+        dg = (C.c_ubyte * 16)()
+        if lib.href_slice_md5(width, height, bit_depth, dg) == 0:
+            out["slice_data_md5"] = bytes(dg).hex()
     return depth.reshape(n, 256), out

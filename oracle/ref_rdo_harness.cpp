@@ -48,6 +48,8 @@
 #include "TLibEncoder/TEncCu.h"
 #include "TLibEncoder/TEncSlice.h"
 #include "TLibEncoder/TEncSearch.h"
+#include "TLibEncoder/TEncSampleAdaptiveOffset.h"
+#include "libmd5/MD5.h"
 #include "TLibEncoder/TEncEntropy.h"
 #include "TLibEncoder/TEncSbac.h"
 #include "TLibEncoder/TEncBinCoderCABAC.h"
@@ -86,6 +88,10 @@ struct Encoder {
   TComPic* pic0 = nullptr;   // the first picture object (pic may point to either while P pictures ping-pong)
   TComPic* pic1 = nullptr;   // second picture object (P-slice variant)
   TComPic* last = nullptr;   // the picture encoded last: reference of the next P picture
+  TEncSampleAdaptiveOffset sao;   // FHREF_SAO=1: the reference's own SAO decision + filter after the deblocking pass
+  bool sao_created = false;
+  unsigned char slice_md5[16] = { 0 };   // md5 of the slice-data bytes the last encodeSlice wrote (FHREF_ENCODE_SLICE=1)
+  bool have_md5 = false;
 };
 
 std::map<long long, Encoder*> g_encoders;
@@ -301,7 +307,7 @@ extern "C" {
 // over CTUs), [1] distortion (SSE, chroma weighted as in TComRdCost), [2] RD cost, [3] seconds in compressSlice,
 // [4] luma SSE of the reconstruction vs the original, [5] number of CTUs, [6] bits counted by encodeCtu, [7] luma SSE after the
 // reference's own deblocking filter when FHREF_DEBLOCK=1 (else -1), [8] slice-data bits written by the reference's own encodeSlice
-// (real CABAC) when FHREF_ENCODE_SLICE=1 (else -1).
+// (real CABAC) when FHREF_ENCODE_SLICE=1 (else -1), [9] luma SSE after deblocking AND the reference's own SAO when FHREF_SAO=1 (else -1).
 int href_rdo_encode_frame_yuv(const int16_t* luma, int stride, const int16_t* cb, const int16_t* cr, int width, int height,
                               int bit_depth, int qp, const uint8_t* forced_depth, uint8_t* depth_out, double* stats);
 
@@ -364,14 +370,9 @@ int href_rdo_encode_frame_yuv(const int16_t* luma, int stride, const int16_t* cb
     stats[5] = n;
     stats[7] = -1.0;
     stats[8] = -1.0;
-    if (env_int("FHREF_ENCODE_SLICE", 0)) {
-      // the reference's own TEncSlice::encodeSlice (TEncSlice.cpp:985-1160: the real arithmetic coder, TEncBinCABAC) over the picture the
-      // decision path has just filled in: slice-data bits as they would stand in the bitstream (no slice header, no SAO syntax: SAO is not run)
-      TComOutputBitstream substream;
-      UInt bins = 0;
-      e->slice.encodeSlice(e->pic, &substream, bins);
-      stats[8] = (double)substream.getNumberOfWrittenBits();
-    }
+    // the in-loop filters and the entropy coder in the order TEncGOP runs them (TEncGOP.cpp:1607-1619 deblocking, :1662-1685 SAO,
+    // :1745 encodeSlice): the SAO syntax of a CTU is part of the slice data, so SAO has to be decided before encodeSlice
+    TComSlice* slice0 = e->pic->getSlice(0);
     if (env_int("FHREF_DEBLOCK", 0)) {
       // the reference's own in-loop deblocking filter on the reconstruction (TComLoopFilter::loopFilterPic, called by TEncGOP.cpp:1607-1619
       // with the slice's default parameters: filter enabled, beta / tc offsets 0), then the luma SSE again: distortion as a decoder
@@ -385,6 +386,48 @@ int href_rdo_encode_frame_yuv(const int16_t* luma, int stride, const int16_t* cb
       for (int y = 0; y < height; y++)
         for (int x = 0; x < width; x++) { const double d = (double)o[y * so + x] - (double)r[y * sr + x]; sse2 += d * d; }
       stats[7] = sse2;
+    }
+    stats[9] = -1.0;
+    if (env_int("FHREF_SAO", 0) && env_int("FHREF_DEBLOCK", 0)) {
+      // the reference's own TEncSampleAdaptiveOffset::SAOProcess on the deblocked picture, set up as TEncTop::create does (TEncTop.cpp:98-101)
+      // and called as TEncGOP does (TEncGOP.cpp:1662-1685; cfg defaults: SaoEncodingRate 0.75 / 0.5, no picture-level test, SAOLcuBoundary 0)
+      if (!e->sao_created) {
+        e->sao.create(width, height, CHROMA_420, 64, 64, 4, 0, 0);
+        e->sao.createEncData(false);
+        e->sao_created = true;
+      }
+      Bool sliceEnabled[MAX_NUM_COMPONENT];
+      TComBitCounter tempBitCounter;
+      tempBitCounter.resetBits();
+      e->rdGoOnSbac.setBitstream(&tempBitCounter);
+      e->sao.initRDOCabacCoder(&e->rdGoOnSbac, slice0);
+      e->sao.SAOProcess(e->pic, sliceEnabled, slice0->getLambdas(), false, 0.75, 0.5, false, false);
+      e->sao.PCMLFDisableProcess(e->pic);
+      e->rdGoOnSbac.setBitstream(NULL);
+      slice0->setSaoEnabledFlag(CHANNEL_TYPE_LUMA, sliceEnabled[COMPONENT_Y]);
+      slice0->setSaoEnabledFlag(CHANNEL_TYPE_CHROMA, sliceEnabled[COMPONENT_Cb]);
+      double sse3 = 0;
+      for (int y = 0; y < height; y++)
+        for (int x = 0; x < width; x++) { const double d = (double)o[y * so + x] - (double)r[y * sr + x]; sse3 += d * d; }
+      stats[9] = sse3;
+    } else {
+      slice0->setSaoEnabledFlag(CHANNEL_TYPE_LUMA, false);    // SAO not run: no SAO syntax in the slice data
+      slice0->setSaoEnabledFlag(CHANNEL_TYPE_CHROMA, false);
+    }
+    e->have_md5 = false;
+    if (env_int("FHREF_ENCODE_SLICE", 0)) {
+      // the reference's own TEncSlice::encodeSlice (TEncSlice.cpp:985-1160: the real arithmetic coder, TEncBinCABAC) over the picture the
+      // decision path has just filled in: slice-data bytes as they would stand in the bitstream (SAO syntax included when SAO ran; the slice
+      // header is TEncGOP's business and not part of it).  Their md5 is kept for href_slice_md5 (SURVEY F11 at the byte level)
+      TComOutputBitstream substream;
+      UInt bins = 0;
+      e->slice.encodeSlice(e->pic, &substream, bins);
+      stats[8] = (double)substream.getNumberOfWrittenBits();
+      MD5 md5;
+      std::vector<uint8_t>& fifo = substream.getFIFO();
+      md5.update(fifo.data(), (unsigned)fifo.size());
+      md5.finalize(e->slice_md5);
+      e->have_md5 = true;
     }
   }
   e->last = e->pic;  // reference of a following P picture (href_rdo_encode_next_p, P-variant builds)
@@ -624,6 +667,16 @@ int href_pattern_search(const int16_t* cur, const int16_t* ref, int stride, int 
   }
   refYuv.destroy();
   return nblocks;
+}
+
+// md5 (16 bytes) of the slice-data bytes written by the reference's encodeSlice in the last href_rdo_encode_frame* call of that geometry
+// (FHREF_ENCODE_SLICE=1); -1 when there is none
+int href_slice_md5(int width, int height, int bit_depth, unsigned char* digest16)
+{
+  Encoder* e = get_encoder(width, height, bit_depth);
+  if (!e->have_md5) return -1;
+  std::memcpy(digest16, e->slice_md5, 16);
+  return 0;
 }
 
 // debugging aid: histograms of the decisions of the last encoded picture of that geometry

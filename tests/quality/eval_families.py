@@ -43,6 +43,7 @@ def work(job):
     family, k, (W, H), margins, blob = job
     os.environ["FHREF_DEBLOCK"] = "1"        # the harness also runs the reference's deblocking filter and reports the PSNR after it
     os.environ["FHREF_ENCODE_SLICE"] = "1"   # ... and the reference's encodeSlice (real arithmetic coder): slice-data bits as written
+    os.environ["FHREF_SAO"] = "1"            # ... and the reference's own SAOProcess after the deblocking pass (its syntax is in the written bits)
     from oracle import oracle_py as op
     ref, hook, oracle = op.bind_rdo(op.load_ref()), op.bind_rdo(op.load_ref(hook=True)), op.load_oracle()
     ws = op.weights_from_arrays(weights.load(blob))
@@ -53,7 +54,7 @@ def work(job):
     out = {}
     for qp in QPS:
         _, sa = op.rdo_encode(ref, buf, org, stride, W, H, 8, qp, chroma=(u, u))
-        out[("anchor", qp)] = (sa["coded_bits"], sa["psnr_y"], sa["seconds"], 1.0, sa.get("psnr_y_deblocked", sa["psnr_y"]), sa.get("slice_data_bits", sa["coded_bits"]))
+        out[("anchor", qp)] = (sa["coded_bits"], sa["psnr_y"], sa["seconds"], 1.0, sa.get("psnr_y_deblocked", sa["psnr_y"]), sa.get("slice_data_bits", sa["coded_bits"]), sa.get("psnr_y_filtered", sa.get("psnr_y_deblocked", sa["psnr_y"])))
         pred = np.zeros(n * 256, np.uint8)
         logits = np.zeros(n * 42, np.int32)
         oracle.fho_predict_frame(ws, op.ptr(buf.reshape(-1), org), stride, W, H, 8, qp, pred, C.c_void_p(logits.ctypes.data))
@@ -63,10 +64,10 @@ def work(job):
                 vw, vh = min(64, W - (c % cw) * 64), min(64, H - (c // cw) * 64)
                 oracle.fho_depth_range_from_logits_levels(np.ascontiguousarray(logits[c * 42:(c + 1) * 42]), vw, vh, ms, mt, dmin[c], dmax[c])
             _, sv = op.rdo_encode(hook, buf, org, stride, W, H, 8, qp, forced_depth=dmin, forced_depth_max=dmax, chroma=(u, u))
-            out[(name, qp)] = (sv["coded_bits"], sv["psnr_y"], sv["seconds"], float((dmin != dmax).mean()), sv.get("psnr_y_deblocked", sv["psnr_y"]), sv.get("slice_data_bits", sv["coded_bits"]))
+            out[(name, qp)] = (sv["coded_bits"], sv["psnr_y"], sv["seconds"], float((dmin != dmax).mean()), sv.get("psnr_y_deblocked", sv["psnr_y"]), sv.get("slice_data_bits", sv["coded_bits"]), sv.get("psnr_y_filtered", sv.get("psnr_y_deblocked", sv["psnr_y"])))
         for c in range(4):  # trivial floors
             _, sc = op.rdo_encode(hook, buf, org, stride, W, H, 8, qp, forced_depth=np.full((n, 256), c, np.uint8), chroma=(u, u))
-            out[(f"const{c}", qp)] = (sc["coded_bits"], sc["psnr_y"], sc["seconds"], 0.0, sc.get("psnr_y_deblocked", sc["psnr_y"]), sc.get("slice_data_bits", sc["coded_bits"]))
+            out[(f"const{c}", qp)] = (sc["coded_bits"], sc["psnr_y"], sc["seconds"], 0.0, sc.get("psnr_y_deblocked", sc["psnr_y"]), sc.get("slice_data_bits", sc["coded_bits"]), sc.get("psnr_y_filtered", sc.get("psnr_y_deblocked", sc["psnr_y"])))
     return family, k, out
 
 
@@ -101,7 +102,8 @@ def main():
             return [(sum(res[(f, k)][(v, qp)][0] for k in range(args.pictures)), float(np.mean([res[(f, k)][(v, qp)][1] for k in range(args.pictures)])),
                      sum(res[(f, k)][(v, qp)][2] for k in range(args.pictures)), float(np.mean([res[(f, k)][(v, qp)][3] for k in range(args.pictures)])),
                      float(np.mean([res[(f, k)][(v, qp)][4] for k in range(args.pictures)])),
-                     sum(res[(f, k)][(v, qp)][5] for k in range(args.pictures))) for qp in QPS]
+                     sum(res[(f, k)][(v, qp)][5] for k in range(args.pictures)),
+                     float(np.mean([res[(f, k)][(v, qp)][6] for k in range(args.pictures)]))) for qp in QPS]
         a = curve("anchor")
         fam = {"anchor": a}
         for v in variants:
@@ -110,6 +112,8 @@ def main():
                       "bd_rate_percent_after_deblocking": bd_rate([p[0] for p in a], [p[4] for p in a], [p[0] for p in c], [p[4] for p in c]),
                       # rate = slice data written by the reference's encodeSlice, distortion = PSNR after its deblocking filter
                       "bd_rate_percent_true_rate_after_deblocking": bd_rate([p[5] for p in a], [p[4] for p in a], [p[5] for p in c], [p[4] for p in c]),
+                      # rate = slice data as written (incl. the SAO syntax), distortion = PSNR after BOTH in-loop filters (deblocking + the reference's own SAO)
+                      "bd_rate_percent_written_bits_after_both_filters": bd_rate([p[5] for p in a], [p[6] for p in a], [p[5] for p in c], [p[6] for p in c]),
                       "time_ratio": sum(p[2] for p in a) / sum(p[2] for p in c), "units_left_to_rdo": float(np.mean([p[3] for p in c]))}
         # per picture spread of the first variant pair, to show how much one picture moves the figure
         fam["per_picture_bd_rate"] = {v: [bd_rate([res[(f, k)][("anchor", qp)][0] for qp in QPS], [res[(f, k)][("anchor", qp)][1] for qp in QPS],

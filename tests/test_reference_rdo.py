@@ -81,6 +81,33 @@ def test_hook_with_own_depth_map_reproduces_full_rdo():
 
 
 @need_ref
+@pytest.mark.parametrize("sao", [False, True])
+def test_own_depth_map_gives_a_byte_identical_slice(sao, monkeypatch):
+    """SURVEY F11 / section 7.1 step 3 at the BYTE level: the slice data the reference's own TEncSlice::encodeSlice writes (real CABAC,
+    TEncSlice.cpp:985) -- md5 over the bytes -- is the same whether the picture went through stock full RDO or through the hm_patch hook
+    fed with HM's own depth map; with SAO on, the reference's own SAOProcess (after its own deblocking pass) decides the same parameters
+    on the same reconstruction, so the SAO syntax inside the slice data is identical too.  A different map changes the md5."""
+    monkeypatch.setenv("FHREF_ENCODE_SLICE", "1")
+    monkeypatch.setenv("FHREF_DEBLOCK", "1")
+    monkeypatch.setenv("FHREF_SAO", "1" if sao else "0")
+    buf, org, stride = _crop()
+    hook = op.bind_rdo(op.load_ref(hook=True))
+    fx = np.load(FIX)
+    ch = _crop_chroma()
+    _, s_stock = op.rdo_encode(hook, buf, org, stride, 768, 512, 8, 32, chroma=ch)
+    _, s_forced = op.rdo_encode(hook, buf, org, stride, 768, 512, 8, 32, forced_depth=fx["depth"], chroma=ch)
+    assert len(s_stock["slice_data_md5"]) == 32 and s_forced["slice_data_md5"] == s_stock["slice_data_md5"]
+    assert s_forced["slice_data_bits"] == s_stock["slice_data_bits"] and s_forced["slice_data_bits"] % 8 == 0
+    assert abs(s_stock["slice_data_bits"] / s_stock["coded_bits"] - 1.0) < 0.01   # the counted bits are the written ones (+ SAO syntax, alignment)
+    if sao:
+        assert s_forced["psnr_y_filtered"] == s_stock["psnr_y_filtered"] and s_stock["psnr_y_filtered"] >= s_stock["psnr_y_deblocked"] - 0.01
+    else:
+        assert "psnr_y_filtered" not in s_stock
+    _, s_other = op.rdo_encode(hook, buf, org, stride, 768, 512, 8, 32, forced_depth=np.full_like(fx["depth"], 2), chroma=ch)
+    assert s_other["slice_data_md5"] != s_stock["slice_data_md5"]
+
+
+@need_ref
 def test_soft_hook_ranges():
     """Soft hook (depth_min/depth_max per unit): the free range [0, 3] is stock full RDO; a range that contains HM's own
     depth everywhere gives HM's own result while searching less; a range that excludes it cannot beat it."""
