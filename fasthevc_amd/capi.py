@@ -25,7 +25,7 @@ SYMBOLS = [
     "fhevc_expand_depth_flags_device", "fhevc_aq_parts", "fhevc_preanalyze", "fhevc_preanalyze_frames_device", "fhevc_aq_qp", "fhevc_intra_first_pass_device",
     "fhevc_predict_frame_range", "fhevc_predict_frames_device_range",
     "fhevc_motion_search", "fhevc_motion_search_device", "fhevc_intra_first_pass_all", "fhevc_p_rule_default", "fhevc_p_depth_range",
-    "fhevc_predict_frames", "fhevc_alloc_host", "fhevc_free_host", "fhevc_set_cnn_arith", "fhevc_get_cnn_arith", "fhevc_set_motion_distortion",
+    "fhevc_predict_frames", "fhevc_alloc_host", "fhevc_free_host", "fhevc_set_cnn_arith", "fhevc_get_cnn_arith", "fhevc_set_motion_distortion", "fhevc_read_yuv_luma",
 ]
 CNN_ARITH = {"i8": 8, "f16": 16}
 
@@ -120,6 +120,8 @@ def load_library(path=None):
                                                    C.c_int, vp, vp]
     lib.fhevc_set_cnn_arith.argtypes = [vp, C.c_int]
     lib.fhevc_set_motion_distortion.argtypes = [vp, C.c_int]
+    lib.fhevc_read_yuv_luma.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp,
+                                        C.c_longlong, C.c_longlong]
     lib.fhevc_get_cnn_arith.argtypes = [vp]
     lib.fhevc_motion_search.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]
     lib.fhevc_motion_search_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
@@ -140,6 +142,20 @@ def load_library(path=None):
     if path is None:
         _lib = lib
     return lib
+
+
+def read_yuv_luma(path, file_size, file_bit_depth, out, first=0, internal_bit_depth=None, chroma_format=420):
+    """The library's own luma reader (fhevc_read_yuv_luma, host C++): fills out [count, H, W] (uint8, or int16 Pel) -- e.g. pinned memory
+    from Context.alloc_host -- with the luma planes of pictures first.. of a planar YUV file, padded by edge replication to out's
+    H x W and shifted to the internal bit depth.  -> number of pictures read."""
+    fw, fh = file_size
+    count, H, W = out.shape
+    assert out.dtype in (np.uint8, np.int16) and out.flags["C_CONTIGUOUS"]
+    n = load_library().fhevc_read_yuv_luma(os.fsencode(path), fw, fh, file_bit_depth, chroma_format, first, count, W, H,
+                                           internal_bit_depth or file_bit_depth, out.dtype.itemsize, out.ctypes.data, W, W * H)
+    if n < 0:
+        raise FastHevcError(n, "fhevc_read_yuv_luma")
+    return n
 
 
 def p_rule_default():

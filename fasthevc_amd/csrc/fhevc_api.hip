@@ -669,6 +669,69 @@ int fhevc_predict_frame(fhevc_ctx* c, const int16_t* luma, int stride_samples, i
   return rc;
 }
 
+int fhevc_read_yuv_luma(const char* path, int file_width, int file_height, int file_bit_depth, int chroma_format, long long first_frame,
+                        int num_frames, int dst_width, int dst_height, int internal_bit_depth, int dst_sample_bytes, void* dst,
+                        long long dst_stride_samples, long long dst_frame_stride_samples)
+{
+  if (!path || !dst || file_width < 1 || file_height < 1 || num_frames < 0 || first_frame < 0) return FHEVC_E_INVALID;
+  if (file_bit_depth < 8 || file_bit_depth > 16 || internal_bit_depth < file_bit_depth || internal_bit_depth > 12) return FHEVC_E_INVALID;
+  if (dst_width < file_width || dst_height < file_height || dst_stride_samples < dst_width) return FHEVC_E_INVALID;
+  if (dst_sample_bytes != 1 && dst_sample_bytes != 2) return FHEVC_E_INVALID;
+  if (dst_sample_bytes == 1 && (file_bit_depth != 8 || internal_bit_depth != 8)) return FHEVC_E_INVALID;
+  if (num_frames > 1 && dst_frame_stride_samples < dst_stride_samples * (dst_height - 1) + dst_width) return FHEVC_E_INVALID;
+  const long long bps = file_bit_depth > 8 ? 2 : 1;
+  long long chroma_samples;  // both chroma planes of the FILE's format
+  const long long cw = (file_width + 1) / 2, chh = (file_height + 1) / 2;
+  switch (chroma_format) {
+    case 400: chroma_samples = 0; break;
+    case 420: chroma_samples = 2 * cw * chh; break;
+    case 422: chroma_samples = 2 * cw * file_height; break;
+    case 444: chroma_samples = 2LL * file_width * file_height; break;
+    default: return FHEVC_E_INVALID;
+  }
+  const long long luma_bytes = (long long)file_width * file_height * bps, frame_bytes = luma_bytes + chroma_samples * bps;
+  FILE* fp = std::fopen(path, "rb");
+  if (!fp) return FHEVC_E_STATE;
+  const int shift = internal_bit_depth - file_bit_depth;
+  std::vector<uint8_t> row8;
+  int done = 0;
+  for (; done < num_frames; ++done) {
+    if (fseeko(fp, (off_t)((first_frame + done) * frame_bytes), SEEK_SET) != 0) break;
+    bool ok = true;
+    if (dst_sample_bytes == 1) {
+      uint8_t* plane = static_cast<uint8_t*>(dst) + (size_t)done * (size_t)dst_frame_stride_samples;
+      if (dst_width == file_width && dst_stride_samples == file_width) ok = std::fread(plane, 1, (size_t)luma_bytes, fp) == (size_t)luma_bytes;  // one read, file -> destination
+      else
+        for (int y = 0; y < file_height && ok; ++y) ok = std::fread(plane + (size_t)y * dst_stride_samples, 1, (size_t)file_width, fp) == (size_t)file_width;
+      if (!ok) break;
+      for (int y = 0; y < file_height; ++y) {
+        uint8_t* r = plane + (size_t)y * dst_stride_samples;
+        for (int x = file_width; x < dst_width; ++x) r[x] = r[file_width - 1];
+      }
+      for (int y = file_height; y < dst_height; ++y) std::memcpy(plane + (size_t)y * dst_stride_samples, plane + (size_t)(file_height - 1) * dst_stride_samples, (size_t)dst_width);
+    } else {
+      int16_t* plane = static_cast<int16_t*>(dst) + (size_t)done * (size_t)dst_frame_stride_samples;
+      if (bps == 1) row8.resize((size_t)file_width);
+      for (int y = 0; y < file_height && ok; ++y) {
+        int16_t* r = plane + (size_t)y * dst_stride_samples;
+        if (bps == 2) {  // two little-endian bytes per sample: the host is little-endian (x86-64), read them in place
+          ok = std::fread(r, 2, (size_t)file_width, fp) == (size_t)file_width;
+          if (shift) for (int x = 0; x < file_width; ++x) r[x] = (int16_t)(r[x] << shift);
+        } else {
+          ok = std::fread(row8.data(), 1, (size_t)file_width, fp) == (size_t)file_width;
+          for (int x = 0; x < file_width; ++x) r[x] = (int16_t)((int)row8[(size_t)x] << shift);
+        }
+        for (int x = file_width; x < dst_width; ++x) r[x] = r[file_width - 1];
+      }
+      if (!ok) break;
+      for (int y = file_height; y < dst_height; ++y) std::memcpy(plane + (size_t)y * dst_stride_samples, plane + (size_t)(file_height - 1) * dst_stride_samples, (size_t)dst_width * 2);
+    }
+  }
+  std::fclose(fp);
+  if (done == 0 && num_frames > 0) return FHEVC_E_STATE;
+  return done;
+}
+
 void* fhevc_alloc_host(fhevc_ctx* c, size_t bytes)
 {
   if (!c || bytes == 0) return nullptr;

@@ -104,6 +104,18 @@ int  fhevc_predict_frame(fhevc_ctx* ctx, const int16_t* luma, int stride_samples
 int  fhevc_predict_frames(fhevc_ctx* ctx, const void* luma, int sample_bytes, int stride_samples, long long frame_stride_samples,
                           int num_frames, int qp, uint8_t* depth_map /* num_frames * numCtus * 256 */,
                           int32_t* ctu_src_hadamard /* num_frames * numCtus, or NULL */);
+/* Library-side luma reader, host code only -- no device work, callable without a context: the luma planes of
+ * `num_frames` pictures of a planar YUV file, from picture `first_frame` on, straight into `dst` (fhevc_alloc_host memory: no intermediate
+ * copy between the file and the DMA source of fhevc_predict_frames).  What TVideoIOYuv::read does for COMPONENT_Y (TVideoIOYuv.cpp:249-330,
+ * 675-760): one byte per sample for file_bit_depth 8, two little-endian bytes above; chroma (chroma_format 400 / 420 / 422 / 444) is skipped
+ * with a seek, never read; the plane is padded on the right and at the bottom by edge replication from file_width x file_height to
+ * dst_width x dst_height (the conformance size: ConformanceWindowMode 1 pads to a multiple of the minimum CU size 8, TAppEncCfg.cpp:1310-1370),
+ * and left-shifted from the file's to the internal bit depth (scalePlane, TVideoIOYuv.cpp:70-84, :730; internal < file is not supported).
+ * dst_sample_bytes 2: int16 Pel samples; 1: uint8 samples (8-bit file at 8-bit internal depth only).  Returns the number of pictures read
+ * (fewer than asked for at the end of the file), or FHEVC_E_INVALID / FHEVC_E_STATE (file cannot be opened / is shorter than one picture). */
+int  fhevc_read_yuv_luma(const char* path, int file_width, int file_height, int file_bit_depth, int chroma_format, long long first_frame,
+                         int num_frames, int dst_width, int dst_height, int internal_bit_depth, int dst_sample_bytes, void* dst,
+                         long long dst_stride_samples, long long dst_frame_stride_samples);
 /* pinned host memory for the batch entry point (a .yuv reader can read luma planes straight into it) */
 void* fhevc_alloc_host(fhevc_ctx* ctx, size_t bytes);
 void  fhevc_free_host(fhevc_ctx* ctx, void* p);

@@ -62,3 +62,52 @@ def test_host_batch_of_hm_pel_planes_10bit(oracle):
         ed, eh = _oracle(oracle, w, lumas[f], bd=bd, qp=27)
         assert np.array_equal(depth[f], ed) and np.array_equal(had[f], eh), f
     ctx.close()
+
+
+def test_padded_10bit_file_through_the_librarys_reader(oracle, tmp_path):
+    """N2 in C++: a 10-bit 4:2:0 file whose size (410 x 236) is not a multiple of the minimum CU -> fhevc_read_yuv_luma pads it to the
+    conformance size 416 x 240 and writes int16 Pel planes straight into fhevc_alloc_host memory -> fhevc_predict_frames (DMA from that
+    memory) -> depth maps and source Hadamards in host memory == the CPU oracle on planes read by the Python restatement of
+    TVideoIOYuv::read.  Also an 8-bit file read as uint8 planes (the half-traffic layout) the same way."""
+    rng = np.random.default_rng(11)
+    w = weights.random_weights(8)
+    fw, fh, NF = 410, 236, 5
+    W, H = 416, 240
+    blob = b""
+    for f in range(NF):
+        y = (frames.texture16_luma(fw, fh, seed=700 + f).astype(np.uint16) << 2) | rng.integers(0, 4, size=(fh, fw)).astype(np.uint16)
+        blob += y.astype("<u2").tobytes() + np.full((fw // 2) * (fh // 2) * 2, 512, "<u2").tobytes()
+    p10 = tmp_path / "clip10.yuv"
+    p10.write_bytes(blob)
+    rd = YuvLumaReader(str(p10), fw, fh, file_bit_depth=10)
+    ctx = capi.Context(W, H, 10, w, max_frames=2)
+    pinned = ctx.alloc_host((NF, H, W), np.int16)
+    assert capi.read_yuv_luma(str(p10), (fw, fh), 10, pinned) == NF
+    d, hd = ctx.predict_frames(pinned, qp=27, origin=0, stride=W, frame_stride=W * H)
+    for f in range(NF):
+        pel = rd.luma(f)   # padded int16 plane, 10 bit
+        assert np.array_equal(pinned[f], pel)
+        buf, org, stride = frames.to_pel_plane(np.zeros((H, W), np.uint8), 8)
+        buf = buf.copy(); buf.reshape(-1)[:] = 0
+        view = buf[frames.HM_MARGIN:frames.HM_MARGIN + H, frames.HM_MARGIN:frames.HM_MARGIN + W]
+        view[:] = pel
+        n = ctx.num_ctus
+        ed, eh = np.zeros(n * 256, np.uint8), np.zeros(n, np.int32)
+        oracle.fho_predict_frame(op.weights_from_arrays(w), op.ptr(buf.reshape(-1), org), stride, W, H, 10, 27, ed, None)
+        oracle.fho_frame_src_hadamard(op.ptr(buf.reshape(-1), org), stride, W, H, eh)
+        assert np.array_equal(d[f], ed.reshape(n, 256)) and np.array_equal(hd[f], eh), f
+    ctx.free_host(pinned)
+    ctx.close()
+    # 8-bit file, uint8 planes, padded as well
+    p8 = tmp_path / "clip8.yuv"
+    p8.write_bytes(b"".join(frames.texture16_luma(fw, fh, seed=800 + f).tobytes() + bytes([128]) * ((fw // 2) * (fh // 2) * 2) for f in range(3)))
+    rd8 = YuvLumaReader(str(p8), fw, fh)
+    ctx = capi.Context(W, H, 8, w, max_frames=2)
+    pin8 = ctx.alloc_host((3, H, W), np.uint8)
+    assert capi.read_yuv_luma(str(p8), (fw, fh), 8, pin8) == 3
+    d8, h8 = ctx.predict_frames(pin8, qp=32)
+    for f in range(3):
+        ed, eh = _oracle(oracle, w, rd8.luma(f), qp=32)
+        assert np.array_equal(d8[f], ed) and np.array_equal(h8[f], eh), f
+    ctx.free_host(pin8)
+    ctx.close()

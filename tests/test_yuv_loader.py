@@ -33,3 +33,37 @@ def test_edge_replication_padding_and_16bit_files(tmp_path):
     assert np.array_equal(out[:h, :w], y.astype(np.int16))
     assert np.array_equal(out[:h, w:], np.repeat(y[:, -1:].astype(np.int16), 4, axis=1))
     assert np.array_equal(out[h:, :], np.repeat(out[h - 1:h, :], 4, axis=0))
+
+
+@pytest.mark.parametrize("w,h,fbd,ibd,chroma", [(416, 240, 8, 8, 420), (420, 236, 10, 10, 420), (410, 234, 8, 10, 420), (100, 70, 8, 8, 400),
+                                                 (422, 238, 12, 12, 444), (64, 64, 8, 8, 422)])
+def test_the_librarys_cpp_reader_equals_the_python_one(tmp_path, w, h, fbd, ibd, chroma):
+    """fhevc_read_yuv_luma (host C++ inside the HIP library; no device needed) against YuvLumaReader, which restates TVideoIOYuv::read for the
+    luma plane: 8- and 16-bit files, edge-replication padding to the conformance size, InputBitDepth -> InternalBitDepth shift, chroma of every
+    format skipped, several pictures from the middle of a file, short reads at the end of the file."""
+    from fasthevc_amd import capi
+    rng = np.random.default_rng(w + h)
+    nf = 4
+    cs = {400: 0, 420: ((w + 1) // 2) * ((h + 1) // 2) * 2, 422: ((w + 1) // 2) * h * 2, 444: w * h * 2}[chroma]
+    dt = "<u2" if fbd > 8 else np.uint8
+    blob = b""
+    for f in range(nf):
+        blob += rng.integers(0, 1 << fbd, size=(h, w)).astype(dt).tobytes() + rng.integers(0, 1 << fbd, size=cs).astype(dt).tobytes()
+    p = tmp_path / "clip.yuv"
+    p.write_bytes(blob)
+    r = YuvLumaReader(str(p), w, h, file_bit_depth=fbd, chroma_format=str(chroma)) if (w % 2 == 0 and h % 2 == 0) else None
+    pw, ph = -(-w // 8) * 8, -(-h // 8) * 8
+    as_u8 = fbd == 8 and ibd == 8
+    out = np.zeros((3, ph, pw), np.uint8 if as_u8 else np.int16)
+    assert capi.read_yuv_luma(str(p), (w, h), fbd, out, first=1, internal_bit_depth=ibd, chroma_format=chroma) == 3
+    for k in range(3):
+        exp = r.luma(1 + k, internal_bit_depth=ibd)
+        assert exp.dtype == out.dtype and np.array_equal(out[k], exp), (k,)
+    # the end of the file: two pictures asked for from the last one on -> one read; beyond the end -> an error status
+    tail = np.zeros((2, ph, pw), out.dtype)
+    assert capi.read_yuv_luma(str(p), (w, h), fbd, tail, first=nf - 1, internal_bit_depth=ibd, chroma_format=chroma) == 1
+    assert np.array_equal(tail[0], r.luma(nf - 1, internal_bit_depth=ibd))
+    with pytest.raises(capi.FastHevcError):
+        capi.read_yuv_luma(str(p), (w, h), fbd, tail, first=nf, internal_bit_depth=ibd, chroma_format=chroma)
+    with pytest.raises(capi.FastHevcError):
+        capi.read_yuv_luma(str(tmp_path / "missing.yuv"), (w, h), fbd, tail, internal_bit_depth=ibd, chroma_format=chroma)
