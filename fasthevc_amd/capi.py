@@ -225,7 +225,7 @@ class Context:
         self.close()
 
     def set_weights(self, w):
-        blob = w if isinstance(w, (bytes, bytearray)) else _weights.pack(w)
+        blob = w if isinstance(w, (bytes, bytearray)) else (_weights.pack_family(w) if "widths" in w else _weights.pack(w))
         self._check(self.lib.fhevc_set_weights(self.h, bytes(blob), len(blob)))
 
     def predict_frame(self, plane, origin=0, stride=None, qp=32, slice_type=2, want_hadamard=True):

@@ -30,6 +30,11 @@ struct fhevc_ctx {
   bool have_weights = false;
   uint4* d_frag = nullptr; float* d_bias = nullptr; uint8_t* d_whead = nullptr; int32_t* d_bhead = nullptr;
   uint4* d_frag_i8 = nullptr; int32_t* d_bias_i8 = nullptr;  // the i8 variant of conv2 / conv3 (k_cnn.hip)
+  // a member of the reference's Bayesian-optimisation network family (FHW3 blob; k_cnn_family.inc): set instead of the arrays above
+  bool family = false;
+  int fam_c[3] = { 0, 0, 0 };
+  uint4* f_frag1 = nullptr; float* f_bias1 = nullptr; uint4* f_frag2 = nullptr; uint4* f_frag3 = nullptr; int32_t* f_bias_i8 = nullptr;
+  uint8_t* f_whead = nullptr; int32_t* f_bhead = nullptr;
   int shift[3] = { 0, 0, 0 };
   int requant_mode[3] = { 0, 0, 0 };
   bool cnn_i8 = true;                                         // fhevc_set_cnn_arith / FHEVC_CNN_ARITH at fhevc_create
@@ -294,6 +299,138 @@ int build_weight_image(fhevc_ctx* c, const BlobView& b)
   return FHEVC_OK;
 }
 
+// FHW3: a member of the reference's Bayesian-optimisation network family (fasthevc_amd/weights.py: family_fields); this round the
+// kernel runs the members with one convolution per block whose widths it is instantiated for (fhevc_cnn_family_supported)
+int build_family_image(fhevc_ctx* c, const uint8_t* blob, size_t bytes)
+{
+  if (bytes < 24) return fail(c, FHEVC_E_WEIGHTS, "FHW3 blob too short");
+  uint32_t ver;
+  int32_t hdr[4];
+  std::memcpy(&ver, blob + 4, 4);
+  std::memcpy(hdr, blob + 8, 16);
+  const int C1 = hdr[0], C2 = hdr[1], C3 = hdr[2], depth = hdr[3];
+  if (ver != 1) return fail(c, FHEVC_E_WEIGHTS, "unsupported FHW3 version");
+  if (depth != 1 || !fhevc_cnn_family_supported(C1, C2, C3))
+    return fail(c, FHEVC_E_WEIGHTS, "this build runs the family members 32/64/128 x 1 (and 16/32/64 x 1); deeper members are oracle-only so far");
+  const size_t need = 24 + 36 + (size_t)C1 * 9 + 4 * (size_t)C1 + (size_t)C2 * C1 * 9 + 4 * (size_t)C2 + (size_t)C3 * C2 * 9 + 4 * (size_t)C3 +
+                      (size_t)(2 * 64 + 2 * 64 + 2 * 16) * C3 + 24 + 3 * 52 * 4;
+  if (bytes != need) return fail(c, FHEVC_E_WEIGHTS, "FHW3 blob has the wrong size");
+  size_t off = 24;
+  auto take = [&](size_t n) { const uint8_t* q = blob + off; off += n; return q; };
+  int32_t shift33[9];
+  std::memcpy(shift33, take(36), 36);
+  const int sh[3] = { shift33[0], shift33[3], shift33[6] };
+  for (int l = 0; l < 3; ++l) if (sh[l] < 0 || sh[l] > 14) return fail(c, FHEVC_E_WEIGHTS, "shift out of range (0..14)");
+  const int8_t* w1 = reinterpret_cast<const int8_t*>(take((size_t)C1 * 9));
+  const uint8_t* b1p = take(4 * (size_t)C1);
+  const int8_t* w2 = reinterpret_cast<const int8_t*>(take((size_t)C2 * C1 * 9));
+  const uint8_t* b2p = take(4 * (size_t)C2);
+  const int8_t* w3 = reinterpret_cast<const int8_t*>(take((size_t)C3 * C2 * 9));
+  const uint8_t* b3p = take(4 * (size_t)C3);
+  const int8_t* wh64 = reinterpret_cast<const int8_t*>(take((size_t)2 * 64 * C3));
+  const uint8_t* bh64p = take(8);
+  const int8_t* wh32 = reinterpret_cast<const int8_t*>(take((size_t)2 * 64 * C3));
+  const uint8_t* bh32p = take(8);
+  const int8_t* wh16 = reinterpret_cast<const int8_t*>(take((size_t)2 * 16 * C3));
+  const uint8_t* bh16p = take(8);
+  const uint8_t* qpb = take(3 * 52 * 4);
+  auto i32at = [](const uint8_t* p, int i) { int32_t v; std::memcpy(&v, p + 4 * (size_t)i, 4); return v; };
+  for (const int8_t* p = w1; p < reinterpret_cast<const int8_t*>(bh16p); ++p) (void)p;
+  const int G1 = C1 / 16, K1 = (C1 + 31) / 32, M2 = C2 / 32, K2 = C2 / 32, M3 = C3 / 32;
+  // conv1: per group of 16 filters the two fragments of the base network (rows = filter x 2x2 pre-pool position, K = 4x4 window)
+  std::vector<uint16_t> frag1((size_t)G1 * 2 * 64 * 8, 0);
+  std::vector<float> bias1((size_t)C1);
+  for (int g = 0; g < G1; ++g)
+    for (int lane = 0; lane < 64; ++lane) {
+      const int r = lane & 31, h = lane >> 5;
+      for (int j = 0; j < 8; ++j)
+        for (int jm = 0; jm < 2; ++jm) {
+          const int ch = 16 * g + (r & 3) + 4 * ((r >> 3) & 1) + 8 * ((r >> 2) & 1), py = (r >> 4) & 1, px = jm;
+          const int wc = 2 * h + ((j >> 1) & 1), wr = 2 * (j >> 2) + (j & 1);
+          const int ky = wr - py, kx = wc - px;
+          if (ky >= 0 && ky <= 2 && kx >= 0 && kx <= 2) {
+            if (w1[ch * 9 + ky * 3 + kx] == -128) return fail(c, FHEVC_E_WEIGHTS, "weight -128 not allowed");
+            const float f = std::ldexp((float)w1[ch * 9 + ky * 3 + kx], -sh[0]);
+            uint32_t u;
+            std::memcpy(&u, &f, 4);
+            frag1[(((size_t)(2 * g + jm) * 64) + lane) * 8 + j] = (uint16_t)(u >> 16);
+          }
+        }
+    }
+  for (int i = 0; i < C1; ++i) {
+    int sw = 0;
+    for (int t = 0; t < 9; ++t) sw += w1[i * 9 + t];
+    if (std::abs(i32at(b1p, i)) > 4194304) return fail(c, FHEVC_E_WEIGHTS, "|bias| > 2^22");
+    bias1[(size_t)i] = std::ldexp((float)(i32at(b1p, i) - 128 * sw), -sh[0]);
+  }
+  // conv2 / conv3: fragment (M tile, K chunk, tap): row = output channel 32 mt + (lane & 31), byte j of lane half h = input channel 32 k + 16 h + j
+  auto build = [&](const int8_t* w, int CI, int M, int K, std::vector<int8_t>& frag) {
+    frag.assign((size_t)M * K * 9 * 64 * 16, 0);
+    for (int mt = 0; mt < M; ++mt)
+      for (int k = 0; k < K; ++k)
+        for (int tap = 0; tap < 9; ++tap)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 16; ++j) {
+              const int oc = 32 * mt + (lane & 31), ic = 32 * k + 16 * (lane >> 5) + j;
+              if (ic < CI) frag[((((size_t)mt * K + k) * 9 + tap) * 64 + lane) * 16 + j] = w[((size_t)oc * CI + ic) * 9 + tap];
+            }
+  };
+  std::vector<int8_t> frag2, frag3;
+  build(w2, C1, M2, K1, frag2);
+  build(w3, C2, M3, K2, frag3);
+  std::vector<int32_t> bias8((size_t)C2 + C3);
+  for (int oc = 0; oc < C2; ++oc) {
+    int sw = 0;
+    for (int i = 0; i < C1 * 9; ++i) sw += w2[(size_t)oc * C1 * 9 + i];
+    bias8[(size_t)oc] = i32at(b2p, oc) + 128 * sw;
+  }
+  for (int oc = 0; oc < C3; ++oc) {
+    int sw = 0;
+    for (int i = 0; i < C2 * 9; ++i) sw += w3[(size_t)oc * C2 * 9 + i];
+    bias8[(size_t)C2 + oc] = i32at(b3p, oc) + 128 * sw;
+  }
+  std::vector<uint8_t> whead((size_t)(2 * 64 + 2 * 64 + 2 * 16) * C3);
+  std::memcpy(whead.data(), wh64, (size_t)2 * 64 * C3);
+  std::memcpy(whead.data() + (size_t)2 * 64 * C3, wh32, (size_t)2 * 64 * C3);
+  std::memcpy(whead.data() + (size_t)4 * 64 * C3, wh16, (size_t)2 * 16 * C3);
+  int32_t bhead[6 + 3 * 52] = { i32at(bh64p, 0), i32at(bh64p, 1), i32at(bh32p, 0), i32at(bh32p, 1), i32at(bh16p, 0), i32at(bh16p, 1) };
+  for (int cls = 0; cls < 2; ++cls) {
+    int s64 = 0, s32 = 0, s16 = 0;
+    for (int i = 0; i < 64 * C3; ++i) { s64 += wh64[(size_t)cls * 64 * C3 + i]; s32 += wh32[(size_t)cls * 64 * C3 + i]; }
+    for (int i = 0; i < 16 * C3; ++i) s16 += wh16[(size_t)cls * 16 * C3 + i];
+    bhead[0 + cls] += 128 * 4 * s64;   // conv3's map travels as a - 128; the 64-level weights act on four positions each
+    bhead[2 + cls] += 128 * s32;
+    bhead[4 + cls] += 128 * s16;
+  }
+  for (int i = 0; i < 3 * 52; ++i) bhead[6 + i] = i32at(qpb, i);
+  (void)hipFree(c->f_frag1); (void)hipFree(c->f_bias1); (void)hipFree(c->f_frag2); (void)hipFree(c->f_frag3); (void)hipFree(c->f_bias_i8); (void)hipFree(c->f_whead); (void)hipFree(c->f_bhead);
+  c->f_frag1 = nullptr; c->f_bias1 = nullptr; c->f_frag2 = nullptr; c->f_frag3 = nullptr; c->f_bias_i8 = nullptr; c->f_whead = nullptr; c->f_bhead = nullptr;
+  HIP_TRY(c, hipMalloc(&c->f_frag1, frag1.size() * 2)); HIP_TRY(c, hipMalloc(&c->f_bias1, bias1.size() * 4));
+  HIP_TRY(c, hipMalloc(&c->f_frag2, frag2.size())); HIP_TRY(c, hipMalloc(&c->f_frag3, frag3.size()));
+  HIP_TRY(c, hipMalloc(&c->f_bias_i8, bias8.size() * 4)); HIP_TRY(c, hipMalloc(&c->f_whead, whead.size())); HIP_TRY(c, hipMalloc(&c->f_bhead, sizeof bhead));
+  HIP_TRY(c, hipMemcpy(c->f_frag1, frag1.data(), frag1.size() * 2, hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(c->f_bias1, bias1.data(), bias1.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(c->f_frag2, frag2.data(), frag2.size(), hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(c->f_frag3, frag3.data(), frag3.size(), hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(c->f_bias_i8, bias8.data(), bias8.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(c->f_whead, whead.data(), whead.size(), hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(c->f_bhead, bhead, sizeof bhead, hipMemcpyHostToDevice));
+  c->fam_c[0] = C1; c->fam_c[1] = C2; c->fam_c[2] = C3;
+  c->shift[0] = sh[0]; c->shift[1] = sh[1]; c->shift[2] = sh[2];
+  c->family = true;
+  c->have_weights = true;
+  return FHEVC_OK;
+}
+
+FhevcFamilyWeights family_weights(const fhevc_ctx* c)
+{
+  FhevcFamilyWeights w;
+  w.c[0] = c->fam_c[0]; w.c[1] = c->fam_c[1]; w.c[2] = c->fam_c[2];
+  w.frag1 = c->f_frag1; w.bias1 = c->f_bias1; w.frag2 = c->f_frag2; w.frag3 = c->f_frag3; w.bias_i8 = c->f_bias_i8; w.whead = c->f_whead; w.bhead = c->f_bhead;
+  w.shift[0] = c->shift[0]; w.shift[1] = c->shift[1]; w.shift[2] = c->shift[2];
+  return w;
+}
+
 FhevcCnnWeights cnn_weights(const fhevc_ctx* c)
 {
   FhevcCnnWeights w;
@@ -415,7 +552,7 @@ int fhevc_create(fhevc_ctx** out, const fhevc_cfg* cfg)
   if (cfg->weights_path) {
     FILE* fp = std::fopen(cfg->weights_path, "rb");
     if (!fp) { fhevc_destroy(c); return FHEVC_E_WEIGHTS; }
-    std::vector<uint8_t> buf(kBlobBytes + 1);
+    std::vector<uint8_t> buf((size_t)4 << 20);   // FHW1 is 42 KB, the largest family member this build runs (FHW3, 32 / 64 / 128) 133 KB
     const size_t n = std::fread(buf.data(), 1, buf.size(), fp);
     std::fclose(fp);
     const int rc = fhevc_set_weights(c, buf.data(), n);
@@ -451,6 +588,7 @@ void fhevc_destroy(fhevc_ctx* c)
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   (void)hipFree(c->d_frag); (void)hipFree(c->d_bias); (void)hipFree(c->d_whead); (void)hipFree(c->d_bhead);
   (void)hipFree(c->d_frag_i8); (void)hipFree(c->d_bias_i8);
+  (void)hipFree(c->f_frag1); (void)hipFree(c->f_bias1); (void)hipFree(c->f_frag2); (void)hipFree(c->f_frag3); (void)hipFree(c->f_bias_i8); (void)hipFree(c->f_whead); (void)hipFree(c->f_bhead);
   (void)hipFree(c->d_luma); (void)hipFree(c->d_depth); (void)hipFree(c->d_had); (void)hipFree(c->d_nodes); (void)hipFree(c->d_satd); (void)hipFree(c->d_satd_out); (void)hipFree(c->d_act); (void)hipFree(c->d_depth_max); (void)hipFree(c->d_pair); (void)hipFree(c->d_motion);
   for (auto& sl : c->slot) {  // the host-batch ring of fhevc_predict_frames: stream, device buffers, pinned staging
     if (sl.st) { (void)hipStreamSynchronize(sl.st); (void)hipStreamDestroy(sl.st); }
@@ -466,6 +604,15 @@ void fhevc_destroy(fhevc_ctx* c)
 int fhevc_set_weights(fhevc_ctx* c, const void* blob, size_t bytes)
 {
   if (!c || !blob) return FHEVC_E_INVALID;
+  if (bytes >= 4 && std::memcmp(blob, "FHW3", 4) == 0) {  // a member of the reference's Bayesian-optimisation network family
+    for (fhevc_ctx* peer : c->peers) {
+      const int rc = fhevc_set_weights(peer, blob, bytes);
+      if (rc != FHEVC_OK) return fail(c, rc, "weights rejected by a peer device");
+    }
+    (void)hipSetDevice(c->device);
+    return build_family_image(c, static_cast<const uint8_t*>(blob), bytes);
+  }
+  c->family = false;
   BlobView v;
   std::vector<uint8_t> copy;
   if (!parse_blob(static_cast<const uint8_t*>(blob), bytes, v, copy)) return fail(c, FHEVC_E_WEIGHTS, "not an FHW1 blob");
@@ -524,7 +671,7 @@ int fhevc_predict_frames_device_range(fhevc_ctx* c, const void* d_luma, int samp
   const FhevcFrames fr = frames_of(c, d_luma, sample_bytes, stride_samples, frame_stride_samples, num_frames, ctu_row_begin, ctu_row_end, qp);
   // the source Hadamard rides on the depth kernel's own pass over the frame wherever the layout allows the fused form
   // (aligned planes, widths that are multiples of 16, up to 10 bit); otherwise it is its own HBM-bound launch
-  const bool fuse = d_hadamard && c->fuse_hadamard && fhevc_cnn_can_fuse_hadamard(fr);
+  const bool fuse = d_hadamard && c->fuse_hadamard && !c->family && fhevc_cnn_can_fuse_hadamard(fr);
   if (d_hadamard && !fuse) {
     time_begin(c, s, 1);
     HIP_TRY(c, fhevc_launch_src_hadamard(fr, d_hadamard, s));
@@ -532,7 +679,8 @@ int fhevc_predict_frames_device_range(fhevc_ctx* c, const void* d_luma, int samp
     c->stats.kernels_launched++;
   }
   time_begin(c, s, 0);
-  HIP_TRY(c, fhevc_launch_cnn(fr, cnn_weights(c), d_depth_map, fuse ? d_hadamard : nullptr, d_logits, d_flags, d_depth_max, margin_split, margin_stop, c->num_cus, s));
+  if (c->family) HIP_TRY(c, fhevc_launch_cnn_family(fr, family_weights(c), d_depth_map, d_logits, d_flags, d_depth_max, margin_split, margin_stop, c->num_cus, s));
+  else HIP_TRY(c, fhevc_launch_cnn(fr, cnn_weights(c), d_depth_map, fuse ? d_hadamard : nullptr, d_logits, d_flags, d_depth_max, margin_split, margin_stop, c->num_cus, s));
   time_end(c, s);
   c->stats.kernels_launched++;
   c->stats.frames += (uint64_t)num_frames;

@@ -57,6 +57,22 @@ struct FhevcCnnWeights {
   int pipe;                  // 1: the i8 form runs as the two-stage software pipeline over CTUs (fhevc_cnn_depth_pipe_kernel; FHEVC_CNN_PIPE)
 };
 
+// a member of the reference's Bayesian-optimisation network family with one convolution per block (k_cnn_family.inc; FHW3 blob)
+struct FhevcFamilyWeights {
+  int c[3];                  // channel widths (multiples of 16 / 32 / 32)
+  const uint4* frag1;        // conv1: [C1 / 16 groups][2 (pre-pool column)][64 lanes], bf16, scaled by 2^-shift1
+  const float* bias1;        // conv1 biases, pre-scaled, - 128 * sum of weights
+  const uint4* frag2;        // conv2: [M tile][K chunk][tap][64 lanes], 16 signed bytes per lane
+  const uint4* frag3;        // conv3: likewise
+  const int32_t* bias_i8;    // bias2[C2], bias3[C3], + 128 * sum of weights
+  const uint8_t* whead;      // wh64[2][8][8][C3], wh32[2][8][8][C3], wh16[2][4][4][C3]
+  const int32_t* bhead;      // as FhevcCnnWeights::bhead
+  int shift[3];
+};
+hipError_t fhevc_launch_cnn_family(const FhevcFrames& fr, const FhevcFamilyWeights& w, uint8_t* d_depth, int32_t* d_logits, uint32_t* d_flags,
+                                   uint8_t* d_depth_max, int margin_split, int margin_stop, int num_cus, hipStream_t stream);
+bool fhevc_cnn_family_supported(int c1, int c2, int c3);
+
 hipError_t fhevc_cnn_prepare_device();  // LDS opt-in of the depth kernel on the current device (once per context)
 // d_depth_max / margins: soft decisions (nullptr / 0, 0 = the plain map only)
 // d_had != nullptr: the per-CTU source Hadamard is computed inside the depth kernel from the samples it loads anyway (one

@@ -1933,6 +1933,8 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_pipe_kernel(FhevcFrame
 #undef FHEVC_PIPE_CONV1_UNIT
 }
 
+#include "k_cnn_family.inc"
+
 // split-flag words -> depth maps (whole pictures, CTU raster order): one thread per row of 16 units = one 16-byte store,
 // 16 threads per CTU, 16 CTUs per workgroup and sweep (HBM-write-bound: 256 B per CTU)
 __global__ __launch_bounds__(256) void fhevc_expand_flags_kernel(FhevcFrames F, const uint32_t* __restrict__ flags,
@@ -1977,6 +1979,8 @@ hipError_t fhevc_cnn_prepare_device()
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_kernel<false, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, Lds<false>::LDS_BYTES);
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_kernel<false, 1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, Lds<false>::LDS_BYTES);
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_kernel<false, 2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, Lds<false>::LDS_BYTES);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_family_kernel<32, 64, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, LdsFam<32, 64, 128>::LDS_BYTES);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_family_kernel<16, 32, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, LdsFam<16, 32, 64>::LDS_BYTES);
   // (the i8 variant's 51 072 B need no opt-in; its pipelined form's 76 816 B do)
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_pipe_kernel<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LdsPipe::LDS_BYTES);
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_pipe_kernel<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LdsPipe::LDS_BYTES);
@@ -2068,5 +2072,23 @@ hipError_t fhevc_launch_cnn_stamped(const FhevcFrames& fr, const FhevcCnnWeights
     launch_depth_kernel<true, 0, 0>(grid, stream, fr, w, d_depth, nullptr, nullptr, nullptr, d_stamps, nullptr, 0, 0);
   } else if (arith == 1) launch_depth_kernel<true, 0, 1>(grid, stream, fr, w, d_depth, nullptr, nullptr, nullptr, d_stamps, nullptr, 0, 0);
   else launch_depth_kernel<true, 0, 2>(grid, stream, fr, w, d_depth, nullptr, nullptr, nullptr, d_stamps, nullptr, 0, 0);
+  return hipGetLastError();
+}
+
+// ---- the reference's Bayesian-optimisation family, one convolution per block (k_cnn_family.inc) ----
+bool fhevc_cnn_family_supported(int c1, int c2, int c3) { return (c1 == 32 && c2 == 64 && c3 == 128) || (c1 == 16 && c2 == 32 && c3 == 64); }
+
+hipError_t fhevc_launch_cnn_family(const FhevcFrames& fr, const FhevcFamilyWeights& w, uint8_t* d_depth, int32_t* d_logits, uint32_t* d_flags,
+                                   uint8_t* d_depth_max, int margin_split, int margin_stop, int num_cus, hipStream_t stream)
+{
+  const long long total = (long long)(fr.row_end - fr.row_begin) * fr.ctus_x * fr.num_frames;
+  if (total <= 0) return hipSuccess;
+  int grid = 2 * num_cus;
+  if (total < grid) grid = (int)total;
+  if (w.c[0] == 32 && w.c[1] == 64 && w.c[2] == 128)
+    hipLaunchKernelGGL((fhevc_cnn_family_kernel<32, 64, 128>), dim3(grid), dim3(256), (LdsFam<32, 64, 128>::LDS_BYTES), stream, fr, w, d_depth, d_logits, d_flags, d_depth_max, margin_split, margin_stop);
+  else if (w.c[0] == 16 && w.c[1] == 32 && w.c[2] == 64)
+    hipLaunchKernelGGL((fhevc_cnn_family_kernel<16, 32, 64>), dim3(grid), dim3(256), (LdsFam<16, 32, 64>::LDS_BYTES), stream, fr, w, d_depth, d_logits, d_flags, d_depth_max, margin_split, margin_stop);
+  else return hipErrorInvalidValue;
   return hipGetLastError();
 }

@@ -43,18 +43,30 @@ def ste_floor(x):
 
 
 class DepthNetQ(nn.Module):
-    def __init__(self, seed=0):
+    """widths (16, 32, 64), depth 1: the Train...Example.m network (FHW1 blob).  Any other widths / depth: a member of the reference's
+    Bayesian-optimisation family (Optimize...Example.m:103-106, 233-259: `depth` convolutions per block; FHW3 blob)."""
+
+    def __init__(self, seed=0, widths=(16, 32, 64), depth=1, shifts=None):
         super().__init__()
         g = torch.Generator().manual_seed(seed)
-        self.w1 = nn.Parameter(torch.randn(16, 1, 3, 3, generator=g) * 21.0)
-        self.b1 = nn.Parameter(torch.zeros(16))
-        self.w2 = nn.Parameter(torch.randn(32, 16, 3, 3, generator=g) * 9.0)
-        self.b2 = nn.Parameter(torch.zeros(32))
-        self.w3 = nn.Parameter(torch.randn(64, 32, 3, 3, generator=g) * 12.5)
-        self.b3 = nn.Parameter(torch.zeros(64))
-        self.h64 = nn.Parameter(torch.randn(2, 64, 8, 8, generator=g) * 6.0)   # [cls][c][y][x] (exported as [cls][y][x][c])
-        self.h32 = nn.Parameter(torch.randn(2, 64, 8, 8, generator=g) * 8.0)
-        self.h16 = nn.Parameter(torch.randn(2, 64, 4, 4, generator=g) * 8.0)
+        self.widths, self.depth = tuple(widths), depth
+        self.family = self.widths != (16, 32, 64) or depth != 1
+        c3 = self.widths[2]
+        self.convs, self.biases, self.shifts = nn.ParameterList(), nn.ParameterList(), []
+        ci = 1
+        for b in range(3):
+            for j in range(depth):
+                fan = 9 * ci
+                # start at about the scale the base network starts at (21 at fan-in 9, 9 at 144, 12.5 at 288)
+                amp = 21.0 if ci == 1 else 110.0 / np.sqrt(fan) * (1.9 if fan >= 288 else 1.0)
+                self.convs.append(nn.Parameter(torch.randn(self.widths[b], ci, 3, 3, generator=g) * amp))
+                self.biases.append(nn.Parameter(torch.zeros(self.widths[b])))
+                self.shifts.append((6 if ci == 1 else 7 if fan <= 160 else 8) if shifts is None else shifts[len(self.shifts)])
+                ci = self.widths[b]
+        hs = np.sqrt(64.0 / c3)   # FC heads over c3 channels: keep the logits' scale
+        self.h64 = nn.Parameter(torch.randn(2, c3, 8, 8, generator=g) * 6.0 * hs)   # [cls][c][y][x] (exported as [cls][y][x][c])
+        self.h32 = nn.Parameter(torch.randn(2, c3, 8, 8, generator=g) * 8.0 * hs)
+        self.h16 = nn.Parameter(torch.randn(2, c3, 4, 4, generator=g) * 8.0 * hs)
         self.bh64 = nn.Parameter(torch.zeros(2))
         self.bh32 = nn.Parameter(torch.zeros(2))
         self.bh16 = nn.Parameter(torch.zeros(2))
@@ -65,13 +77,16 @@ class DepthNetQ(nn.Module):
         return ste_round(torch.clamp(w, -127, 127))
 
     def trunk(self, x):
-        """x: [B,1,64,64] float holding integers -128..127 -> a3 [B,64,16,16] integers 0..255"""
-        z = Fn.conv2d(x, self.q8(self.w1), ste_round(self.b1), padding=1)
-        a = torch.clamp(ste_floor(Fn.max_pool2d(z, 2) / float(1 << SHIFTS[0])), 0, 255)
-        z = Fn.conv2d(a, self.q8(self.w2), ste_round(self.b2), padding=1)
-        a = torch.clamp(ste_floor(Fn.max_pool2d(z, 2) / float(1 << SHIFTS[1])), 0, 255)
-        z = Fn.conv2d(a, self.q8(self.w3), ste_round(self.b3), padding=1)
-        return torch.clamp(ste_floor(z / float(1 << SHIFTS[2])), 0, 255)
+        """x: [B,1,64,64] float holding integers -128..127 -> a3 [B,c3,16,16] integers 0..255"""
+        k = 0
+        for b in range(3):
+            for j in range(self.depth):
+                z = Fn.conv2d(x, self.q8(self.convs[k]), ste_round(self.biases[k]), padding=1)
+                if j == self.depth - 1 and b < 2:
+                    z = Fn.max_pool2d(z, 2)
+                x = torch.clamp(ste_floor(z / float(1 << self.shifts[k])), 0, 255)
+                k += 1
+        return x
 
     def heads(self, a3):
         """integer logits without the QP prior: l64 [B,2], l32 [B,2,2,2], l16 [B,2,4,4]"""
@@ -84,18 +99,26 @@ class DepthNetQ(nn.Module):
     def export(self):
         r = lambda t: torch.round(t.detach()).to(torch.int64).numpy()
         q = lambda t: np.clip(r(t), -127, 127).astype(np.int8)
-        out = {
-            "shift": np.array(SHIFTS, np.int32),
-            "w1": q(self.w1).reshape(16, 3, 3), "b1": r(self.b1).astype(np.int32),
-            "w2": q(self.w2), "b2": r(self.b2).astype(np.int32),
-            "w3": q(self.w3), "b3": r(self.b3).astype(np.int32),
+        heads = {
             "wh64": q(self.h64).transpose(0, 2, 3, 1).copy(), "bh64": r(self.bh64).astype(np.int32),
             "wh32": q(self.h32).transpose(0, 2, 3, 1).copy(), "bh32": r(self.bh32).astype(np.int32),
             "wh16": q(self.h16).transpose(0, 2, 3, 1).copy(), "bh16": r(self.bh16).astype(np.int32),
             "qp_bias": r(self.qp_bias).astype(np.int32),
         }
-        for k in ("b1", "b2", "b3"):
-            out[k] = np.clip(out[k], -W.BIAS_LIMIT, W.BIAS_LIMIT).astype(np.int32)
+        bias = lambda k: np.clip(r(self.biases[k]), -W.BIAS_LIMIT, W.BIAS_LIMIT).astype(np.int32)
+        if not self.family:
+            out = {"shift": np.array(self.shifts, np.int32), "w1": q(self.convs[0]).reshape(16, 3, 3), "b1": bias(0),
+                   "w2": q(self.convs[1]), "b2": bias(1), "w3": q(self.convs[2]), "b3": bias(2)}
+            out.update(heads)
+            return out
+        out = {"widths": np.array(self.widths, np.int32), "depth": self.depth, "shift": np.zeros((3, 3), np.int32)}
+        k = 0
+        for b in range(3):
+            for j in range(self.depth):
+                out[f"w{b}{j}"], out[f"b{b}{j}"] = q(self.convs[k]), bias(k)
+                out["shift"][b, j] = self.shifts[k]
+                k += 1
+        out.update(heads)
         return out
 
 
@@ -160,6 +183,9 @@ def main():
     ap.add_argument("--threads", type=int, default=8)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--qps", default="", help="comma-separated slice QPs of the label files (default 22,27,32,37; P-picture labels: 28,33,38,43)")
+    ap.add_argument("--depth", type=int, default=0, help="1..3: train the member of the reference's Bayesian-optimisation family with that many convolutions "
+                    "per block (widths round(32 / sqrt(depth)), x2, x4: Optimize...Example.m:233-259) and write an FHW3 blob; 0: the 16 / 32 / 64 network (FHW1)")
+    ap.add_argument("--widths", default="", help="override the family member's widths, e.g. 32,64,128")
     args = ap.parse_args()
     if args.qps:
         global QPS
@@ -168,9 +194,15 @@ def main():
     torch.manual_seed(args.seed)
     (tr_t, tr_d), (va_t, va_d), nfiles = load_data(args.data)
     print(f"{nfiles} pictures: {len(tr_t)} training CTUs, {len(va_t)} validation CTUs, QPs {QPS}", flush=True)
-    model = DepthNetQ(args.seed)
-    conv_w = [model.w1, model.w2, model.w3]
-    conv_b = [model.b1, model.b2, model.b3]
+    if args.depth or args.widths:
+        depth = args.depth or 1
+        widths = tuple(int(v) for v in args.widths.split(",")) if args.widths else W.family_widths(depth)
+        model = DepthNetQ(args.seed, widths, depth)
+        print(f"family member: widths {widths}, {depth} convolution(s) per block, shifts {model.shifts}", flush=True)
+    else:
+        model = DepthNetQ(args.seed)
+    conv_w = list(model.convs)
+    conv_b = list(model.biases)
     head_w = [model.h64, model.h32, model.h16]
     head_b = [model.bh64, model.bh32, model.bh16, model.qp_bias]
     base = [0.4, 15.0, 0.4, 400.0]
@@ -214,7 +246,11 @@ def main():
         msg = " ".join(f"q{qp}: 64 {s[0] / max(s[1], 1):.3f} 32 {s[2] / max(s[3], 1):.3f} 16 {s[4] / max(s[5], 1):.3f}" for qp, s in stats.items())
         print(f"epoch {ep}: val loss {vl / len(va_t):.4f} acc {msg} ({time.time() - t0:.0f} s)", flush=True)
         os.makedirs(os.path.dirname(args.out), exist_ok=True)
-        W.save(args.out, model.export())
+        if model.family:
+            with open(args.out, "wb") as fo:
+                fo.write(W.pack_family(model.export()))
+        else:
+            W.save(args.out, model.export())
     print("saved", args.out)
 
 

@@ -761,6 +761,104 @@ void fho_cnn_ctu(const fho_weights* w, const int8_t* ctu, int qp, int32_t logits
   fho_cnn_ctu_debug(w, ctu, qp, 0, 0, 0, logits);
 }
 
+/* ---- the reference's Bayesian-optimisation network family (fho_family, see the header) ----
+ * conv3x3 pad 1 on [n][n][ci] (uint8 activations; the first one on the centred int8 samples) -> int32 accumulators [n][n][co] */
+static void conv3x3_family(const uint8_t* in_u8, const int8_t* in_i8, int n, int ci, int co, const int8_t* wt, const int32_t* bias, int32_t* acc)
+{
+  for (int y = 0; y < n; y++)
+    for (int x = 0; x < n; x++)
+      for (int oc = 0; oc < co; oc++) {
+        int32_t a = bias[oc];
+        for (int ky = 0; ky < 3; ky++)
+          for (int kx = 0; kx < 3; kx++) {
+            const int yy = y + ky - 1, xx = x + kx - 1;
+            if (yy < 0 || yy >= n || xx < 0 || xx >= n) continue;
+            for (int ic = 0; ic < ci; ic++) {
+              const int32_t v = in_i8 ? (int32_t)in_i8[(yy * n + xx) * ci + ic] : (int32_t)in_u8[(yy * n + xx) * ci + ic];
+              a += (int32_t)wt[((oc * ci + ic) * 3 + ky) * 3 + kx] * v;
+            }
+          }
+        acc[(y * n + x) * co + oc] = a;
+      }
+}
+void fho_cnn_ctu_family(const fho_family* w, const int8_t* ctu, int qp, int32_t logits[21][2])
+{
+  const int cmax = imax(w->c[0], imax(w->c[1], w->c[2]));
+  int32_t* acc = (int32_t*)malloc(sizeof(int32_t) * 64 * 64 * (size_t)cmax);
+  uint8_t* cur = (uint8_t*)malloc(64 * 64 * (size_t)cmax);
+  uint8_t* nxt = (uint8_t*)malloc(64 * 64 * (size_t)cmax);
+  int n = 64, ci = 1;
+  for (int b = 0; b < 3; b++) {
+    const int co = w->c[b];
+    for (int j = 0; j < w->depth; j++) {
+      conv3x3_family((b == 0 && j == 0) ? 0 : cur, (b == 0 && j == 0) ? ctu : 0, n, ci, co, w->w[b][j], w->b[b][j], acc);
+      const int pool = (j == w->depth - 1) && b < 2;   /* max-pool 2x2 after the first two blocks; max commutes with the monotone requant */
+      if (pool) {
+        for (int y = 0; y < n / 2; y++)
+          for (int x = 0; x < n / 2; x++)
+            for (int c = 0; c < co; c++) {
+              int32_t m = acc[((2 * y) * n + 2 * x) * co + c];
+              m = imax(m, acc[((2 * y) * n + 2 * x + 1) * co + c]);
+              m = imax(m, acc[((2 * y + 1) * n + 2 * x) * co + c]);
+              m = imax(m, acc[((2 * y + 1) * n + 2 * x + 1) * co + c]);
+              nxt[(y * (n / 2) + x) * co + c] = requant(m, w->shift[b][j]);
+            }
+        n /= 2;
+      } else {
+        for (int i = 0; i < n * n * co; i++) nxt[i] = requant(acc[i], w->shift[b][j]);
+      }
+      uint8_t* t = cur; cur = nxt; nxt = t;
+      ci = co;
+    }
+  }
+  /* heads on a3 = cur [16][16][c3], as fho_cnn_ctu_debug's with c3 channels */
+  const int c3 = w->c[2];
+  const uint8_t* a3 = cur;
+  for (int cls = 0; cls < 2; cls++) {
+    int32_t a = w->bh64[cls];
+    for (int y = 0; y < 16; y++)
+      for (int x = 0; x < 16; x++)
+        for (int c = 0; c < c3; c++) a += (int32_t)w->wh64[((cls * 8 + (y >> 1)) * 8 + (x >> 1)) * c3 + c] * a3[(y * 16 + x) * c3 + c];
+    logits[0][cls] = a;
+    for (int q = 0; q < 4; q++) {
+      const int qy = q >> 1, qx = q & 1;
+      a = w->bh32[cls];
+      for (int y = 0; y < 8; y++)
+        for (int x = 0; x < 8; x++)
+          for (int c = 0; c < c3; c++) a += (int32_t)w->wh32[((cls * 8 + y) * 8 + x) * c3 + c] * a3[((qy * 8 + y) * 16 + qx * 8 + x) * c3 + c];
+      logits[1 + q][cls] = a;
+    }
+    for (int b = 0; b < 16; b++) {
+      const int by = b >> 2, bx = b & 3;
+      a = w->bh16[cls];
+      for (int y = 0; y < 4; y++)
+        for (int x = 0; x < 4; x++)
+          for (int c = 0; c < c3; c++) a += (int32_t)w->wh16[((cls * 4 + y) * 4 + x) * c3 + c] * a3[((by * 4 + y) * 16 + bx * 4 + x) * c3 + c];
+      logits[5 + b][cls] = a;
+    }
+  }
+  const int q = clip3(0, 51, qp);
+  logits[0][1] += w->qp_bias[q];
+  for (int i = 1; i < 5; i++) logits[i][1] += w->qp_bias[52 + q];
+  for (int i = 5; i < 21; i++) logits[i][1] += w->qp_bias[104 + q];
+  free(acc); free(cur); free(nxt);
+}
+void fho_predict_frame_family(const fho_family* w, const int16_t* luma, int stride, int width, int height,
+                              int bit_depth, int qp, uint8_t* depth_map, int32_t* logits_out)
+{
+  const int cw = (width + 63) / 64, ch = (height + 63) / 64;
+  int8_t ctu[64 * 64];
+  int32_t logits[21][2];
+  for (int cy = 0; cy < ch; cy++)
+    for (int cx = 0; cx < cw; cx++) {
+      const int a = cy * cw + cx;
+      fho_load_ctu(luma, stride, width, height, cx, cy, bit_depth, ctu);
+      fho_cnn_ctu_family(w, ctu, qp, logits);
+      fho_depth_from_logits(logits, imin(64, width - cx * 64), imin(64, height - cy * 64), depth_map + a * 256);
+      if (logits_out) memcpy(logits_out + a * 42, logits, sizeof logits);
+    }
+}
+
 /* split decision: class 1 ("div", sortToDirLabels.m:11-19) wins only on a strict majority. */
 static inline int is_split(const int32_t l[2]) { return l[1] > l[0]; }
 /* split when the logit difference exceeds thr (thr = 0: the plain decision) */

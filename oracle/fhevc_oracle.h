@@ -151,6 +151,27 @@ typedef struct {
   int32_t qp_bias[3 * 52];     /* [level 64,32,16][slice QP]: added to the split logit */
 } fho_weights;
 
+/* The Bayesian-optimisation network FAMILY of the reference (matlab/dataExtraction/OptimizeDeepNeuralNetworksUsingBayesianOptimizationExample.m
+ * :103-106 NetworkDepth in [1, 3]; :233-259 convBlock(3, F, depth) x 3 with F = round(32 / sqrt(depth)) filters, 2F, 4F; max-pool after the
+ * first two blocks; :367-373 convBlock = depth x (conv3x3 pad 1 + BN + ReLU)): channel widths c1, c2, c3 and `depth` convolutions per
+ * block, the same fixed-point arithmetic as fho_weights (int8 weights, int32 biases, one requant shift per convolution, activations
+ * clamp((acc + b) >> s, 0, 255)), the same three heads on the last block's map.  depth = 1, widths 16 / 32 / 64 is fho_weights' network.
+ *   w[b][j]: convolution j of block b, [oc][ic][ky][kx]; its input width is 1 (b = 0, j = 0), the block's own width (j > 0) or the
+ *   previous block's width (j = 0).  shift[b][j], bias[b][j] likewise. */
+typedef struct {
+  int32_t c[3];                /* channel widths of the three blocks */
+  int32_t depth;               /* convolutions per block, 1..3 */
+  int32_t shift[3][3];
+  const int8_t* w[3][3];
+  const int32_t* b[3][3];
+  const int8_t* wh64; const int8_t* wh32; const int8_t* wh16;   /* [cls][y][x][c3] as in fho_weights */
+  int32_t bh64[2], bh32[2], bh16[2];
+  int32_t qp_bias[3 * 52];
+} fho_family;
+void fho_cnn_ctu_family(const fho_family* w, const int8_t* ctu, int qp, int32_t logits[21][2]);
+void fho_predict_frame_family(const fho_family* w, const int16_t* luma, int stride, int width, int height,
+                              int bit_depth, int qp, uint8_t* depth_map, int32_t* logits_out);
+
 /* ctu: 64x64 centred 8-bit samples (value-128), row stride 64, zeros outside the picture.
  * logits[21][2]: 0 = 64-level, 1..4 = 32-level quadrants (raster), 5..20 = 16-level blocks (raster). */
 void fho_cnn_ctu(const fho_weights* w, const int8_t* ctu, int qp, int32_t logits[21][2]);

@@ -87,6 +87,10 @@ def load_oracle():
     lib.fho_motion_ctu_dist.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_double, C.c_int, C.c_void_p]
     lib.fho_motion_ctu_dist.restype = None
+    lib.fho_cnn_ctu_family.argtypes = [C.POINTER(Family), C.c_void_p, C.c_int, C.c_void_p]
+    lib.fho_cnn_ctu_family.restype = None
+    lib.fho_predict_frame_family.argtypes = [C.POINTER(Family), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lib.fho_predict_frame_family.restype = None
     lib.fho_ilog2_q8.argtypes = [C.c_uint32]
     lib.fho_ilog2_q8.restype = C.c_int32
     lib.fho_p_depth_range.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(PRule), C.c_void_p, C.c_void_p]
@@ -180,6 +184,36 @@ def weights_from_arrays(d):
         assert len(field) == arr.size, (k, len(field), arr.size)
         C.memmove(field, arr.ctypes.data, arr.nbytes)
     return w
+
+
+class Family(C.Structure):
+    _fields_ = [("c", C.c_int32 * 3), ("depth", C.c_int32), ("shift", (C.c_int32 * 3) * 3), ("w", (C.c_void_p * 3) * 3), ("b", (C.c_void_p * 3) * 3),
+                ("wh64", C.c_void_p), ("wh32", C.c_void_p), ("wh16", C.c_void_p), ("bh64", C.c_int32 * 2), ("bh32", C.c_int32 * 2), ("bh16", C.c_int32 * 2),
+                ("qp_bias", C.c_int32 * 156)]
+
+
+def family_from_arrays(d):
+    """fasthevc_amd.weights family dict (unpack_family / random_family / family_from_base) -> fho_family; the struct keeps the arrays alive"""
+    f = Family()
+    keep = []
+    f.c[:] = [int(v) for v in d["widths"]]
+    f.depth = int(d["depth"])
+    for b in range(3):
+        for j in range(3):
+            f.shift[b][j] = int(d["shift"][b][j])
+            if j < f.depth:
+                wa, ba = np.ascontiguousarray(d[f"w{b}{j}"], np.int8), np.ascontiguousarray(d[f"b{b}{j}"], np.int32)
+                keep += [wa, ba]
+                f.w[b][j], f.b[b][j] = wa.ctypes.data, ba.ctypes.data
+    for k in ("wh64", "wh32", "wh16"):
+        a = np.ascontiguousarray(d[k], np.int8)
+        keep.append(a)
+        setattr(f, k, a.ctypes.data)
+    for k in ("bh64", "bh32", "bh16"):
+        getattr(f, k)[:] = [int(v) for v in d[k]]
+    f.qp_bias[:] = [int(v) for v in np.asarray(d["qp_bias"]).reshape(-1)]
+    f._keep = keep
+    return f
 
 
 def ref_line_to_roi(ref, n):

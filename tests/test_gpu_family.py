@@ -1,0 +1,94 @@
+"""The reference's Bayesian-optimisation network family on the MI355X (k_cnn_family.inc) against the CPU oracle (fho_cnn_ctu_family),
+bit for bit: the NetworkDepth-1 member 32 / 64 / 128 (Optimize...Example.m:103-106, 233-259), and the 16 / 32 / 64 widths through the same
+code path, which must reproduce the tuned base-network kernel's output."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import oracle_py as op
+from fasthevc_amd import capi, frames, weights
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_family(oracle, fam, luma, bd, qp):
+    H, W = luma.shape
+    buf, org, stride = frames.to_pel_plane(luma, bd)
+    n = ((W + 63) // 64) * ((H + 63) // 64)
+    depth, logits = np.zeros(n * 256, np.uint8), np.zeros(n * 42, np.int32)
+    f = op.family_from_arrays(fam)
+    oracle.fho_predict_frame_family(C.byref(f), op.ptr(buf.reshape(-1), org), stride, W, H, bd, qp, depth.ctypes.data, logits.ctypes.data)
+    had = np.zeros(n, np.int32)
+    oracle.fho_frame_src_hadamard(op.ptr(buf.reshape(-1), org), stride, W, H, had)
+    return buf, org, stride, depth.reshape(n, 256), logits.reshape(n, 42), had
+
+
+@pytest.mark.parametrize("W,H,bd,seed", [(416, 240, 8, 0), (416, 240, 10, 1), (200, 136, 8, 2), (832, 480, 8, 3)])
+def test_family_32_64_128_equals_the_oracle(oracle, W, H, bd, seed):
+    fam = weights.random_family((32, 64, 128), 1, seed=seed)
+    luma = frames.texture16_luma(W, H, seed=40 + seed)
+    buf, org, stride, depth_ref, logits_ref, had_ref = _oracle_family(oracle, fam, luma, bd, 22 + 5 * seed)
+    ctx = capi.Context(W, H, bd, fam)
+    depth, had = ctx.predict_frame(buf, org, stride, qp=22 + 5 * seed)
+    bad = np.nonzero((depth != depth_ref).any(axis=1))[0]
+    assert bad.size == 0, f"CTUs with a differing depth map: {bad[:10]}"
+    assert np.array_equal(had, had_ref)   # the stand-alone source-Hadamard kernel runs beside the family kernel
+    assert len(np.unique(depth)) >= 2
+    ctx.close()
+
+
+def test_family_logits_soft_ranges_and_a_device_batch(oracle):
+    import torch
+    assert torch.cuda.is_available()
+    W, H, NF = 416, 240, 3
+    fam = weights.random_family((32, 64, 128), 1, seed=9)
+    lumas = [frames.hetero_luma(W, H, seed=60 + f) for f in range(NF)]
+    refs = [_oracle_family(oracle, fam, y, 8, 32) for y in lumas]
+    ctx = capi.Context(W, H, 8, fam, max_frames=NF)
+    dev = torch.device("cuda:0")
+    d8 = torch.from_numpy(np.stack(lumas)).to(dev)
+    depth = torch.zeros((NF, ctx.num_ctus, 256), dtype=torch.uint8, device=dev)
+    logits = torch.zeros((NF, ctx.num_ctus, 42), dtype=torch.int32, device=dev)
+    flags = torch.zeros((NF, ctx.num_ctus), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ctx.predict_frames_device(d8.data_ptr(), 1, W, W * H, NF, depth.data_ptr(), None, logits.data_ptr(), qp=32, d_flags=flags.data_ptr())
+    expanded = torch.zeros_like(depth)
+    ctx.expand_depth_flags_device(flags.data_ptr(), NF, expanded.data_ptr())
+    torch.cuda.synchronize()
+    for f in range(NF):
+        assert np.array_equal(logits[f].cpu().numpy(), refs[f][4]), f
+        assert np.array_equal(depth[f].cpu().numpy(), refs[f][3]), f
+    assert torch.equal(expanded, depth)
+    buf, org, stride = refs[0][0], refs[0][1], refs[0][2]
+    dmin, dmax = ctx.predict_frame_range(buf, org, stride, qp=32, margin=30000, margin_stop=10000)
+    n = ctx.num_ctus
+    emin, emax = np.zeros((n, 256), np.uint8), np.zeros((n, 256), np.uint8)
+    cw = (W + 63) // 64
+    for c in range(n):
+        vw, vh = min(64, W - (c % cw) * 64), min(64, H - (c // cw) * 64)
+        oracle.fho_depth_range_from_logits(np.ascontiguousarray(refs[0][4][c]), vw, vh, 30000, 10000, emin[c], emax[c])
+    assert np.array_equal(dmin, emin) and np.array_equal(dmax, emax)
+    ctx.close()
+
+
+def test_family_code_path_reproduces_the_base_network(oracle):
+    """widths 16 / 32 / 64 through the family kernel == the tuned base-network kernels (both arithmetic forms) == the base oracle"""
+    W, H = 416, 240
+    base = weights.random_weights(12)
+    luma = frames.texture16_luma(W, H, seed=5)
+    buf, org, stride = frames.to_pel_plane(luma, 8)
+    ref_ctx = capi.Context(W, H, 8, base)
+    d_ref, _ = ref_ctx.predict_frame(buf, org, stride, qp=27)
+    ref_ctx.close()
+    ctx = capi.Context(W, H, 8, weights.family_from_base(base))
+    d, _ = ctx.predict_frame(buf, org, stride, qp=27)
+    assert np.array_equal(d, d_ref)
+    ctx.close()
+
+
+def test_deeper_family_members_are_refused_with_a_status():
+    fam = weights.random_family(weights.family_widths(2), 2, seed=1)
+    with pytest.raises(capi.FastHevcError) as e:
+        capi.Context(416, 240, 8, fam)
+    assert e.value.code == capi.E_WEIGHTS

@@ -149,3 +149,50 @@ def test_split_flag_word_equals_depth_map(oracle):
         d = np.zeros(256, np.uint8)
         oracle.fho_depth_from_flags(word, vw, vh, d)
         assert np.array_equal(d, d_ref), (vw, vh, hex(word))
+
+
+def test_family_oracle_reproduces_the_base_network_and_a_float64_restatement(oracle):
+    """The reference's Bayesian-optimisation family (fho_cnn_ctu_family; Optimize...Example.m:103-106, 233-259) in the oracle:
+    (i) the depth-1 member with widths 16 / 32 / 64 IS the base network -- identical logits to fho_cnn_ctu on random CTUs;
+    (ii) the depth-1 member 32 / 64 / 128 and the depth-2 member 23 / 46 / 92 against an independent float64 torch restatement."""
+    import ctypes as C
+    import torch
+    import torch.nn.functional as Fn
+    from oracle import oracle_py as op
+    from fasthevc_amd import weights
+    rng = np.random.default_rng(3)
+    base = weights.random_weights(4)
+    fam = op.family_from_arrays(weights.family_from_base(base))
+    ws = op.weights_from_arrays(base)
+    for _ in range(3):
+        ctu = rng.integers(-128, 128, size=64 * 64).astype(np.int8)
+        a, b = np.zeros(42, np.int32), np.zeros(42, np.int32)
+        oracle.fho_cnn_ctu(ws, ctu, 27, a)
+        oracle.fho_cnn_ctu_family(C.byref(fam), ctu.ctypes.data, 27, b.ctypes.data)
+        assert np.array_equal(a, b)
+    assert weights.family_widths(1) == (32, 64, 128) and weights.family_widths(2) == (23, 46, 92) and weights.family_widths(3) == (18, 36, 72)  # 2 * and 4 * the ROUNDED first width (:242, :248, :253)
+    for depth in (1, 2):
+        w = weights.random_family(weights.family_widths(depth), depth, seed=depth)
+        assert weights.unpack_family(weights.pack_family(w))["w20"].shape == w["w20"].shape
+        f = op.family_from_arrays(w)
+        ctu = rng.integers(-128, 128, size=64 * 64).astype(np.int8)
+        got = np.zeros(42, np.int32)
+        oracle.fho_cnn_ctu_family(C.byref(f), ctu.ctypes.data, 32, got.ctypes.data)
+        x = torch.from_numpy(ctu.astype(np.float64)).reshape(1, 1, 64, 64)
+        for blk in range(3):
+            for j in range(depth):
+                z = Fn.conv2d(x, torch.from_numpy(w[f"w{blk}{j}"].astype(np.float64)), torch.from_numpy(w[f"b{blk}{j}"].astype(np.float64)), padding=1)
+                if j == depth - 1 and blk < 2:
+                    z = Fn.max_pool2d(z, 2)
+                x = torch.clamp(torch.floor(z / float(1 << int(w["shift"][blk][j]))), 0, 255)
+        a3 = x
+        t = lambda k: torch.from_numpy(w[k].astype(np.float64)).permute(0, 3, 1, 2)
+        l64 = Fn.conv2d(4.0 * Fn.avg_pool2d(a3, 2), t("wh64"), torch.from_numpy(w["bh64"].astype(np.float64))).flatten()
+        l32 = Fn.conv2d(a3, t("wh32"), torch.from_numpy(w["bh32"].astype(np.float64)), stride=8)[0]
+        l16 = Fn.conv2d(a3, t("wh16"), torch.from_numpy(w["bh16"].astype(np.float64)), stride=4)[0]
+        exp = np.zeros((21, 2))
+        exp[0] = l64.numpy()
+        exp[1:5] = l32.reshape(2, 4).numpy().T
+        exp[5:21] = l16.reshape(2, 16).numpy().T
+        exp[0, 1] += w["qp_bias"][0, 32]; exp[1:5, 1] += w["qp_bias"][1, 32]; exp[5:, 1] += w["qp_bias"][2, 32]
+        assert np.array_equal(got.reshape(21, 2), exp.astype(np.int64)), depth
