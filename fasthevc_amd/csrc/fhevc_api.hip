@@ -34,7 +34,7 @@ struct fhevc_ctx {
   bool family = false;
   int fam_c[3] = { 0, 0, 0 };
   uint4* f_frag1 = nullptr; float* f_bias1 = nullptr; uint4* f_frag2 = nullptr; uint4* f_frag3 = nullptr; int32_t* f_bias_i8 = nullptr;
-  uint8_t* f_whead = nullptr; int32_t* f_bhead = nullptr;
+  uint8_t* f_whead = nullptr; uint8_t* f_headm = nullptr; int32_t* f_bhead = nullptr;
   int shift[3] = { 0, 0, 0 };
   int requant_mode[3] = { 0, 0, 0 };
   bool cnn_i8 = true;                                         // fhevc_set_cnn_arith / FHEVC_CNN_ARITH at fhevc_create
@@ -393,6 +393,20 @@ int build_family_image(fhevc_ctx* c, const uint8_t* blob, size_t bytes)
   std::memcpy(whead.data(), wh64, (size_t)2 * 64 * C3);
   std::memcpy(whead.data() + (size_t)2 * 64 * C3, wh32, (size_t)2 * 64 * C3);
   std::memcpy(whead.data() + (size_t)4 * 64 * C3, wh16, (size_t)2 * 16 * C3);
+  // the MFMA image of the two smaller heads: [position j = (py, px) of a 16x16 block][chunk of 64 channels][column][64 B]
+  const int KC = C3 / 64;
+  std::vector<uint8_t> headm((size_t)16 * KC * 16 * 64, 0);
+  for (int j = 0; j < 16; ++j)
+    for (int kc = 0; kc < KC; ++kc)
+      for (int n = 0; n < 10; ++n) {
+        const int8_t* src;
+        if (n < 2) src = wh16 + ((size_t)n * 16 + j) * C3 + 64 * kc;
+        else {
+          const int sub = (n - 2) >> 1, cls = n & 1, py = j >> 2, px = j & 3;
+          src = wh32 + ((size_t)cls * 64 + ((sub >> 1) * 4 + py) * 8 + (sub & 1) * 4 + px) * C3 + 64 * kc;
+        }
+        std::memcpy(headm.data() + (((size_t)j * KC + kc) * 16 + n) * 64, src, 64);
+      }
   int32_t bhead[6 + 3 * 52] = { i32at(bh64p, 0), i32at(bh64p, 1), i32at(bh32p, 0), i32at(bh32p, 1), i32at(bh16p, 0), i32at(bh16p, 1) };
   for (int cls = 0; cls < 2; ++cls) {
     int s64 = 0, s32 = 0, s16 = 0;
@@ -403,17 +417,18 @@ int build_family_image(fhevc_ctx* c, const uint8_t* blob, size_t bytes)
     bhead[4 + cls] += 128 * s16;
   }
   for (int i = 0; i < 3 * 52; ++i) bhead[6 + i] = i32at(qpb, i);
-  (void)hipFree(c->f_frag1); (void)hipFree(c->f_bias1); (void)hipFree(c->f_frag2); (void)hipFree(c->f_frag3); (void)hipFree(c->f_bias_i8); (void)hipFree(c->f_whead); (void)hipFree(c->f_bhead);
-  c->f_frag1 = nullptr; c->f_bias1 = nullptr; c->f_frag2 = nullptr; c->f_frag3 = nullptr; c->f_bias_i8 = nullptr; c->f_whead = nullptr; c->f_bhead = nullptr;
+  (void)hipFree(c->f_frag1); (void)hipFree(c->f_bias1); (void)hipFree(c->f_frag2); (void)hipFree(c->f_frag3); (void)hipFree(c->f_bias_i8); (void)hipFree(c->f_whead); (void)hipFree(c->f_headm); (void)hipFree(c->f_bhead);
+  c->f_frag1 = nullptr; c->f_headm = nullptr; c->f_bias1 = nullptr; c->f_frag2 = nullptr; c->f_frag3 = nullptr; c->f_bias_i8 = nullptr; c->f_whead = nullptr; c->f_bhead = nullptr;
   HIP_TRY(c, hipMalloc(&c->f_frag1, frag1.size() * 2)); HIP_TRY(c, hipMalloc(&c->f_bias1, bias1.size() * 4));
   HIP_TRY(c, hipMalloc(&c->f_frag2, frag2.size())); HIP_TRY(c, hipMalloc(&c->f_frag3, frag3.size()));
-  HIP_TRY(c, hipMalloc(&c->f_bias_i8, bias8.size() * 4)); HIP_TRY(c, hipMalloc(&c->f_whead, whead.size())); HIP_TRY(c, hipMalloc(&c->f_bhead, sizeof bhead));
+  HIP_TRY(c, hipMalloc(&c->f_bias_i8, bias8.size() * 4)); HIP_TRY(c, hipMalloc(&c->f_whead, whead.size())); HIP_TRY(c, hipMalloc(&c->f_headm, headm.size())); HIP_TRY(c, hipMalloc(&c->f_bhead, sizeof bhead));
   HIP_TRY(c, hipMemcpy(c->f_frag1, frag1.data(), frag1.size() * 2, hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(c->f_bias1, bias1.data(), bias1.size() * 4, hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(c->f_frag2, frag2.data(), frag2.size(), hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(c->f_frag3, frag3.data(), frag3.size(), hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(c->f_bias_i8, bias8.data(), bias8.size() * 4, hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(c->f_whead, whead.data(), whead.size(), hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(c->f_headm, headm.data(), headm.size(), hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(c->f_bhead, bhead, sizeof bhead, hipMemcpyHostToDevice));
   c->fam_c[0] = C1; c->fam_c[1] = C2; c->fam_c[2] = C3;
   c->shift[0] = sh[0]; c->shift[1] = sh[1]; c->shift[2] = sh[2];
@@ -426,7 +441,7 @@ FhevcFamilyWeights family_weights(const fhevc_ctx* c)
 {
   FhevcFamilyWeights w;
   w.c[0] = c->fam_c[0]; w.c[1] = c->fam_c[1]; w.c[2] = c->fam_c[2];
-  w.frag1 = c->f_frag1; w.bias1 = c->f_bias1; w.frag2 = c->f_frag2; w.frag3 = c->f_frag3; w.bias_i8 = c->f_bias_i8; w.whead = c->f_whead; w.bhead = c->f_bhead;
+  w.frag1 = c->f_frag1; w.bias1 = c->f_bias1; w.frag2 = c->f_frag2; w.frag3 = c->f_frag3; w.bias_i8 = c->f_bias_i8; w.whead = c->f_whead; w.headm = c->f_headm; w.bhead = c->f_bhead;
   w.shift[0] = c->shift[0]; w.shift[1] = c->shift[1]; w.shift[2] = c->shift[2];
   return w;
 }
@@ -588,7 +603,7 @@ void fhevc_destroy(fhevc_ctx* c)
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   (void)hipFree(c->d_frag); (void)hipFree(c->d_bias); (void)hipFree(c->d_whead); (void)hipFree(c->d_bhead);
   (void)hipFree(c->d_frag_i8); (void)hipFree(c->d_bias_i8);
-  (void)hipFree(c->f_frag1); (void)hipFree(c->f_bias1); (void)hipFree(c->f_frag2); (void)hipFree(c->f_frag3); (void)hipFree(c->f_bias_i8); (void)hipFree(c->f_whead); (void)hipFree(c->f_bhead);
+  (void)hipFree(c->f_frag1); (void)hipFree(c->f_bias1); (void)hipFree(c->f_frag2); (void)hipFree(c->f_frag3); (void)hipFree(c->f_bias_i8); (void)hipFree(c->f_whead); (void)hipFree(c->f_headm); (void)hipFree(c->f_bhead);
   (void)hipFree(c->d_luma); (void)hipFree(c->d_depth); (void)hipFree(c->d_had); (void)hipFree(c->d_nodes); (void)hipFree(c->d_satd); (void)hipFree(c->d_satd_out); (void)hipFree(c->d_act); (void)hipFree(c->d_depth_max); (void)hipFree(c->d_pair); (void)hipFree(c->d_motion);
   for (auto& sl : c->slot) {  // the host-batch ring of fhevc_predict_frames: stream, device buffers, pinned staging
     if (sl.st) { (void)hipStreamSynchronize(sl.st); (void)hipStreamDestroy(sl.st); }

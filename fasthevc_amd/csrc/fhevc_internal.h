@@ -66,6 +66,7 @@ struct FhevcFamilyWeights {
   const uint4* frag3;        // conv3: likewise
   const int32_t* bias_i8;    // bias2[C2], bias3[C3], + 128 * sum of weights
   const uint8_t* whead;      // wh64[2][8][8][C3], wh32[2][8][8][C3], wh16[2][4][4][C3]
+  const uint8_t* headm;      // MFMA image of wh32 / wh16: [position 16][chunk C3 / 64][column 16][64 B] (columns 0, 1: 16-level; 2 + 2 sub + class: 32-level)
   const int32_t* bhead;      // as FhevcCnnWeights::bhead
   int shift[3];
 };

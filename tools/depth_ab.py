@@ -47,12 +47,13 @@ for spec in args.variants:
             for kv in p.split(","):
                 k, v = kv.split("=")
                 envs[k] = v
+    fam = envs.pop("FAMILY", None)   # FAMILY=32x64x128: random-init weights of that member of the reference's Bayesian-optimisation family
     lib_path = envs.pop("LIB", None)
     if lib_path is not None:
         lib_path = os.path.join(ROOT, "build", "ab", lib_path + ".so")
     old = {k: os.environ.get(k) for k in envs}
     os.environ.update(envs)
-    ctx = capi.Context(W, H, 8, w, max_frames=NF, lib_path=lib_path)
+    ctx = capi.Context(W, H, 8, weights.random_family(tuple(int(v) for v in fam.split("x")), 1, seed=0) if fam else w, max_frames=NF, lib_path=lib_path)
     for k, v in old.items():
         if v is None:
             del os.environ[k]
