@@ -127,16 +127,22 @@ def cpu_baseline_port(width, height, bit_depth, w, seconds=10.0):
             "sample": f"{done} CTUs of the same 1080p hetero frame through oracle/fhevc_oracle.c (depth CNN + source Hadamard, 1 thread, {dt:.1f} s)"}
 
 
-def gpu_hook_leg(width, height, bit_depth, crops):
+def gpu_hook_leg(width, height, bit_depth, crops, margins=None):
     """the same compressSlice with the hm_patch hook linked to the GPU library (oracle/_ref/libhmref_hookgpu.so): HM's decision
-    stage end to end, GPU call (H2D + kernels + D2H) included, on the same crops"""
+    stage end to end, GPU call (H2D + kernels + D2H) included, on the same crops.  margins None: the hook's SHIPPED defaults
+    (100000 : 48000, the calibration that keeps every content family within 1 % BD-rate); (split, stop): that setting"""
     from oracle import oracle_py as op
     gpu_so = os.path.join(ROOT, "oracle", "_ref", "libhmref_hookgpu.so")
     blob = os.path.join(ROOT, "fasthevc_amd", "weights", "depthnet_v1.fhw")
     if not (os.path.exists(gpu_so) and os.path.exists(blob)):
         return None
-    knobs = {"FHEVC_ENABLE": "1", "FHEVC_WEIGHTS": blob, "FHEVC_MARGIN_SPLIT": "32000", "FHEVC_MARGIN_STOP": "0"}
-    saved = {k: os.environ.get(k) for k in knobs}
+    knobs = {"FHEVC_ENABLE": "1", "FHEVC_WEIGHTS": blob}
+    if margins is not None:
+        knobs.update({"FHEVC_MARGIN_SPLIT": str(margins[0]), "FHEVC_MARGIN_STOP": str(margins[1])})
+    clear = ("FHEVC_MARGIN", "FHEVC_MARGIN_SPLIT", "FHEVC_MARGIN_STOP")
+    saved = {k: os.environ.get(k) for k in set(knobs) | set(clear)}
+    for k in clear:
+        os.environ.pop(k, None)
     os.environ.update(knobs)
     try:
         glib = op.bind_rdo(op.load_ref(hook="gpu"))
@@ -144,15 +150,18 @@ def gpu_hook_leg(width, height, bit_depth, crops):
         from fasthevc_amd import frames
         luma = frames.hetero_luma(width, height)
         cu, cv = frames.chroma_planes("hetero", width, height)
+        # TEncFastDepth reads its knobs when the harness constructs the encoder of a geometry: the second setting runs on crops 8 px narrower
+        cw_ = CROP_W if margins is None else CROP_W - 64
         for (ox, oy) in [c for c in CROPS if c[1] + CROP_H <= height and c[0] + CROP_W <= width][:crops]:
-            buf, org, stride = frames.to_pel_plane(luma[oy:oy + CROP_H, ox:ox + CROP_W].copy(), bit_depth)
-            chroma = tuple((c[oy // 2:(oy + CROP_H) // 2, ox // 2:(ox + CROP_W) // 2].astype(np.int16) << (bit_depth - 8)) for c in (cu, cv))
-            _, st = op.rdo_encode(glib, buf, org, stride, CROP_W, CROP_H, bit_depth, 32, chroma=chroma)
+            buf, org, stride = frames.to_pel_plane(luma[oy:oy + CROP_H, ox:ox + cw_].copy(), bit_depth)
+            chroma = tuple((c[oy // 2:(oy + CROP_H) // 2, ox // 2:(ox + cw_) // 2].astype(np.int16) << (bit_depth - 8)) for c in (cu, cv))
+            _, st = op.rdo_encode(glib, buf, org, stride, cw_, CROP_H, bit_depth, 32, chroma=chroma)
             done += st["ctus"]
             spent += st["seconds"]
-        return {"value": done / spent, "unit": "CTUs/s through compressSlice",
-                "sample": f"{done} CTUs, same crops, hm_patch hook -> fhevc_predict_frame_range at the content-matched margins 32000:0 (+0.56 % BD-rate on this "
-                          f"family; the hook's all-content default 100000:48000 keeps 1.3x), {spent:.1f} s of 1 thread incl. the GPU calls"}
+        what = "the hook's shipped defaults 100000:48000 (every content family within 1 % BD-rate)" if margins is None else \
+            f"margins {margins[0]}:{margins[1]} (content-matched: +0.56 % BD-rate on this family, more on others)"
+        return {"value": done / spent, "unit": "CTUs/s through compressSlice", "margins": "100000:48000" if margins is None else f"{margins[0]}:{margins[1]}",
+                "sample": f"{done} CTUs, crops of the same picture, hm_patch hook -> fhevc_predict_frame_range at {what}, {spent:.1f} s of 1 thread incl. the GPU calls"}
     finally:
         for k, v in saved.items():
             if v is None:
@@ -165,13 +174,16 @@ def quoted_bd_rate():
     """the quality half of BASELINE's metric, quoted from the committed evaluations under profiles/ (tests/quality/eval_rd.py,
     eval_p.py: minutes of CPU each, not re-run here)"""
     out = {}
-    for tag, name in (("intra", "bdrate_generalization"), ("intra_soft_hook", "bdrate_soft_hook"), ("p_slices", "p_slice_motion_rule")):
-        for rnd in ("r02", "r01"):
+    for tag, name in (("intra", "bdrate_generalization"), ("intra_family_32_64_128", "bdrate_family_d1"), ("p_slices", "p_slice_motion_rule"),
+                      ("p_slices_large_motion", "p_slice_motion_speed32_832x480")):
+        for rnd in ("r03", "r02", "r01"):
             path = os.path.join(ROOT, "profiles", f"{rnd}_{name}.json")
             if os.path.exists(path):
                 try:
                     d = json.load(open(path))
-                    out[tag] = {"source": f"profiles/{rnd}_{name}.json", "summary": d.get("headline") or d.get("summary")}
+                    summ = d.get("headline") or d.get("summary")
+                    if summ:
+                        out[tag] = {"source": f"profiles/{rnd}_{name}.json", "summary": summ}
                 except Exception:
                     pass
                 break
@@ -197,6 +209,7 @@ def main():
     ap.add_argument("--bands", action="store_true", help="CTU-row bands of every picture over the ranks (config 3); implies strong scaling")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stages", action="store_true", help="skip the first-pass / pre-analysis / motion-search stage report")
+    ap.add_argument("--no-family", action="store_true", help="skip the line of the reference's Bayesian-optimisation family member 32 / 64 / 128")
     ap.add_argument("--no-host-path", action="store_true", help="skip the host-to-host (PCIe-inclusive) leg")
     ap.add_argument("--cpu-procs", type=int, default=None, help="processes of the all-cores CPU baseline (default: host cores, at most 16)")
     ap.add_argument("--arith", choices=("i8", "f16"), default=None,
@@ -445,7 +458,7 @@ def main():
         FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) -- only for the workload they were taken on."""
         if not (NF == 64 and args.sample_bytes == 2 and (W, H) == (1920, 1080) and mode == "frames"):
             return None, None
-        for rnd in ("r02", "r01"):
+        for rnd in ("r03", "r02", "r01"):
             path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_bench_frames64_int16.json")
             if os.path.exists(path):
                 d = json.load(open(path))
@@ -458,6 +471,61 @@ def main():
                     if k.startswith(kernel) and isinstance(v, dict) and "hbm_read_bytes_corrected" in v and "hbm_write_bytes" in v:
                         return v["hbm_read_bytes_corrected"] + v["hbm_write_bytes"], f"profiles/{rnd}_pmc_bench_frames64_int16.json (commit {d.get('commit', 'of that round')})"
         return None, None
+
+    def measured_mfma_busy():
+        """SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x kernel cycles) of the depth kernel from the committed PMC pass: how much of the launch the matrix
+        pipes were busy, at the 2.4 GHz the peak is quoted at and at the clock the chip held (GRBM_GUI_ACTIVE / 8 / time, where the pass has it)"""
+        if not (NF == 64 and args.sample_bytes == 2 and (W, H) == (1920, 1080) and mode == "frames"):
+            return None
+        for rnd in ("r03", "r02"):
+            path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_bench_frames64_int16.json")
+            if not os.path.exists(path):
+                continue
+            d = json.load(open(path))
+            for k, v in d.items():
+                if not (k.startswith("fhevc_cnn_depth_kernel<") and isinstance(v, dict) and "SQ_VALU_MFMA_BUSY_CYCLES" in v):
+                    continue
+                targs = k.split("<", 1)[1].split(">", 1)[0].split(",")
+                if (arith == "i8") != (len(targs) == 3 and targs[2].strip() in ("1", "2")):
+                    continue
+                ms = v.get("avg_ms") or v.get("duration_ms") or cnn_ms
+                if not ms:
+                    continue
+                out = {"SQ_VALU_MFMA_BUSY_CYCLES": v["SQ_VALU_MFMA_BUSY_CYCLES"], "launch_ms_of_that_pass": ms,
+                       "busy_frac_at_2.4GHz": v["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * ms * 2.4e6), "source": f"profiles/{rnd}_pmc_bench_frames64_int16.json"}
+                if v.get("GRBM_GUI_ACTIVE"):
+                    out["busy_frac_at_held_clock"] = v["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * v["GRBM_GUI_ACTIVE"] / 8.0)
+                return out
+        return None
+
+    # ---- the reference's Bayesian-optimisation network family (NetworkDepth 1: 32 / 64 / 128) on the same GOP: its own line, never `value` ----
+    family_line = None
+    if rank == 0 and world == 1 and not args.no_family:
+        fblob = os.path.join(ROOT, "fasthevc_amd", "weights", "depthnet_family_d1.fhw")
+        fw = weights.load_any(fblob) if os.path.exists(fblob) else weights.random_family((32, 64, 128), 1, seed=0)
+        fctx = capi.Context(W, H, bd, fw, device=local, max_frames=max(1, min(NF, 16)))
+        fctx.enable_kernel_timing(True)
+        fdepth = torch.zeros((nf_local, n_ctus, 256), dtype=torch.uint8, device=dev)
+        for _ in range(10):
+            fctx.predict_frames_device(luma_ptr, args.sample_bytes, stride, frame_stride, nf_local, fdepth.data_ptr(), None, None, stream=stream)
+        torch.cuda.synchronize()
+        fctx.kernel_timing(0, reset=True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            fctx.predict_frames_device(luma_ptr, args.sample_bytes, stride, frame_stride, nf_local, fdepth.data_ptr(), None, None, stream=stream)
+        torch.cuda.synchronize()
+        fdt = time.perf_counter() - t0
+        f_ms, f_n = fctx.kernel_timing(0, reset=True)
+        fctx.close()
+        c1, c2, c3 = 32, 64, 128
+        fmac = 4096 * 9 * c1 + 1024 * 9 * c1 * c2 + 256 * 9 * c2 * c3 + (64 * 4 + 4 * 64 + 16 * 16) * c3 * 2
+        fach = 2 * fmac * nf_local * n_ctus / (f_ms * 1e-3) / 1e12 if f_ms else None
+        family_line = {"network": "NetworkDepth 1 member of the reference's Bayesian-optimisation family: conv3x3 x 32 / 64 / 128, one convolution per block "
+                                  "(Optimize...Example.m:103-106, 233-259)", "weights": "trained (fasthevc_amd/weights/depthnet_family_d1.fhw)" if os.path.exists(fblob) else "random-init",
+                       "value": nf_local * n_ctus * args.steps / fdt, "unit": "CTU/s", "ms_per_step": fdt / args.steps * 1e3, "op_per_ctu": 2 * fmac,
+                       "note": "depth maps only (the source Hadamard is not fused into this kernel)",
+                       "roofline": {"bound": "mfma", "kernel": "fhevc_cnn_family_kernel<32, 64, 128>", "achieved": fach, "peak": PEAK_I8_TOPS, "unit": "TOP/s (2 per MAC)",
+                                    "frac": fach / PEAK_I8_TOPS if fach else None, "avg_launch_ms": f_ms, "launches": f_n}}
 
     if rank == 0:
         ctus_per_step = total_frames * n_ctus
@@ -475,6 +543,9 @@ def main():
                 "avg_launch_ms": cnn_ms, "launches": cnn_n, "flop_per_ctu": FLOP_PER_CTU, "ctus_per_launch": local_ctus,
                 "peak_note": "dense 16-bit MFMA" if arith == "f16" else "dense i8 MFMA; conv1 (6 % of the MACs) runs on the 16-bit MFMA at half that rate"}
         roof["frac"] = roof["achieved"] / roof["peak"] if roof["achieved"] else None
+        busy = measured_mfma_busy()
+        if busy:
+            roof["mfma_busy"] = busy
         if variants:
             for name, v in variants.items():
                 ach = flop_per_launch / (v["cnn_ms"] * 1e-3) / 1e12 if v["cnn_ms"] else None
@@ -483,11 +554,14 @@ def main():
                                   "roofline": {"bound": "mfma", "kernel": f"fhevc_cnn_depth_kernel ({name} form)", "achieved": ach, "peak": ARITH_PEAK[name],
                                                "unit": "TFLOP/s" if name == "f16" else "TOP/s (2 per MAC)", "frac": ach / ARITH_PEAK[name] if ach else None,
                                                "avg_launch_ms": v["cnn_ms"], "launches": v["launches"]}}
-        htraffic, htraffic_src = measured_traffic("fhevc_src_hadamard_kernel")
-        hbm = {"bound": "hbm", "kernel": "fhevc_src_hadamard_kernel", "achieved": bytes_per_launch_had / (had_ms * 1e-3) / 1e9 if had_ms else None,
-               "peak": PEAK_HBM_GBS, "unit": "GB/s", "traffic": htraffic, "traffic_source": htraffic_src, "avg_launch_ms": had_ms, "launches": had_n,
-               "bytes_per_launch": bytes_per_launch_had}
-        hbm["frac"] = hbm["achieved"] / hbm["peak"] if hbm["achieved"] else None
+        # the source Hadamard rides on the depth kernel since round 2: the stand-alone HBM-bound kernel that remains on the path is the AQ
+        # pre-analysis (N3), timed with the other stages after the timed region
+        hbm = None
+        if stages and stages.get("preanalyze"):
+            ptraffic, ptraffic_src = measured_traffic("fhevc_preanalyze_kernel")
+            pa = stages["preanalyze"]
+            hbm = {"bound": "hbm", "kernel": "fhevc_preanalyze_kernel (four AQ layers)", "achieved": pa["achieved_GB_s"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                   "frac": pa["frac"], "traffic": ptraffic, "traffic_source": ptraffic_src, "avg_launch_ms": pa["avg_launch_ms"], "frames": pa["frames"]}
         geom = "BQTerrace geometry" if (W, H) == (1920, 1080) else "synthetic"
         line = {
             "metric": "CTU depth decisions/sec at 1080p all-intra + BD-rate delta vs full-RDO HM" if (W, H) == (1920, 1080) else f"CTU depth decisions/sec at {W}x{H} all-intra",
@@ -509,8 +583,12 @@ def main():
                            " + one all-gather of the depth decisions (4-byte split-flag words per CTU, padded equal slices, expanded on every rank)")},
             "repeats": {"n": len(regions), "region_steps": args.steps, "min": thr[0], "median": value, "max": thr[-1],
                         "region_ms": [round(t * 1e3, 3) for t in regions]},
-            "roofline": roof, "roofline_hbm_kernel": hbm,
+            "roofline": roof,
         }
+        if hbm:
+            line["roofline_hbm_kernel"] = hbm
+        if family_line:
+            line["family"] = family_line
         bdr = quoted_bd_rate()
         if bdr:
             line["bd_rate"] = bdr
@@ -527,10 +605,14 @@ def main():
             if cpu is None:
                 cpu = cpu_baseline_port(1920, 1080, bd, w)
             else:
-                hook = gpu_hook_leg(1920, 1080, bd, crops=8)
+                hook = gpu_hook_leg(1920, 1080, bd, crops=8)                       # the SHIPPED hook default
                 if hook:
                     hook["speedup"] = hook["value"] / cpu["value"]
                     cpu["with_gpu_hook"] = hook
+                    matched = gpu_hook_leg(1920, 1080, bd, crops=6, margins=(32000, 0))   # the content-matched setting, beside it
+                    if matched:
+                        matched["speedup"] = matched["value"] / cpu["value"]
+                        cpu["with_gpu_hook_content_matched"] = matched
             line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)
     ctx.close()

@@ -46,7 +46,9 @@ def work(job):
     os.environ["FHREF_SAO"] = "1"            # ... and the reference's own SAOProcess after the deblocking pass (its syntax is in the written bits)
     from oracle import oracle_py as op
     ref, hook, oracle = op.bind_rdo(op.load_ref()), op.bind_rdo(op.load_ref(hook=True)), op.load_oracle()
-    ws = op.weights_from_arrays(weights.load(blob))
+    wd = weights.load_any(blob)   # FHW1 (16 / 32 / 64) or FHW3 (a member of the reference's Bayesian-optimisation family)
+    fam = op.family_from_arrays(wd) if "widths" in wd else None
+    ws = None if fam is not None else op.weights_from_arrays(wd)
     luma = picture(family, k, W, H)
     buf, org, stride = frames.to_pel_plane(luma, 8)
     u = np.full((H // 2, W // 2), 128, np.int16)
@@ -57,7 +59,10 @@ def work(job):
         out[("anchor", qp)] = (sa["coded_bits"], sa["psnr_y"], sa["seconds"], 1.0, sa.get("psnr_y_deblocked", sa["psnr_y"]), sa.get("slice_data_bits", sa["coded_bits"]), sa.get("psnr_y_filtered", sa.get("psnr_y_deblocked", sa["psnr_y"])))
         pred = np.zeros(n * 256, np.uint8)
         logits = np.zeros(n * 42, np.int32)
-        oracle.fho_predict_frame(ws, op.ptr(buf.reshape(-1), org), stride, W, H, 8, qp, pred, C.c_void_p(logits.ctypes.data))
+        if fam is not None:
+            oracle.fho_predict_frame_family(C.byref(fam), op.ptr(buf.reshape(-1), org), stride, W, H, 8, qp, pred.ctypes.data, logits.ctypes.data)
+        else:
+            oracle.fho_predict_frame(ws, op.ptr(buf.reshape(-1), org), stride, W, H, 8, qp, pred, C.c_void_p(logits.ctypes.data))
         for (name, ms, mt) in margins:
             dmin, dmax = np.zeros((n, 256), np.uint8), np.zeros((n, 256), np.uint8)
             for c in range(n):
@@ -65,7 +70,7 @@ def work(job):
                 oracle.fho_depth_range_from_logits_levels(np.ascontiguousarray(logits[c * 42:(c + 1) * 42]), vw, vh, ms, mt, dmin[c], dmax[c])
             _, sv = op.rdo_encode(hook, buf, org, stride, W, H, 8, qp, forced_depth=dmin, forced_depth_max=dmax, chroma=(u, u))
             out[(name, qp)] = (sv["coded_bits"], sv["psnr_y"], sv["seconds"], float((dmin != dmax).mean()), sv.get("psnr_y_deblocked", sv["psnr_y"]), sv.get("slice_data_bits", sv["coded_bits"]), sv.get("psnr_y_filtered", sv.get("psnr_y_deblocked", sv["psnr_y"])))
-        for c in range(4):  # trivial floors
+        for c in (range(4) if not os.environ.get("FHEVC_EVAL_NO_FLOORS") else ()):  # trivial floors
             _, sc = op.rdo_encode(hook, buf, org, stride, W, H, 8, qp, forced_depth=np.full((n, 256), c, np.uint8), chroma=(u, u))
             out[(f"const{c}", qp)] = (sc["coded_bits"], sc["psnr_y"], sc["seconds"], 0.0, sc.get("psnr_y_deblocked", sc["psnr_y"]), sc.get("slice_data_bits", sc["coded_bits"]), sc.get("psnr_y_filtered", sc.get("psnr_y_deblocked", sc["psnr_y"])))
     return family, k, out
@@ -94,7 +99,7 @@ def main():
         for i, (family, k, out) in enumerate(pool.imap_unordered(work, jobs)):
             res[(family, k)] = out
             print(f"{i + 1}/{len(jobs)} {family} #{k}", flush=True)
-    variants = [m[0] for m in margins] + [f"const{c}" for c in range(4)]
+    variants = [m[0] for m in margins] + ([] if os.environ.get("FHEVC_EVAL_NO_FLOORS") else [f"const{c}" for c in range(4)])
     report = {"what": f"{args.pictures} unseen {W}x{H} pictures per family, QP {list(QPS)}, shipped blob {os.path.basename(args.weights)}; per family ONE RD curve "
                       "(bits summed, PSNR averaged over its pictures); decision-stage BD-rate vs the reference's full RDO", "families": {}, "summary": {}}
     for f in fams:
