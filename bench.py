@@ -491,7 +491,7 @@ def main():
                 ms = v.get("avg_ms") or v.get("duration_ms") or cnn_ms
                 if not ms:
                     continue
-                out = {"SQ_VALU_MFMA_BUSY_CYCLES": v["SQ_VALU_MFMA_BUSY_CYCLES"], "launch_ms_of_that_pass": ms,
+                out = {"SQ_VALU_MFMA_BUSY_CYCLES": v["SQ_VALU_MFMA_BUSY_CYCLES"], "launch_ms_used": ms,
                        "busy_frac_at_2.4GHz": v["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * ms * 2.4e6), "source": f"profiles/{rnd}_pmc_bench_frames64_int16.json"}
                 if v.get("GRBM_GUI_ACTIVE"):
                     out["busy_frac_at_held_clock"] = v["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * v["GRBM_GUI_ACTIVE"] / 8.0)

@@ -3,7 +3,7 @@
 #   tools/profile_round.sh r01
 # Writes into gpurun_out/<tag>/; copy the summaries into profiles/ afterwards (tools/profile_collect.py).
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd "$GRAFT_REPO_ROOT"
@@ -14,7 +14,8 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/
 cd "$GRAFT_REPO_ROOT"
 bash tools/pmc_run.sh "$OUT/pmc_bench" "FETCH_SIZE" "WRITE_SIZE" \
   "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES" \
-  "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" || exit 1
+  "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
+  "GRBM_GUI_ACTIVE SQ_VALU_MFMA_COEXEC_CYCLES" || exit 1
 bash tools/pmc_kernels.sh "$OUT/pmc_kernels" "FETCH_SIZE" "WRITE_SIZE" \
   "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" || exit 1
 python3 tools/pmc_summary.py "$OUT/pmc_bench" "$OUT/pmc_bench.json" > /dev/null
