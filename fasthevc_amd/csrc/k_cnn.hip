@@ -6,25 +6,23 @@
 //   run convolutionally over the CTU, with three FC heads (64-, 32- and 16-level split decisions) and the
 //   top-down assembly of the 16x16 depth map that TEncCu::xCompressCU consumes (TEncCu.cpp:496-1058).
 //
-// How:
-//   * persistent workgroups (256 threads = 4 waves), grid = 2 per CU, grid-stride over CTUs;
-//   * every conv layer is an im2col GEMM on 16-bit MFMA -- conv1 v_mfma_f32_32x32x16_bf16, conv2 v_mfma_f32_32x32x16_f16,
-//     conv3 v_mfma_f32_16x16x32_f16 -- with A = weights (rows = output channels, resident in VGPRs for the whole kernel) and
-//     B = im2col (columns = spatial positions) read from LDS with one ds_read_b128 per K-step: activations live in LDS as
-//     8-channel planes [y][x][8] of f16 so that the 16-lane groups of a ds_read_b128 cover 256 contiguous bytes;
-//   * operands are fixed-point integers (|w| <= 127, activations 0..255, |acc| < 2^24) so the fp32
-//     accumulation is exact in any order -> the integer depth map is bit-exact against the CPU oracle; every conv
-//     carries its 2^-shift in the weights (still exact) and starts from the pre-scaled bias as the MFMA's C operand;
-//   * the waves run with fp32 rounding toward -inf, which turns v_cvt_pk_u8_f32 into floor + ReLU + clamp + pack: conv3's
-//     whole epilogue, and the first half of conv1's and conv2's (v_cvt_f16_u16 with SDWA byte select makes the f16 pairs);
-//     every other fp32 operation of the kernel is exact, so the mode changes nothing else;
-//   * the 2x2 max-pools are in-lane: conv1 folds the pool window into the MFMA's M dimension (A rows = 16 filters x 2x2
-//     pre-pool positions = two MFMAs, K = the 4x4 input window read as row-pair dwords), conv2 gives a lane one pooled
-//     position and four accumulators (dy, dx) over a parity-split column layout of conv1's output; no DPP in either;
-//   * FC heads on v_dot4_i32_i8 (int8 weights resident in LDS, conv3's output stored as a - 128, offsets folded into biases);
-//   * the next CTU's samples are prefetched into registers from the start of conv3 and staged into LDS after the heads;
-//   * MFMA chains read their fragments through a register ring that runs across the units of a phase; thread
-//     coordinates are re-derived per phase so that nothing address-like stays live across the conv2 phase (no spills).
+// How (DESIGN.md sections 5.1 - 5.1c, 5.6).  One template, fhevc_cnn_depth_kernel<STAMPS, HAD, ARITH>, in two arithmetic forms that
+// deliver the same integers (every GPU parity test runs both):
+//   ARITH = 0, the 16-bit form (round 1): conv1 v_mfma_f32_32x32x16_bf16, conv2 v_mfma_f32_32x32x16_f16, conv3 v_mfma_f32_16x16x32_f16;
+//     activations between the convs as f16 in 8-channel LDS planes; weights carry 2^-shift, biases are the C operand, fp32 rounding toward
+//     -inf turns v_cvt_pk_u8_f32 into floor + ReLU + clamp + pack; FC heads on v_dot4_i32_i8; two workgroups per CU (79.8 KB of LDS, 254 VGPRs);
+//   ARITH = 1 | 2, the i8 form (round 2, the library's default): conv2 and conv3 on v_mfma_i32_32x32x32_i8 with the activations as signed
+//     bytes a - 128 in 16-channel planes (half the LDS), int32 accumulators, requant by shifts (2: the short forms where the blob's shifts
+//     and accumulator bounds allow), the 16- / 32-level heads as one v_mfma_i32_16x16x64_i8 GEMM, conv2's fragments re-fetched per CTU;
+//     three workgroups per CU (51 KB of LDS, 168 VGPRs), s_setprio per phase.
+// Common to both: persistent workgroups of 256 threads, grid-stride over CTUs in an XCD-aware order; A = weights (resident in VGPRs), B =
+// im2col fragments read from LDS with one ds_read_b128 per K step through a register ring; the 2x2 max-pools in-lane (conv1 folds the pool
+// window into the MFMA's M dimension, conv2 gives a lane one pooled position and four accumulators); the next CTU's samples prefetched
+// into registers during conv3 and staged into LDS after the heads; four barriers per CTU.
+//   HAD = 1: the per-CTU source Hadamard (TEncCu::updateCtuDataISlice) on packed 16-bit VALU from the prefetched samples, at the tail of
+//     conv3 (default); HAD = 2: the same on the bf16 MFMA from the staged tile (8-bit content; measured slower, kept for A/B and tests).
+// Round 3 adds, after the kernel: fhevc_cnn_depth_pipe_kernel, the i8 form as a two-stage software pipeline over CTUs (opt-in, measured
+// slower), and k_cnn_family.inc, the reference's Bayesian-optimisation network family (NetworkDepth 1: 32 / 64 / 128 filters).
 #include "fhevc_internal.h"
 #include <cstdlib>
 #include <type_traits>
