@@ -1542,6 +1542,9 @@ struct LdsPipe {
 #ifndef FHEVC_PIPE_SCHED_X
 #define FHEVC_PIPE_SCHED_X 9    // VALU instructions offered per (MFMA, fragment read) group of conv2's chains in interval X: Hadamard, heads, pools, requant
 #endif
+#ifndef FHEVC_PIPE_FENCE_Y
+#define FHEVC_PIPE_FENCE_Y 0    // 1: a hard sched_barrier after every step of interval Y instead of the group description: the interleave then
+#endif                          // holds in the ISA (7-8 VALU behind every MFMA) and the kernel gains 1.7 % (0.4066 against 0.4135 ms; default kernel 0.3827)
 #ifndef FHEVC_PIPE_SCHED_Y
 #define FHEVC_PIPE_SCHED_Y 10   // VALU instructions offered per conv3 MFMA step of interval Y (0: no pipeline description)
 #endif
@@ -1875,7 +1878,8 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_pipe_kernel(FhevcFrame
               requant4_i8(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3], shift3, FASTRQ ? 2 : 0);
         }
         // the pipeline description of this step: its MFMA(s) and fragment read(s), then the slices' VALU work and their one LDS store
-        if (FHEVC_PIPE_SCHED_Y) {
+        if (FHEVC_PIPE_FENCE_Y) __builtin_amdgcn_sched_barrier(0);  // nothing moves across a step boundary: the slices stay where they were dealt
+        else if (FHEVC_PIPE_SCHED_Y) {
           constexpr bool issue = (j % 9 == 0) || (j % 9 == 4);  // steps 0, 4, 9, 13, 18, 22, 27, 31: a conv1 unit's two MFMAs and two ds_read_b64 go out first
           __builtin_amdgcn_sched_group_barrier(0x100, issue ? 3 : 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x008, issue ? 3 : 1, 0);
