@@ -133,7 +133,7 @@ def load_ref(hook=False):
     """Open oracle/_ref/libhmref.so (or the hook variant, libhmref_hook.so = the same reference objects with
     hm_patch/ applied; hook="gpu": libhmref_hookgpu.so, whose TEncFastDepth calls the real GPU library) with
     RTLD_LAZY: one never-called reference symbol stays unresolved, see oracle/Makefile."""
-    path = HOOK_SO.replace("_hook.so", "_hookgpu.so") if hook == "gpu" else (HOOK_SO if hook else REF_SO)
+    path = HOOK_SO.replace("_hook.so", "_hookgpu.so") if hook == "gpu" else HOOK_SO.replace("_hook.so", "_costs.so") if hook == "costs" else (HOOK_SO if hook else REF_SO)
     if hook == "gpu":
         # this library pulls in fasthevc_amd/lib/libfasthevc_hip.so; in a Python process that also holds torch the HIP runtime
         # must be the one torch ships (same SONAME as /opt/rocm's): let the product loader map it first
@@ -242,6 +242,17 @@ def bind_rdo(lib):
     lib.href_rdo_encode_frame_yuv.restype = C.c_int
     lib.href_has_hook.restype = C.c_int
     return lib
+
+
+def split_costs(lib, num_ctus):
+    """`make -C oracle costs` build (load_ref(hook="costs")): RD costs of the last rdo_encode's xCompressCU nodes -> [numCtus, 21, 2] float64
+    ([..., 0] best non-split mode, [..., 1] four-way split; node 0 the CTU, 1 + q quadrant q, 5 + b 16x16 block b, q / b in z-order;
+    NaN where the reference did not evaluate both)."""
+    out = np.zeros(num_ctus * 42, np.float64)
+    lib.href_split_costs.argtypes = [C.c_void_p, C.c_int]
+    if lib.href_split_costs(C.c_void_p(out.ctypes.data), num_ctus) != 0:
+        raise RuntimeError("href_split_costs: geometry differs from the last encode")
+    return out.reshape(num_ctus, 21, 2)
 
 
 def rdo_encode(lib, plane, origin, stride, width, height, bit_depth, qp, forced_depth=None, chroma=None, forced_depth_max=None):

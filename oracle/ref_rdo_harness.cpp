@@ -299,6 +299,26 @@ void init_slice(Encoder& e, int qp)
 
 }  // namespace
 
+#ifdef FHREF_RECORD_COSTS
+// `make costs` build (tests/quality/record_costs_patch.py): xCompressCU reports the two RD costs its xCheckBestMode compares at every
+// node it evaluates both ways.  Table: [ctu][node 0..20][0 = best non-split mode, 1 = four-way split]; node 0 = the CTU, 1 + q = its
+// quadrant q, 5 + b = its 16x16 block b, q and b in z-order (zorder >> 6, zorder >> 4).  NaN = not evaluated both ways.
+static std::vector<double> g_split_costs;
+extern "C" void fhref_record_split(unsigned ctu, unsigned zorder, unsigned depth, double cost_no_split, double cost_split)
+{
+  if (depth > 2) return;
+  const size_t node = depth == 0 ? 0 : depth == 1 ? 1 + (zorder >> 6) : 5 + (zorder >> 4);
+  const size_t i = ((size_t)ctu * 21 + node) * 2;
+  if (i + 1 < g_split_costs.size()) { g_split_costs[i] = cost_no_split; g_split_costs[i + 1] = cost_split; }
+}
+extern "C" int href_split_costs(double* out, int num_ctus)
+{
+  if ((size_t)num_ctus * 42 != g_split_costs.size()) return -1;
+  std::memcpy(out, g_split_costs.data(), g_split_costs.size() * sizeof(double));
+  return 0;
+}
+#endif
+
 extern "C" {
 
 // One intra picture through the reference's compressSlice.  luma: Pel samples at the internal bit depth.
@@ -345,6 +365,9 @@ int href_rdo_encode_frame_yuv(const int16_t* luma, int stride, const int16_t* cb
   g_forced_max = nullptr;  // one-shot
 #else
   if (forced_depth) return -2;
+#endif
+#ifdef FHREF_RECORD_COSTS
+  g_split_costs.assign((size_t)e->pic->getNumberOfCtusInFrame() * 42, std::nan(""));
 #endif
   const auto t0 = std::chrono::steady_clock::now();
   e->slice.compressSlice(e->pic, false, false);

@@ -50,9 +50,13 @@ def training_picture(seed):
     return np.clip(np.rint(y), 0, 255).astype(np.uint8), ("texture16" if kind == 3 else "hetero")
 
 
+COSTS = False  # --costs: the cost-recording build of the reference (make -C oracle costs): also store, per CTU and QP, the RD costs of
+               # "best non-split mode" and "split" of the 21 nodes xCompressCU compares (cost_q<qp> [numCtus, 21, 2] float32)
+
+
 def work(seed):
     from oracle import oracle_py as op
-    lib = op.bind_rdo(op.load_ref())
+    lib = op.bind_rdo(op.load_ref(hook="costs" if COSTS else False))
     luma, kind = training_picture(seed)
     chroma = None if kind == "flatchroma" else tuple(c.astype(np.int16) for c in frames.chroma_planes(kind, W, H))
     buf, org, stride = frames.to_pel_plane(luma, 8)
@@ -62,6 +66,8 @@ def work(seed):
     for qp in QPS:
         depth, st = op.rdo_encode(lib, buf, org, stride, W, H, 8, qp, chroma=chroma)
         out[f"depth_q{qp}"] = depth.reshape(cw * ch, 16, 16)
+        if COSTS:
+            out[f"cost_q{qp}"] = op.split_costs(lib, cw * ch).astype(np.float32)
         out[f"stats_q{qp}"] = np.array([st["bits"], st["dist"], st["psnr_y"], st["seconds"]])
     return seed, out
 
@@ -72,7 +78,10 @@ def main():
     ap.add_argument("--frames", type=int, default=64)
     ap.add_argument("--first", type=int, default=0)
     ap.add_argument("--workers", type=int, default=8)
+    ap.add_argument("--costs", action="store_true", help="also record the split / no-split RD costs of every node (needs `make -C oracle costs`)")
     args = ap.parse_args()
+    global COSTS
+    COSTS = args.costs
     os.makedirs(args.out, exist_ok=True)
     t0 = time.time()
     with Pool(args.workers) as pool:
