@@ -451,6 +451,25 @@ def main():
                                        "ctu_per_s": (nf_local - 1) * n_ctus / (mo_ms * 1e-3), "bound": "int VALU/LDS (packed 16-bit)",
                                        "achieved_Tintop_s": mo_ops / (mo_ms * 1e-3) / 1e12, "peak_Tintop_s": 2 * PEAK_INT32_TOPS,
                                        "frac": mo_ops / (mo_ms * 1e-3) / 1e12 / (2 * PEAK_INT32_TOPS)}
+        if nf_local > 1 and args.bit_depth == 8:
+            # the same search at HM's own SearchRange 64 (SAD, k_motion_wide.hip: 16 641 vectors per node instead of 81), on the first 5 pictures
+            nw = min(nf_local, 5)
+            ctx.set_motion_distortion("sad")
+            for timed in (False, True):
+                ctx.kernel_timing(4, reset=True)
+                for _ in range(2):
+                    ctx.motion_search_device(luma_ptr, args.sample_bytes, stride, frame_stride, nw, mot.data_ptr(), stream=stream, qp=38, search_range=64)
+                torch.cuda.synchronize()
+            mw_ms, _ = ctx.kernel_timing(4)
+            ctx.set_motion_distortion("satd")
+            qsad_ops = (nw - 1) * n_ctus * 129 * 129 * 4096 / 16  # algorithmic lane-operations: one v_qsad_pk_u16_u8 = 16 sample differences
+            stages["motion_search_range64"] = {"kernel": "fhevc_motion_wide_kernel", "picture_pairs": nw - 1, "search_range": 64, "distortion": "SAD",
+                                               "avg_launch_ms": mw_ms, "ctu_per_s": (nw - 1) * n_ctus / (mw_ms * 1e-3),
+                                               "vectors_per_s": (nw - 1) * n_ctus * 85 * 16641 / (mw_ms * 1e-3),
+                                               "bound": "int VALU (v_qsad_pk_u16_u8: 16 sample differences per lane-op)",
+                                               "achieved_Tlaneop_s": qsad_ops / (mw_ms * 1e-3) / 1e12, "peak_Tlaneop_s": PEAK_INT32_TOPS,
+                                               "frac": qsad_ops / (mw_ms * 1e-3) / 1e12 / PEAK_INT32_TOPS,
+                                               "note": "frac counts the SAD instructions only; keys, minima and sums are about as many again"}
     ctx.enable_kernel_timing(False)
 
     def measured_traffic(kernel):

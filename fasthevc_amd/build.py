@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libfasthevc_hip.so")
-SOURCES = ["fhevc_api.hip", "k_cnn.hip", "k_hadamard.hip", "k_firstpass.hip", "k_preanalyze.hip", "k_motion.hip"]
+SOURCES = ["fhevc_api.hip", "k_cnn.hip", "k_hadamard.hip", "k_firstpass.hip", "k_preanalyze.hip", "k_motion.hip", "k_motion_wide.hip"]
 # per-source extra flags: the CNN kernel holds only finite integers in fp32, so the NaN-canonicalising v_max can go
 EXTRA = {"k_cnn.hip": ["-ffinite-math-only", "-fno-signed-zeros"]}
 # -ffp-contract=off: the first-pass cost is compared bit-for-bit with the CPU oracle's double arithmetic

@@ -57,6 +57,9 @@ struct fhevc_ctx {
   double* d_act = nullptr;
   int16_t* d_pair = nullptr;          // two staging planes (reference, current) of fhevc_motion_search
   FhevcMotionNode* d_motion = nullptr;
+  uint32_t* d_mvtab = nullptr;        // vector costs of the wide search (k_motion_wide.hip), rebuilt when (qp, range) changes
+  int mvtab_qp = -1, mvtab_range = -1;
+  std::vector<uint32_t> mvtab_host;
   // host-batch ring (fhevc_predict_frames): two slots, each with its own stream, device buffers and pinned staging
   struct Slot {
     hipStream_t st = nullptr;
@@ -604,7 +607,7 @@ void fhevc_destroy(fhevc_ctx* c)
   (void)hipFree(c->d_frag); (void)hipFree(c->d_bias); (void)hipFree(c->d_whead); (void)hipFree(c->d_bhead);
   (void)hipFree(c->d_frag_i8); (void)hipFree(c->d_bias_i8);
   (void)hipFree(c->f_frag1); (void)hipFree(c->f_bias1); (void)hipFree(c->f_frag2); (void)hipFree(c->f_frag3); (void)hipFree(c->f_bias_i8); (void)hipFree(c->f_whead); (void)hipFree(c->f_headm); (void)hipFree(c->f_bhead);
-  (void)hipFree(c->d_luma); (void)hipFree(c->d_depth); (void)hipFree(c->d_had); (void)hipFree(c->d_nodes); (void)hipFree(c->d_satd); (void)hipFree(c->d_satd_out); (void)hipFree(c->d_act); (void)hipFree(c->d_depth_max); (void)hipFree(c->d_pair); (void)hipFree(c->d_motion);
+  (void)hipFree(c->d_luma); (void)hipFree(c->d_depth); (void)hipFree(c->d_had); (void)hipFree(c->d_nodes); (void)hipFree(c->d_satd); (void)hipFree(c->d_satd_out); (void)hipFree(c->d_act); (void)hipFree(c->d_depth_max); (void)hipFree(c->d_pair); (void)hipFree(c->d_motion); (void)hipFree(c->d_mvtab);
   for (auto& sl : c->slot) {  // the host-batch ring of fhevc_predict_frames: stream, device buffers, pinned staging
     if (sl.st) { (void)hipStreamSynchronize(sl.st); (void)hipStreamDestroy(sl.st); }
     (void)hipFree(sl.d_in); (void)hipFree(sl.d_depth); (void)hipFree(sl.d_had);
@@ -1230,8 +1233,11 @@ int fhevc_motion_search_device(fhevc_ctx* c, const void* d_luma, int sample_byte
 {
   if (!c || !d_luma || !d_out) return FHEVC_E_INVALID;
   if ((sample_bytes != 1 && sample_bytes != 2) || stride_samples < c->cfg.width || num_frames < 2 || qp < 0 || qp > 51 ||
-      ctu_row_begin < 0 || ctu_row_end > c->ctus_y || ctu_row_begin > ctu_row_end || search_range < 1 || search_range > FHEVC_MOTION_MAX_RANGE)
+      ctu_row_begin < 0 || ctu_row_end > c->ctus_y || ctu_row_begin > ctu_row_end || search_range < 1 || search_range > FHEVC_MOTION_WIDE_MAX_RANGE)
     return fail(c, FHEVC_E_INVALID, "bad motion-search arguments");
+  const bool wide = search_range > FHEVC_MOTION_MAX_RANGE;
+  if (wide && !(c->motion_sad && c->cfg.bit_depth == 8))
+    return fail(c, FHEVC_E_INVALID, "search ranges above 8 need the SAD distortion (fhevc_set_motion_distortion) and 8-bit content");
   if (sample_bytes == 1 && c->cfg.bit_depth != 8) return fail(c, FHEVC_E_INVALID, "uint8 samples need bit depth 8");
   if (frame_stride_samples < (long long)stride_samples * (c->cfg.height - 1) + c->cfg.width) return fail(c, FHEVC_E_INVALID, "frames overlap");
   if (ctu_row_begin == ctu_row_end) return FHEVC_OK;
@@ -1239,8 +1245,22 @@ int fhevc_motion_search_device(fhevc_ctx* c, const void* d_luma, int sample_byte
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
   const FhevcFrames fr = frames_of(c, d_luma, sample_bytes, stride_samples, frame_stride_samples, num_frames, ctu_row_begin, ctu_row_end, qp);
   static_assert(sizeof(fhevc_motion_node) == sizeof(FhevcMotionNode), "motion node layout");
+  if (wide && (c->mvtab_qp != qp || c->mvtab_range != search_range)) {
+    // the vector costs of the window in raster order, HM's arithmetic as mv_cost_table
+    const double motion_lambda = 65536.0 * std::sqrt(0.57 * std::pow(2.0, ((double)qp - 12.0) / 3.0));
+    auto eg = [](int v) { unsigned len = 1, u = (v <= 0) ? (((unsigned)(-v)) << 1) + 1 : ((unsigned)v) << 1; while (u != 1) { u >>= 1; len += 2; } return len; };
+    const int side = 2 * search_range + 1;
+    if (!c->d_mvtab) HIP_TRY(c, hipMalloc(&c->d_mvtab, sizeof(uint32_t) * (2 * FHEVC_MOTION_WIDE_MAX_RANGE + 1) * (2 * FHEVC_MOTION_WIDE_MAX_RANGE + 1)));
+    HIP_TRY(c, hipStreamSynchronize(st));  // a launch in flight may still read the old table
+    c->mvtab_host.resize((size_t)side * side);
+    for (int m = 0; m < side * side; ++m)
+      c->mvtab_host[m] = (uint32_t)((motion_lambda * (eg(((m % side) - search_range) << 2) + eg(((m / side) - search_range) << 2))) / 65536.0);
+    HIP_TRY(c, hipMemcpy(c->d_mvtab, c->mvtab_host.data(), c->mvtab_host.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    c->mvtab_qp = qp; c->mvtab_range = search_range;
+  }
   time_begin(c, st, 4);
-  HIP_TRY(c, fhevc_launch_motion(fr, search_range, mv_cost_table(qp, search_range), reinterpret_cast<FhevcMotionNode*>(d_out), c->num_cus, c->motion_sad, st));
+  if (wide) HIP_TRY(c, fhevc_launch_motion_wide(fr, search_range, c->d_mvtab, reinterpret_cast<FhevcMotionNode*>(d_out), c->num_cus, st));
+  else HIP_TRY(c, fhevc_launch_motion(fr, search_range, mv_cost_table(qp, search_range), reinterpret_cast<FhevcMotionNode*>(d_out), c->num_cus, c->motion_sad, st));
   time_end(c, st);
   c->stats.kernels_launched++;
   return FHEVC_OK;

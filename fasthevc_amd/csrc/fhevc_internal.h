@@ -105,6 +105,11 @@ struct FhevcMvCost { uint32_t c[(2 * FHEVC_MOTION_MAX_RANGE + 1) * (2 * FHEVC_MO
 // sad: SAD (HM's integer-search distortion, pinned to the reference's xPatternSearch) instead of Hadamard SATD
 hipError_t fhevc_launch_motion(const FhevcFrames& fr, int range, const FhevcMvCost& mvc, FhevcMotionNode* d_out, int num_cus, bool sad, hipStream_t stream);
 
+// the same search in its SAD mode over a window of up to +-64 (HM's SearchRange), 8-bit content (k_motion_wide.hip); d_mvtab: (2 range + 1)^2
+// vector costs in raster order, in HBM
+#define FHEVC_MOTION_WIDE_MAX_RANGE 64
+hipError_t fhevc_launch_motion_wide(const FhevcFrames& fr, int range, const uint32_t* d_mvtab, FhevcMotionNode* d_out, int num_cus, hipStream_t stream);
+
 // the shipped P-picture rule (fhevc_p_rule_default): see fasthevc.h; regenerate with tests/quality/fit_p_rule.py
 #define FHEVC_P_RULE_WEIGHTS { { 3101, 188, -94, 80, 1149, 1149, 3174, -138, 15748, -351620 }, \
                                { 594, 101, 375, -8, 1078, 1078, -197, 436, 3462, 256745 },      \

@@ -114,6 +114,7 @@ def main():
     preanalyze_golden(ref)
     intra_lines_golden(ref)
     pattern_search_golden(ref)
+    pattern_search_golden(ref, PATTERN_SEARCH_WIDE_CASES, "ref_pattern_search_wide.npz")
 
 
 PREANALYZE_CASES = (("texture16", 416, 240, 8, 3), ("hetero", 1000, 568, 10, 4), ("hetero", 64, 64, 8, 1))
@@ -202,7 +203,13 @@ PATTERN_SEARCH_CASES = (  # (bit depth, qp, range, clip seed, CTUs of the 7 x 4 
     (8, 22, 8, 17, (9, 26)))
 
 
-def pattern_search_golden(ref):
+PATTERN_SEARCH_WIDE_CASES = (  # the same at HM's own SearchRange and two odd ones, 8 bit, clips with large motion: (.., clip seed, CTUs, speeds)
+    (8, 32, 64, 31, (0, 9, 27), (21, -37)),
+    (8, 27, 24, 32, (3, 13), (13, 9)),
+    (8, 37, 33, 33, (6, 17, 24), (-30, 5)))
+
+
+def pattern_search_golden(ref, cases=None, name="ref_pattern_search.npz"):
     """Config 4: what the reference's OWN TEncSearch::xPatternSearch (TEncSearch.cpp:3786-3848: SAD + vector cost, raster order, strict <)
     returns for every in-picture CU node of whole CTUs -- vector, SAD, cost -- on the seeded pan clip (original planes, zero predictor).
     The planes are stored with the expected outputs (data only)."""
@@ -210,10 +217,12 @@ def pattern_search_golden(ref):
     oracle = op.load_oracle()
     ref.href_pattern_search.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     W, H = 416, 240
-    out = {"cases": np.array([list(c[:4]) for c in PATTERN_SEARCH_CASES], np.int32)}
+    cases = PATTERN_SEARCH_CASES if cases is None else cases
+    out = {"cases": np.array([list(c[:4]) for c in cases], np.int32)}
     total = 0
-    for k, (bd, qp, rng, seed, ctus) in enumerate(PATTERN_SEARCH_CASES):
-        ys = frames.pan_clip(W, H, 2, seed=seed)
+    for k, case in enumerate(cases):
+        (bd, qp, rng, seed, ctus), speeds = case[:5], (case[5] if len(case) > 5 else (3, 3))
+        ys = frames.pan_clip(W, H, 2, seed=seed, v_structure=speeds[0], v_noise=speeds[1])
         (rb, org, stride), (cb, _, _) = [frames.to_pel_plane(y, bd) for y in ys]
         if bd > 8:  # use the low bits too
             cb = (cb + np.random.default_rng(bd).integers(0, 1 << (bd - 8), size=cb.shape, dtype=np.int16)).astype(np.int16)
@@ -241,6 +250,6 @@ def pattern_search_golden(ref):
             total += len(blocks)
         out[f"cur{k}"], out[f"ref{k}"], out[f"stride{k}"] = cur, refp, np.int32(stride)
         out[f"ctus{k}"], out[f"nodes{k}"] = np.array(ctus, np.int32), res
-    dst = os.path.join(os.path.dirname(HERE), "tests", "golden", "ref_pattern_search.npz")
+    dst = os.path.join(os.path.dirname(HERE), "tests", "golden", name)
     np.savez_compressed(dst, **out)
     print("wrote", dst, os.path.getsize(dst), "bytes;", total, "nodes searched by the reference's xPatternSearch")

@@ -121,12 +121,14 @@ def test_motion_search_1080p_device_batch(oracle):
     ctx.close()
 
 
-def test_sad_mode_reproduces_the_references_xPatternSearch():
-    """The HIP kernel in its SAD mode, through the C ABI, against what the reference's OWN TEncSearch::xPatternSearch returned
-    (tests/golden/ref_pattern_search.npz: 706 nodes of whole CTUs incl. picture corners and edges, 8 / 10 bit, ranges 3 / 4 / 8):
-    vector, SAD and cost, directly -- no oracle in between."""
+@pytest.mark.parametrize("name,nodes", [("ref_pattern_search.npz", 706), ("ref_pattern_search_wide.npz", 517)])
+def test_sad_mode_reproduces_the_references_xPatternSearch(name, nodes):
+    """The HIP kernels in the SAD mode, through the C ABI, against what the reference's OWN TEncSearch::xPatternSearch returned
+    (tests/golden/ref_pattern_search.npz: 706 nodes of whole CTUs incl. picture corners and edges, 8 / 10 bit, ranges 3 / 4 / 8;
+    ref_pattern_search_wide.npz: 517 nodes at HM's SearchRange 64 and at 24 / 33 on clips moving 5 .. 37 samples per picture --
+    k_motion_wide.hip): vector, SAD and cost, directly -- no oracle in between."""
     import os
-    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_pattern_search.npz"))
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name))
     W, H = 416, 240
     checked = 0
     for k, (bd, qp, rng, _seed) in enumerate(g["cases"]):
@@ -143,4 +145,52 @@ def test_sad_mode_reproduces_the_references_xPatternSearch():
             assert np.array_equal(n["satd_best"][valid], exp[valid, 2].astype(np.uint32)) and np.array_equal(n["cost_best"][valid], exp[valid, 3].astype(np.uint32)), (k, c)
             checked += int(valid.sum())
         ctx.close()
-    assert checked == 706
+    assert checked == nodes
+
+
+@pytest.mark.parametrize("rng,qp,speeds", [(64, 32, (21, -37)), (16, 22, (9, 14)), (33, 40, (-30, 5)), (9, 51, (3, 3)), (47, 27, (40, -44))])
+def test_wide_sad_search_vs_oracle(oracle, rng, qp, speeds):
+    """Ranges above 8 (k_motion_wide.hip: 8 dy x 4 dx vectors per lane on v_qsad_pk_u16_u8, keys merged by LDS atomic minima) against the oracle's
+    plain loops, every node of every CTU of a ragged picture (last column 32 wide, last row 48 tall): zero-vector SAD, vector, SAD, cost."""
+    W, H = 416, 240
+    ys = frames.pan_clip(W, H, 2, seed=100 + rng, v_structure=speeds[0], v_noise=speeds[1])
+    (rb, org, stride), (cb, _, _) = [frames.to_pel_plane(y, 8) for y in ys]
+    ctx = capi.Context(W, H, 8)
+    ctx.set_motion_distortion("sad")
+    got = ctx.motion_search(cb, rb, org, stride, qp=qp, search_range=rng)
+    exp = oracle_motion(oracle, cb, rb, org, stride, W, H, 8, qp, rng, sad=True)
+    for k in capi.MOTION_DTYPE.names:
+        assert np.array_equal(got[k], exp[k]), (k, np.argwhere(got[k] != exp[k])[:5])
+    if min(abs(v) for v in speeds) > 8:
+        assert (np.abs(got["mvx"][got["cost_best"] != 0xFFFFFFFF]) > 8).any()   # the clip does move farther than the small kernel reaches
+    ctx.close()
+
+
+def test_wide_sad_search_extremes_and_uint8_batch(oracle):
+    """Saturated content (white on black: every packed 16-bit sum at its maximum, ties everywhere -> the FIRST vector in raster order must win),
+    a flat picture (all costs equal up to the vector cost), and the device-resident uint8 batch entry point against the int16 one."""
+    import torch
+    W, H, rng, qp = 192, 128, 64, 30
+    white, black = np.full((H, W), 255, np.uint8), np.zeros((H, W), np.uint8)
+    half = black.copy(); half[:, W // 2:] = 255
+    ctx = capi.Context(W, H, 8)
+    ctx.set_motion_distortion("sad")
+    for cur, ref in ((white, black), (black, white), (white, white), (half, np.roll(half, 40, axis=1))):
+        (rb, org, stride), (cb, _, _) = frames.to_pel_plane(ref, 8), frames.to_pel_plane(cur, 8)
+        got = ctx.motion_search(cb, rb, org, stride, qp=qp, search_range=rng)
+        exp = oracle_motion(oracle, cb, rb, org, stride, W, H, 8, qp, rng, sad=True)
+        assert same(got, exp)
+    ys = frames.pan_clip(W, H, 3, seed=5, v_structure=25, v_noise=-18)
+    d8 = torch.from_numpy(np.stack(ys)).cuda()
+    out8 = torch.zeros((2, 6, 85, 16), dtype=torch.uint8, device="cuda")
+    ctx.motion_search_device(d8.data_ptr(), 1, W, W * H, 3, out8.data_ptr(), qp=qp, search_range=rng)
+    torch.cuda.synchronize()
+    got8 = out8.cpu().numpy().view(capi.MOTION_DTYPE).reshape(2, 6, 85)
+    for f in (1, 2):
+        (rb, org, stride), (cb, _, _) = frames.to_pel_plane(ys[f - 1], 8), frames.to_pel_plane(ys[f], 8)
+        assert same(got8[f - 1], ctx.motion_search(cb, rb, org, stride, qp=qp, search_range=rng))
+    # above 8 the search needs the SAD distortion and 8-bit content
+    ctx.set_motion_distortion("satd")
+    with pytest.raises(capi.FastHevcError):
+        ctx.motion_search(cb, rb, org, stride, qp=qp, search_range=9)
+    ctx.close()
