@@ -1422,6 +1422,30 @@ int fhevc_set_cnn_arith(fhevc_ctx* c, int arith)
   return FHEVC_OK;
 }
 
+int fhevc_p_motion_compensated_depth(const fhevc_motion_node* nodes, const uint8_t* prev_map, int width, int height, int ctu, uint8_t* out)
+{
+  if (!nodes || !prev_map || !out || width < 8 || height < 8 || ctu < 0) return FHEVC_E_INVALID;
+  const int cw = (width + 63) / 64, chh = (height + 63) / 64;
+  if (ctu >= cw * chh) return FHEVC_E_INVALID;
+  const int x0 = (ctu % cw) * 64, y0 = (ctu / cw) * 64;
+  for (int by = 0; by < 4; ++by)
+    for (int bx = 0; bx < 4; ++bx) {
+      // the vector of the smallest valid node around the block: 16x16, 32x32, the CTU
+      const fhevc_motion_node* cand[3] = { &nodes[5 + by * 4 + bx], &nodes[1 + (by >> 1) * 2 + (bx >> 1)], &nodes[0] };
+      int mvx = 0, mvy = 0;
+      for (int k = 0; k < 3; ++k)
+        if (cand[k]->cost_best != 0xFFFFFFFFu) { mvx = cand[k]->mvx; mvy = cand[k]->mvy; break; }
+      for (int uy = 0; uy < 4; ++uy)
+        for (int ux = 0; ux < 4; ++ux) {
+          const int px = std::min(std::max(x0 + bx * 16 + ux * 4 + 2 + mvx, 0), width - 1);
+          const int py = std::min(std::max(y0 + by * 16 + uy * 4 + 2 + mvy, 0), height - 1);
+          const int sc = (py >> 6) * cw + (px >> 6);
+          out[(by * 4 + uy) * 16 + bx * 4 + ux] = prev_map[(size_t)sc * 256 + ((py & 63) >> 2) * 16 + ((px & 63) >> 2)];
+        }
+    }
+  return FHEVC_OK;
+}
+
 int fhevc_set_motion_distortion(fhevc_ctx* c, int mode)
 {
   if (!c) return FHEVC_E_INVALID;

@@ -46,7 +46,11 @@ void TEncFastDepth::readKnobs()
   const char* pr = std::getenv("FHEVC_P_RANGE");
   m_pRange = pr ? std::atoi(pr) : 4;
   if (m_pRange < 1) m_pRange = 1;
-  if (m_pRange > 8) m_pRange = 8;
+  if (m_pRange > 64) m_pRange = 64;   // above 8: HM's own integer search (SAD, xPatternSearch) over the window, 8-bit content (fasthevc.h)
+  // FHEVC_P_MC=1: the reference picture's depths are taken where the motion search says the content came from
+  // (fhevc_p_motion_compensated_depth) instead of co-located; the default for search ranges above 8, where content moves by more than a CU
+  const char* pc = std::getenv("FHEVC_P_MC");
+  m_pMotionCompensated = pc != NULL ? std::atoi(pc) != 0 : m_pRange > 8;
 #ifndef FHEVC_HOOK_NO_GPU
   fhevc_p_rule_default(P_RULE);
   const char* pt = std::getenv("FHEVC_P_THRESH");   // "split64,split32,split16,stop64,stop32,stop16" in score units (1.0 = 2^18)
@@ -146,6 +150,7 @@ bool TEncFastDepth::predictPicture(TComPic* pcPic, int sliceQp, int sliceType)
     TComPicYuv* rorg = ref->getPicYuvOrg();
     if (rorg == NULL || rorg->getStride(COMPONENT_Y) != org->getStride(COMPONENT_Y)) return false;
     std::vector<fhevc_motion_node> nodes((size_t)numCtus * FHEVC_NODES_PER_CTU);
+    fhevc_set_motion_distortion(m_ctx, m_pRange > 8 ? FHEVC_MOTION_SAD : FHEVC_MOTION_SATD);
     const int rc = fhevc_motion_search(m_ctx, org->getAddr(COMPONENT_Y), rorg->getAddr(COMPONENT_Y), org->getStride(COMPONENT_Y), sliceQp,
                                        m_pRange, &nodes[0]);
     if (rc != FHEVC_OK)
@@ -157,7 +162,14 @@ bool TEncFastDepth::predictPicture(TComPic* pcPic, int sliceQp, int sliceType)
     for (int c = 0; c < numCtus; c++)
     {
       const int vw = std::min(64, w - (c % cw) * 64), vh = std::min(64, h - (c / cw) * 64);
-      if (fhevc_p_depth_range(&nodes[(size_t)c * FHEVC_NODES_PER_CTU], &prev[(size_t)c * 256], vw, vh, sliceQp, P_RULE,
+      unsigned char seen[256];
+      const unsigned char* prevCtu = &prev[(size_t)c * 256];
+      if (m_pMotionCompensated)
+      {
+        if (fhevc_p_motion_compensated_depth(&nodes[(size_t)c * FHEVC_NODES_PER_CTU], &prev[0], w, h, c, seen) != FHEVC_OK) return false;
+        prevCtu = seen;
+      }
+      if (fhevc_p_depth_range(&nodes[(size_t)c * FHEVC_NODES_PER_CTU], prevCtu, vw, vh, sliceQp, P_RULE,
                               &m_depth[(size_t)c * 256], &m_depthMax[(size_t)c * 256]) != FHEVC_OK) return false;
     }
     m_valid = true;

@@ -55,6 +55,7 @@ private:
   int        m_width, m_height, m_bitDepth, m_marginSplit, m_marginStop, m_pWindow;
   enum PMode { P_OFF, P_WINDOW, P_MOTION };
   int        m_pMode, m_pRange;
+  bool       m_pMotionCompensated;  ///< reference depths taken at the motion-compensated position (FHEVC_P_MC)
   int        m_pRule[37];                     // fhevc_p_rule (include/fasthevc.h), kept opaque so that this header needs no library header
   bool       ensureContext(TComPic* pcPic);   // (re-)create the GPU context for this picture geometry
   std::vector<unsigned char> m_depth;     // numCtus * 256, raster 16x16 per CTU: depth_min

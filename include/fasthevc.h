@@ -209,11 +209,14 @@ int  fhevc_preanalyze_frames_device(fhevc_ctx* ctx, const void* d_luma, int samp
  *                      refinement only (HadamardME, TEncSearch.cpp:836): this is the library's own choice, the one the P-picture
  *                      rule of fhevc_p_depth_range was fitted on.
  * HM's own search runs on reconstructed references inside its serial CTU loop; this is its source-only twin, available for
- * the whole picture before that loop starts.  search_range 1..8 (HM's cfg: 64 with a TZ search). */
+ * the whole picture before that loop starts.  search_range 1..8 in either mode; 9..64 (HM's cfg: SearchRange 64) in the SAD mode on
+ * 8-bit content: the same full search, same result as xPatternSearch over that window, on a kernel laid out for 16 641 vectors per node
+ * (k_motion_wide.hip); FHEVC_E_INVALID otherwise. */
 #define FHEVC_MOTION_SATD 0
 #define FHEVC_MOTION_SAD  1
 int  fhevc_set_motion_distortion(fhevc_ctx* ctx, int mode);
-#define FHEVC_MOTION_MAX_RANGE 8
+#define FHEVC_MOTION_MAX_RANGE 8        /* SATD mode, and content above 8 bit */
+#define FHEVC_MOTION_SAD_MAX_RANGE 64   /* SAD mode, 8-bit content */
 typedef struct {
   uint32_t satd_zero;       /* distortion (SATD or SAD) at vector (0, 0) */
   uint32_t satd_best;       /* distortion at the cheapest vector */
@@ -253,6 +256,15 @@ typedef struct {
 void fhevc_p_rule_default(fhevc_p_rule* rule);   /* the shipped rule (fitted on the reference's own P-picture decisions) */
 int  fhevc_p_depth_range(const fhevc_motion_node* nodes /* 85 */, const uint8_t* prev_depth /* 256, raster */, int valid_w,
                          int valid_h, int qp, const fhevc_p_rule* rule, uint8_t* depth_min /* 256 */, uint8_t* depth_max /* 256 */);
+
+/* "Inter-CU depth reuse" for content that moves: the reference picture's depths seen THROUGH the motion.  For every 4x4 unit of CTU `ctu`
+ * (raster CTU index) the depth the reference picture's map holds where the unit's centre lands when displaced by the cheapest vector
+ * of the 16x16 node the unit lies in (a node crossing the picture edge: the vector of its 32x32 node, then of the CTU, then zero),
+ * positions clamped to the picture.  prev_map: numCtus * 256 depths of the reference picture (raster per CTU, as fhevc_predict_frame writes
+ * them and TComDataCU::getDepth holds them); out: 256, the prev_depth argument of fhevc_p_depth_range.  With zero vectors this is the
+ * co-located map.  Host-side integer logic, no device work, no context. */
+int  fhevc_p_motion_compensated_depth(const fhevc_motion_node* nodes /* 85 */, const uint8_t* prev_map, int width, int height, int ctu,
+                                      uint8_t* out /* 256 */);
 
 /* CTU-row band of rank `rank` out of `world`: rows [begin, end) */
 int  fhevc_band(int ctu_rows, int rank, int world, int* begin, int* end);

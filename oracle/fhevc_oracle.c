@@ -568,6 +568,21 @@ void fho_motion_ctu(const int16_t* cur, int cs, const int16_t* ref, int rs, int 
   fho_motion_ctu_dist(cur, cs, ref, rs, width, height, ctu_x, ctu_y, bit_depth, range, sqrt_lambda, 0, out);
 }
 
+/* the reference picture's depths seen through the motion (include/fasthevc.h: fhevc_p_motion_compensated_depth) */
+void fho_p_motion_compensated_depth(const fho_motion_node nodes[85], const uint8_t* prev_map, int width, int height, int ctu, uint8_t out[256])
+{
+  const int cw = (width + 63) / 64, x0 = (ctu % cw) * 64, y0 = (ctu / cw) * 64;
+  for (int u = 0; u < 256; u++) {
+    const int uy = u >> 4, ux = u & 15, by = uy >> 2, bx = ux >> 2;
+    const fho_motion_node* n = &nodes[5 + by * 4 + bx];
+    if (n->cost_best == 0xFFFFFFFFu) n = &nodes[1 + (by >> 1) * 2 + (bx >> 1)];
+    if (n->cost_best == 0xFFFFFFFFu) n = &nodes[0];
+    const int mvx = n->cost_best == 0xFFFFFFFFu ? 0 : n->mvx, mvy = n->cost_best == 0xFFFFFFFFu ? 0 : n->mvy;
+    const int px = clip3(0, width - 1, x0 + ux * 4 + 2 + mvx), py = clip3(0, height - 1, y0 + uy * 4 + 2 + mvy);
+    out[u] = prev_map[(size_t)((py >> 6) * cw + (px >> 6)) * 256 + ((py & 63) >> 2) * 16 + ((px & 63) >> 2)];
+  }
+}
+
 /* P-picture depth range (include/fasthevc.h: fhevc_p_depth_range) */
 int32_t fho_ilog2_q8(uint32_t x)
 {

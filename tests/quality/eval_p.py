@@ -64,16 +64,31 @@ def cnn_ranges(oracle, ws, y, qp, margin_split, margin_stop):
     return dmin, dmax
 
 
-def motion_ranges(oracle, rule, cur, ref, prev_depth, qp, search_range=4):
+def mc_depth(oracle, nodes, prev_depth, W, H):
+    """the previous picture's depths seen through the motion nodes (oracle twin of fhevc_p_motion_compensated_depth)"""
+    n = nodes.shape[0]
+    prev = np.ascontiguousarray(prev_depth, np.uint8).reshape(n, 256)
+    out = np.zeros((n, 256), np.uint8)
+    oracle.fho_p_motion_compensated_depth.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    for c in range(n):
+        oracle.fho_p_motion_compensated_depth(nodes[c].ctypes.data, prev.ctypes.data, W, H, c, out[c].ctypes.data)
+    return out
+
+
+def motion_ranges(oracle, rule, cur, ref, prev_depth, qp, search_range=4, dist=0, mc=False, window_only=None):
     """depth range of a P picture from the source-only motion search (oracle twin of k_motion.hip) and the previous picture's
     depths, through the oracle twin of fhevc_p_depth_range (the GPU path is bit-exact with both)"""
     import p_features
     H, W = cur.shape
     cw = (W + 63) // 64
-    nodes = p_features.motion_frame(oracle, cur, ref, qp, search_range)
+    nodes = p_features.motion_frame(oracle, cur, ref, qp, search_range, dist=dist)
     n = nodes.shape[0]
     dmin, dmax = np.zeros((n, 256), np.uint8), np.zeros((n, 256), np.uint8)
     prev = np.ascontiguousarray(prev_depth, np.uint8).reshape(n, 256)
+    if mc:  # "inter-CU depth reuse" through the motion: the depths at the displaced position instead of the co-located ones
+        prev = mc_depth(oracle, nodes, prev, W, H)
+    if window_only is not None:  # no rule: the (motion-compensated) depths +- a window
+        return np.clip(prev.astype(int) - window_only[0], 0, 3).astype(np.uint8), np.clip(prev.astype(int) + window_only[1], 0, 3).astype(np.uint8)
     for c in range(n):
         vw, vh = min(64, W - (c % cw) * 64), min(64, H - (c // cw) * 64)
         oracle.fho_p_depth_range(nodes[c].ctypes.data, prev[c].ctypes.data, vw, vh, qp, C.byref(rule), dmin[c].ctypes.data, dmax[c].ctypes.data)
@@ -99,7 +114,7 @@ def encode_seq(lib, ys, qp, window=None, cnn=None, motion=None):
             fmin, fmax = cnn_ranges(cnn[0], cnn[1], ys[f], qp + 6, cnn[2], cnn[3])
             fmin, fmax = np.ascontiguousarray(fmin), np.ascontiguousarray(fmax)
         elif motion is not None and f >= 2:  # (oracle, rule): motion features + the previous P picture's depths
-            fmin, fmax = motion_ranges(motion[0], motion[1], ys[f], ys[f - 1], out[-1][0], qp + 6, motion[2] if len(motion) > 2 else 4)
+            fmin, fmax = motion_ranges(motion[0], motion[1], ys[f], ys[f - 1], out[-1][0], qp + 6, **(motion[2] if len(motion) > 2 else {}))
             fmin, fmax = np.ascontiguousarray(fmin), np.ascontiguousarray(fmax)
         elif window is not None and f >= 2:
             prev = out[-1][0].astype(int)
@@ -139,7 +154,9 @@ def _run_qp(job):
                 if "t_stop" in v:
                     rule.t_stop[l] = int(v["t_stop"][l] * (1 << 18))
             rule.window = v.get("window", rule.window)
-            seq = encode_seq(lib, ys, qp, motion=(oracle, rule, v.get("search_range", 4)))
+            opts = {"search_range": v.get("search_range", 4), "dist": 1 if v.get("dist") == "sad" else 0, "mc": bool(v.get("mc", False)),
+                    "window_only": tuple(v["mc_window"]) if "mc_window" in v else None}
+            seq = encode_seq(lib, ys, qp, motion=(oracle, rule, opts))
         out[name] = tail(seq)
         out[name + ":agreement"] = [float((seq[f][0] == anchor[f][0]).mean()) for f in range(2, nframes)]
     return qp, out

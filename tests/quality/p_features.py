@@ -22,8 +22,8 @@ MOTION_DTYPE = np.dtype([("satd_zero", np.uint32), ("satd_best", np.uint32), ("c
 QPS = (28, 33, 38, 43)
 
 
-def motion_frame(oracle, cur, ref, qp, rng, bit_depth=8):
-    """85 motion nodes per CTU of `cur` (uint8 [H, W]) searched in `ref`"""
+def motion_frame(oracle, cur, ref, qp, rng, bit_depth=8, dist=0):
+    """85 motion nodes per CTU of `cur` (uint8 [H, W]) searched in `ref`; dist: 0 Hadamard SATD, 1 SAD (ranges above 8: the wide kernel's mode)"""
     from fasthevc_amd import frames
     H, W = cur.shape
     cb, co, cs = frames.to_pel_plane(cur, bit_depth)
@@ -33,8 +33,8 @@ def motion_frame(oracle, cur, ref, qp, rng, bit_depth=8):
     sl = oracle.fho_lambda_intra(qp, bit_depth) ** 0.5
     cp, rp = cb.reshape(-1).ctypes.data + 2 * co, rb.reshape(-1).ctypes.data + 2 * ro
     for c in range(cw * ch):
-        oracle.fho_motion_ctu(C.c_void_p(cp), cs, C.c_void_p(rp), rs, W, H, c % cw, c // cw, bit_depth, rng, C.c_double(sl),
-                              C.c_void_p(out[c].ctypes.data))
+        oracle.fho_motion_ctu_dist(C.c_void_p(cp), cs, C.c_void_p(rp), rs, W, H, c % cw, c // cw, bit_depth, rng, C.c_double(sl), dist,
+                                   C.c_void_p(out[c].ctypes.data))
     return out
 
 

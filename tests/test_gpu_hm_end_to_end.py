@@ -83,7 +83,7 @@ def test_reference_encoder_driven_by_the_gpu_library(oracle):
 
 P_SO = os.path.join(ROOT, "oracle", "_ref", "libhmref_p.so")
 PGPU_SO = os.path.join(ROOT, "oracle", "_ref", "libhmref_pgpu.so")
-P_KNOBS = KNOBS + ("FHEVC_P_MODE", "FHEVC_P_WINDOW", "FHEVC_P_RANGE", "FHEVC_P_THRESH")
+P_KNOBS = KNOBS + ("FHEVC_P_MODE", "FHEVC_P_WINDOW", "FHEVC_P_RANGE", "FHEVC_P_THRESH", "FHEVC_P_MC")
 
 
 def _load_p(path):
@@ -110,15 +110,20 @@ def _next_p(lib, y, W, H, qp, poc, fmin=None, fmax=None):
     return d.reshape(n, 256), s
 
 
+@pytest.mark.parametrize("size,rng,speeds", [((640, 448), 4, (3, 3)), ((576, 384), 64, (21, -17))])
 @pytest.mark.skipif(not os.path.exists(PGPU_SO), reason="oracle/_ref/libhmref_pgpu.so is built where /root/reference exists")
-def test_config4_p_pictures_driven_by_the_gpu_motion_search(oracle):
+def test_config4_p_pictures_driven_by_the_gpu_motion_search(oracle, size, rng, speeds):
     """BASELINE config 4 end to end: I P P P through the reference's compressSlice with HM-16.14's inter checks restored.  In the
     GPU build TEncFastDepth::predictPicture asks the MI355X for the motion nodes of every P picture whose reference is a P
     picture (fhevc_motion_search) and turns them into depth ranges (fhevc_p_depth_range); the result must equal the CPU-hook
-    build fed with the oracle's ranges (fho_motion_ctu + fho_p_depth_range), picture by picture, and differ from full RDO."""
+    build fed with the oracle's ranges (fho_motion_ctu + fho_p_depth_range), picture by picture, and differ from full RDO.
+    Second case: FHEVC_P_RANGE=64 on a clip moving 21 / 17 samples per picture -- the hook then asks for HM's own integer search
+    (SAD, k_motion_wide.hip) and takes the reference picture's depths at the motion-compensated position (fhevc_p_motion_compensated_depth)."""
     from fasthevc_amd import capi
-    W, H, QPI, QPP = 640, 448, 32, 38
-    ys = frames.pan_clip(W, H, 4, seed=77)
+    (W, H), QPI, QPP = size, 32, 38
+    wide = rng > 8
+    ys = frames.pan_clip(W, H, 4, seed=77, v_structure=speeds[0], v_noise=speeds[1])
+    oracle.fho_p_motion_compensated_depth.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     cpu, gpu = _load_p(P_SO), _load_p(PGPU_SO)
     n, cw = (W // 64) * (H // 64), W // 64
     u = np.full((H // 2, W // 2), 128, np.int16)
@@ -143,10 +148,16 @@ def test_config4_p_pictures_driven_by_the_gpu_motion_search(oracle):
                     sl = oracle.fho_lambda_intra(QPP, 8) ** 0.5
                     fmin, fmax = np.zeros((n, 256), np.uint8), np.zeros((n, 256), np.uint8)
                     prev = np.ascontiguousarray(maps[-1])
+                    seen = np.zeros(256, np.uint8)
                     for c in range(n):
-                        oracle.fho_motion_ctu(C.c_void_p(pb.reshape(-1).ctypes.data + 2 * po), ps, C.c_void_p(rb.reshape(-1).ctypes.data + 2 * po), ps,
-                                              W, H, c % cw, c // cw, 8, 4, C.c_double(sl), C.c_void_p(nodes[c].ctypes.data))
-                        oracle.fho_p_depth_range(nodes[c].ctypes.data, prev[c].ctypes.data, 64, 64, QPP, C.byref(rule), fmin[c].ctypes.data, fmax[c].ctypes.data)
+                        oracle.fho_motion_ctu_dist(C.c_void_p(pb.reshape(-1).ctypes.data + 2 * po), ps, C.c_void_p(rb.reshape(-1).ctypes.data + 2 * po), ps,
+                                                   W, H, c % cw, c // cw, 8, rng, C.c_double(sl), 1 if wide else 0, C.c_void_p(nodes[c].ctypes.data))
+                    for c in range(n):
+                        pc = prev[c]
+                        if wide:
+                            oracle.fho_p_motion_compensated_depth(nodes[c].ctypes.data, prev.ctypes.data, W, H, c, seen.ctypes.data)
+                            pc = seen
+                        oracle.fho_p_depth_range(nodes[c].ctypes.data, pc.ctypes.data, 64, 64, QPP, C.byref(rule), fmin[c].ctypes.data, fmax[c].ctypes.data)
                 d, s = _next_p(lib, ys[f], W, H, QPP, f, fmin, fmax)
                 maps.append(d)
                 stats.append(float(s[6]))
@@ -157,7 +168,7 @@ def test_config4_p_pictures_driven_by_the_gpu_motion_search(oracle):
         # TEncFastDepth reads the I-picture knobs when the encoder object of a geometry is built: build it before FHEVC_ENABLE is
         # set, so that POC 0 runs stock RDO in both builds; the P pictures re-read the knobs (href_rdo_encode_next_p)
         op.rdo_encode(gpu, buf, org, stride, W, H, 8, QPI, chroma=(u, u))
-        os.environ.update({"FHEVC_P_MODE": "motion", "FHEVC_ENABLE": "1", "FHEVC_WEIGHTS": BLOB, "FHEVC_P_RANGE": "4"})
+        os.environ.update({"FHEVC_P_MODE": "motion", "FHEVC_ENABLE": "1", "FHEVC_WEIGHTS": BLOB, "FHEVC_P_RANGE": str(rng)})
         gpu_maps, gpu_bits = run(gpu, False)
         for f in range(4):
             assert np.array_equal(gpu_maps[f], ref_maps[f]), f

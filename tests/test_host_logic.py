@@ -86,3 +86,34 @@ def test_struct_sizes_match_header():
     assert capi.NODE_DTYPE.itemsize == 16
     import ctypes
     assert ctypes.sizeof(capi.NodeCost) == 16
+
+
+def test_p_motion_compensated_depth_equals_the_oracle(oracle):
+    """Host-side logic behind the C ABI (no GPU): the reference picture's depths seen through the motion nodes of the current picture,
+    on a ragged picture, with vectors up to +-64, nodes flagged as crossing the picture edge (the enclosing node's vector counts), and
+    zero motion = the co-located map."""
+    import ctypes as C
+    W, H = 416, 240
+    cw, ch = 7, 4
+    rng = np.random.default_rng(11)
+    prev = rng.integers(0, 4, size=(cw * ch, 256)).astype(np.uint8)
+    nodes = np.zeros((cw * ch, 85), capi.MOTION_DTYPE)
+    nodes["mvx"] = rng.integers(-64, 65, size=nodes.shape)
+    nodes["mvy"] = rng.integers(-64, 65, size=nodes.shape)
+    nodes["cost_best"] = rng.integers(0, 1000, size=nodes.shape)
+    flag = rng.random(nodes.shape) < 0.2
+    nodes["cost_best"][flag] = 0xFFFFFFFF
+    got = capi.p_motion_compensated_depth(nodes, prev, W, H)
+    exp = np.zeros_like(got)
+    oracle.fho_p_motion_compensated_depth.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    for c in range(cw * ch):
+        oracle.fho_p_motion_compensated_depth(nodes[c].ctypes.data, prev.ctypes.data, W, H, c, exp[c].ctypes.data)
+    assert np.array_equal(got, exp)
+    assert (got != prev).any()
+    nodes["mvx"] = 0
+    nodes["mvy"] = 0
+    still = capi.p_motion_compensated_depth(nodes, prev, W, H)
+    inside = np.zeros((cw * ch, 16, 16), bool)   # units whose centre lies inside the picture
+    for c in range(cw * ch):
+        inside[c, :min(16, (H - (c // cw) * 64) // 4), :min(16, (W - (c % cw) * 64) // 4)] = True
+    assert np.array_equal(still.reshape(-1, 16, 16)[inside], prev.reshape(-1, 16, 16)[inside])
