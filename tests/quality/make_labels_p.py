@@ -26,15 +26,18 @@ W, H = 1024, 576
 
 def clip(seed):
     rng = np.random.default_rng(90_000 + seed)
-    if seed >= 1000:  # two overlaid motions (structure one way, noise the other), as in the config-4 evaluation clip
-        return frames.pan_clip(W, H, 4, seed=70_000 + seed, v_structure=int(rng.integers(-4, 5)), v_noise=int(rng.integers(-4, 5)))
+    fast = seed >= 2000                  # seeds 2000..: motion of up to 48 (horizontal) / 24 (vertical) samples per picture, for the +-64 search
+    vx, vy = (48, 24) if fast else (4, 2)
+    if 1000 <= seed < 2000 or seed >= 3000:  # two overlaid motions (structure one way, noise the other), as in the config-4 evaluation clip
+        return frames.pan_clip(W, H, 4, seed=70_000 + seed, v_structure=int(rng.integers(-vx, vx + 1)), v_noise=int(rng.integers(-vx, vx + 1)))
     gen = [frames.hetero_luma, frames.texture16_luma, frames.fractal_luma, frames.gratings_luma, frames.polygon_luma,
            frames.chirp_luma, frames.deadleaves_luma][seed % 7]
-    big = gen(W + 64, H + 64, seed=80_000 + seed)
-    dx, dy = int(rng.integers(-4, 5)), int(rng.integers(-2, 3))   # global pan per frame
+    px, py = (8 + 3 * vx, 8 + 3 * vy) if fast else (32, 32)
+    big = gen(W + 2 * px, H + 2 * py, seed=80_000 + seed)
+    dx, dy = int(rng.integers(-vx, vx + 1)), int(rng.integers(-vy, vy + 1))   # global pan per frame
     out = []
     for f in range(4):
-        x0, y0 = 32 + dx * f, 32 + dy * f
+        x0, y0 = px + dx * f, py + dy * f
         y = big[y0:y0 + H, x0:x0 + W].astype(np.float64)
         y = y + rng.normal(0, 0.7, size=y.shape) + 0.4 * f        # a little sensor noise and brightness drift
         out.append(np.clip(np.rint(y), 0, 255).astype(np.uint8))
