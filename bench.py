@@ -130,10 +130,10 @@ def cpu_baseline_port(width, height, bit_depth, w, seconds=10.0):
 def gpu_hook_leg(width, height, bit_depth, crops, margins=None):
     """the same compressSlice with the hm_patch hook linked to the GPU library (oracle/_ref/libhmref_hookgpu.so): HM's decision
     stage end to end, GPU call (H2D + kernels + D2H) included, on the same crops.  margins None: the hook's SHIPPED defaults
-    (100000 : 48000, the calibration that keeps every content family within 1 % BD-rate); (split, stop): that setting"""
+    (depthnet_v2.fhw at 100000 : 64000, the calibration that keeps every content family within 1 % BD-rate); (split, stop): that setting"""
     from oracle import oracle_py as op
     gpu_so = os.path.join(ROOT, "oracle", "_ref", "libhmref_hookgpu.so")
-    blob = os.path.join(ROOT, "fasthevc_amd", "weights", "depthnet_v1.fhw")
+    blob = os.path.join(ROOT, "fasthevc_amd", "weights", "depthnet_v2.fhw")
     if not (os.path.exists(gpu_so) and os.path.exists(blob)):
         return None
     knobs = {"FHEVC_ENABLE": "1", "FHEVC_WEIGHTS": blob}
@@ -158,9 +158,9 @@ def gpu_hook_leg(width, height, bit_depth, crops, margins=None):
             _, st = op.rdo_encode(glib, buf, org, stride, cw_, CROP_H, bit_depth, 32, chroma=chroma)
             done += st["ctus"]
             spent += st["seconds"]
-        what = "the hook's shipped defaults 100000:48000 (every content family within 1 % BD-rate)" if margins is None else \
-            f"margins {margins[0]}:{margins[1]} (content-matched: +0.56 % BD-rate on this family, more on others)"
-        return {"value": done / spent, "unit": "CTUs/s through compressSlice", "margins": "100000:48000" if margins is None else f"{margins[0]}:{margins[1]}",
+        what = "the hook's shipped defaults 100000:64000 (every content family within 1 % BD-rate)" if margins is None else \
+            f"margins {margins[0]}:{margins[1]} (content-matched: +0.15 % BD-rate on this family, more on others)"
+        return {"value": done / spent, "unit": "CTUs/s through compressSlice", "margins": "100000:64000" if margins is None else f"{margins[0]}:{margins[1]}",
                 "sample": f"{done} CTUs, crops of the same picture, hm_patch hook -> fhevc_predict_frame_range at {what}, {spent:.1f} s of 1 thread incl. the GPU calls"}
     finally:
         for k, v in saved.items():
@@ -250,9 +250,9 @@ def main():
     dev = torch.device("cuda", local)
     group, host_group = gather.init_groups(world, rank, dev, args.backend)
 
-    trained = os.path.join(ROOT, "fasthevc_amd", "weights", "depthnet_v1.fhw")
+    trained = os.path.join(ROOT, "fasthevc_amd", "weights", "depthnet_v2.fhw")
     if os.path.exists(trained):
-        w, wdesc = weights.load(trained), "trained weights fasthevc_amd/weights/depthnet_v1.fhw"
+        w, wdesc = weights.load(trained), "trained weights fasthevc_amd/weights/depthnet_v2.fhw"
     else:
         w, wdesc = weights.random_weights(0), "random-init weights"  # same architecture, same arithmetic
     total_frames = world * NF if (mode == "frames" and scaling == "weak") else NF
@@ -628,7 +628,7 @@ def main():
                 if hook:
                     hook["speedup"] = hook["value"] / cpu["value"]
                     cpu["with_gpu_hook"] = hook
-                    matched = gpu_hook_leg(1920, 1080, bd, crops=6, margins=(32000, 0))   # the content-matched setting, beside it
+                    matched = gpu_hook_leg(1920, 1080, bd, crops=6, margins=(48000, 16000))   # the content-matched setting, beside it
                     if matched:
                         matched["speedup"] = matched["value"] / cpu["value"]
                         cpu["with_gpu_hook_content_matched"] = matched

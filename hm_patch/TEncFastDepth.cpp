@@ -29,11 +29,12 @@ void TEncFastDepth::readKnobs()
   const char* mg = std::getenv("FHEVC_MARGIN");
   const char* ms = std::getenv("FHEVC_MARGIN_SPLIT");
   const char* mt = std::getenv("FHEVC_MARGIN_STOP");
-  // defaults: the calibration that keeps EVERY content family within 1 % BD-rate (profiles/r02_bdrate_generalization.json):
-  // splits are forced only above +100000, forbidden only below -48000, HM's own search decides in between.  On content like the
-  // classifier's training set FHEVC_MARGIN_SPLIT=32000 FHEVC_MARGIN_STOP=0 keeps the loss below 0.6 % at 3.5-4.8x less decision time.
+  // defaults: the calibration that keeps EVERY content family within 1 % BD-rate with the shipped blob depthnet_v2.fhw (DESIGN.md section 4,
+  // profiles/r03_bdrate_generalization.json): splits are forced only above +100000, forbidden only below -64000, HM's own search decides in
+  // between (the round-2 blob depthnet_v1.fhw: 100000 / 48000).  On content like the classifier's training set FHEVC_MARGIN_SPLIT=48000
+  // FHEVC_MARGIN_STOP=16000 keeps the loss at or below 0.2 % at 1.5-3.7x less decision time.
   m_marginSplit = ms ? std::atoi(ms) : (mg ? std::atoi(mg) : 100000);
-  m_marginStop  = mt ? std::atoi(mt) : (mg ? std::atoi(mg) : 48000);
+  m_marginStop  = mt ? std::atoi(mt) : (mg ? std::atoi(mg) : 64000);
   if (m_marginSplit < 0) m_marginSplit = 0;
   if (m_marginStop < 0) m_marginStop = 0;
   const char* pw = std::getenv("FHEVC_P_WINDOW");

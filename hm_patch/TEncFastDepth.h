@@ -11,13 +11,14 @@
  *   FHEVC_DEVICE=<ordinal>    HIP device (default 0)
  *   FHEVC_MARGIN=<int>        soft decisions: logit margin inside which a split decision is left to HM's RDO;
  *   FHEVC_MARGIN_SPLIT / FHEVC_MARGIN_STOP set the two sides separately (not forcing unsure splits is almost free,
- *                             not forbidding unsure ones costs the recursion it allows).  Defaults: split 100000, stop 48000 (every content
- *                             family measured stays within 1 % BD-rate); split 32000, stop 0 for content like the training set;
+ *                             not forbidding unsure ones costs the recursion it allows).  Defaults: split 100000, stop 64000 (every content
+ *                             family measured stays within 1 % BD-rate with depthnet_v2.fhw); split 48000, stop 16000 for content like the
+ *                             training set;
  *                             FHEVC_MARGIN=0 gives hard decisions
  *   FHEVC_P_MODE=window|motion  P/B pictures whose first reference picture was inter coded (default: off = stock RDO):
  *                             window = co-located depth of that picture +- FHEVC_P_WINDOW levels (host logic only, independent of
  *                             FHEVC_ENABLE); motion = GPU motion search of every CU node in the reference's ORIGINAL picture
- *                             (FHEVC_P_RANGE = window radius 1..8, default 4) + fhevc_p_depth_range (needs FHEVC_ENABLE=1);
+ *                             (FHEVC_P_RANGE = window radius 1..64, default 4; above 8: SAD search + FHEVC_P_MC depths at the motion-compensated position) + fhevc_p_depth_range (needs FHEVC_ENABLE=1);
  *                             FHEVC_P_THRESH overrides the six thresholds of the rule, FHEVC_P_WINDOW adds the +- clip to it
  */
 #ifndef __TENCFASTDEPTH__

@@ -12,7 +12,7 @@ from fasthevc_amd import bands, capi, frames, weights
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SHIPPED = os.path.join(ROOT, "fasthevc_amd", "weights", "depthnet_v1.fhw")
+SHIPPED = os.path.join(ROOT, "fasthevc_amd", "weights", "depthnet_v2.fhw")
 
 
 def _oracle(oracle, w, buf, org, stride, W, H, bd, qp):

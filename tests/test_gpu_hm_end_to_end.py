@@ -14,7 +14,7 @@ from fasthevc_amd import frames, weights
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-BLOB = os.path.join(ROOT, "fasthevc_amd", "weights", "depthnet_v1.fhw")
+BLOB = os.path.join(ROOT, "fasthevc_amd", "weights", "depthnet_v2.fhw")   # the shipped blob
 GPU_SO = os.path.join(ROOT, "oracle", "_ref", "libhmref_hookgpu.so")
 KNOBS = ("FHEVC_ENABLE", "FHEVC_WEIGHTS", "FHEVC_MARGIN", "FHEVC_MARGIN_SPLIT", "FHEVC_MARGIN_STOP", "FHEVC_DEVICE", "FHEVC_DEVICES")
 QP = 32
@@ -47,8 +47,8 @@ def test_reference_encoder_driven_by_the_gpu_library(oracle):
     try:
         # TEncFastDepth reads its knobs when the harness constructs the encoder of a geometry: one geometry per setting
         for (W, H), env, margins in (((768, 512), {"FHEVC_ENABLE": "1", "FHEVC_WEIGHTS": BLOB, "FHEVC_MARGIN": "0"}, (0, 0)),
-                                    ((832, 448), {"FHEVC_ENABLE": "1", "FHEVC_WEIGHTS": BLOB}, (100000, 48000)),   # the hook's defaults
-                                    ((704, 512), {"FHEVC_ENABLE": "1", "FHEVC_WEIGHTS": BLOB, "FHEVC_MARGIN_SPLIT": "32000"}, (32000, 48000)),   # the other side keeps its default
+                                    ((832, 448), {"FHEVC_ENABLE": "1", "FHEVC_WEIGHTS": BLOB}, (100000, 64000)),   # the hook's defaults
+                                    ((704, 512), {"FHEVC_ENABLE": "1", "FHEVC_WEIGHTS": BLOB, "FHEVC_MARGIN_SPLIT": "32000"}, (32000, 64000)),   # the other side keeps its default
                                     ((576, 512), {"FHEVC_ENABLE": "1", "FHEVC_WEIGHTS": BLOB, "FHEVC_MARGIN_SPLIT": "32000", "FHEVC_MARGIN_STOP": "0"}, (32000, 0)),
                                     ((640, 448), {"FHEVC_ENABLE": "1", "FHEVC_WEIGHTS": BLOB, "FHEVC_MARGIN": "8000"}, (8000, 8000)),
                                     # a multi-device context behind the hook (FHEVC_DEVICES): CTU-row bands over two queues of the one MI355X here

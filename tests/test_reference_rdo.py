@@ -175,11 +175,13 @@ def test_p_slice_variant_and_temporal_depth_window():
             os.environ["FHEVC_P_WINDOW"] = saved
 
 
-def test_trained_weights_follow_the_reference_decisions(oracle):
-    """The shipped blob (fasthevc_amd/weights/depthnet_v1.fhw, trained on the reference's full-RDO labels) against the
-    committed reference depth map of a picture it never saw (pinned hetero content): most units get HM's depth, nearly all within one level."""
+@pytest.mark.parametrize("blob", ["depthnet_v2.fhw", "depthnet_v1.fhw"])
+def test_trained_weights_follow_the_reference_decisions(oracle, blob):
+    """The shipped blob (fasthevc_amd/weights/depthnet_v2.fhw, trained cost-sensitively on the reference's full-RDO decisions and their RD
+    costs; depthnet_v1.fhw: round 2's, trained on the decisions alone) against the committed reference depth map of a picture it never saw
+    (pinned hetero content): most units get HM's depth, nearly all within one level."""
     from fasthevc_amd import weights
-    path = os.path.join(ROOT, "fasthevc_amd", "weights", "depthnet_v1.fhw")
+    path = os.path.join(ROOT, "fasthevc_amd", "weights", blob)
     w = weights.load(path)
     buf, org, stride = _crop()
     pred = np.zeros(96 * 256, np.uint8)

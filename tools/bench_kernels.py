@@ -118,6 +118,22 @@ for rng_ in (4, 8):
     mops = 15 * ctx.num_ctus * (2 * rng_ + 1) ** 2 * 64 * (64 + 575)  # per (vector, 8x8 tile): 64 differences + ~575 Hadamard ops
     out[f"motion_search[15 pairs, range {rng_}]"] = {"ms": ms, "launches": n, "ctu/s": 15 * ctx.num_ctus / ms * 1e3, "approx_int_ops": mops,
                                                      "Tint-op/s": mops / ms / 1e9}
+# --- the same search in its SAD mode at HM's SearchRange (k_motion_wide.hip), 5 pictures (4 pairs), int16 planes and uint8 planes
+ctx.set_motion_distortion("sad")
+for rng_ in (16, 32, 64):
+    for _ in range(2):
+        ctx.motion_search_device(d16.data_ptr() + 2 * org, 2, stride, fs, 5, mot.data_ptr(), qp=38, search_range=rng_)
+    torch.cuda.synchronize()
+    ctx.kernel_timing(4, reset=True)
+    for _ in range(4):
+        ctx.motion_search_device(d16.data_ptr() + 2 * org, 2, stride, fs, 5, mot.data_ptr(), qp=38, search_range=rng_)
+    torch.cuda.synchronize()
+    ms, n = ctx.kernel_timing(4, reset=True)
+    vec = (2 * rng_ + 1) ** 2
+    out[f"motion_search_sad_wide[4 pairs, range {rng_}]"] = {"ms": ms, "launches": n, "ctu/s": 4 * ctx.num_ctus / ms * 1e3, "vectors_per_node": vec,
+                                                             "node_vectors/s": 4 * ctx.num_ctus * 85 * vec / ms * 1e3,
+                                                             "qsad_Tlaneop/s": 4 * ctx.num_ctus * vec * 4096 / 16 / ms / 1e9}
+ctx.set_motion_distortion("satd")
 print(json.dumps(out, indent=1))
 ctx.close()
 ctx_unfused.close()

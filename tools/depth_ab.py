@@ -27,7 +27,7 @@ args = ap.parse_args()
 W, H, NF = 1920, 1080, 64
 dev = torch.device("cuda:0")
 torch.cuda.init()
-blob = os.path.join(ROOT, "fasthevc_amd", "weights", "depthnet_v1.fhw")
+blob = os.path.join(ROOT, "fasthevc_amd", "weights", "depthnet_v2.fhw")
 w = weights.load(blob)
 base = frames.hetero_luma(W, H)
 planes = np.stack([frames.to_pel_plane(np.roll(base, 3 * f, axis=1), 8)[0] for f in range(NF)])
