@@ -63,7 +63,10 @@ def test_reference_encoder_driven_by_the_gpu_library(oracle):
             d_gpu, s_gpu = op.rdo_encode(gpu, buf, org, stride, W, H, 8, QP, chroma=chroma)
             assert np.array_equal(d_gpu, d_ref), (W, H)
             assert s_gpu["bits"] == s_ref["bits"] and s_gpu["dist"] == s_ref["dist"], (W, H)
-            assert not np.array_equal(d_gpu, d_full) and s_gpu["seconds"] < (0.95 if margins[1] >= 48000 else 0.8) * s_full["seconds"], (W, H)
+            # the ranges did restrict the search: less time in compressSlice; with narrow margins the decisions differ from full RDO too
+            # (at the shipped default the restricted search may well end at full RDO's own map: that is the point of the guard)
+            assert s_gpu["seconds"] < (0.95 if margins[1] >= 48000 else 0.8) * s_full["seconds"], (W, H)
+            assert margins[1] >= 48000 or not np.array_equal(d_gpu, d_full), (W, H)
         # library switched off (FHEVC_ENABLE unset) / weights missing: stock full RDO, never an abort
         for (W, H), env in (((576, 448), {}), ((512, 448), {"FHEVC_ENABLE": "1", "FHEVC_WEIGHTS": "/nonexistent.fhw"})):  # (geometries not used above)
             buf, org, stride, chroma = _picture(W, H)
