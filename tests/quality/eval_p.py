@@ -154,6 +154,10 @@ def _run_qp(job):
                 if "t_stop" in v:
                     rule.t_stop[l] = int(v["t_stop"][l] * (1 << 18))
             rule.window = v.get("window", rule.window)
+            if "w" in v:  # a refitted rule: weights [3][10] in the fixed-point form of FHEVC_P_RULE_WEIGHTS
+                for l in range(3):
+                    for i in range(10):
+                        rule.w[l][i] = int(v["w"][l][i])
             opts = {"search_range": v.get("search_range", 4), "dist": 1 if v.get("dist") == "sad" else 0, "mc": bool(v.get("mc", False)),
                     "window_only": tuple(v["mc_window"]) if "mc_window" in v else None}
             seq = encode_seq(lib, ys, qp, motion=(oracle, rule, opts))

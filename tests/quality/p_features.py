@@ -39,7 +39,7 @@ def motion_frame(oracle, cur, ref, qp, rng, bit_depth=8, dist=0):
 
 
 def work(args):
-    path, rng = args
+    path, rng, dist, mc = args
     import make_labels_p
     from oracle import oracle_py as op
     oracle = op.load_oracle()
@@ -48,9 +48,18 @@ def work(args):
     d = np.load(path)
     n = d["tiles"].shape[0] // 2
     out = {}
+    H, W = ys[3].shape
+    oracle.fho_p_motion_compensated_depth.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     for qp in QPS:
-        out[f"nodes_q{qp}"] = motion_frame(oracle, ys[3], ys[2], qp, rng)
-        out[f"prev_q{qp}"] = d[f"depth_q{qp}"][:n].reshape(n, 256)
+        nodes = motion_frame(oracle, ys[3], ys[2], qp, rng, dist=dist)
+        out[f"nodes_q{qp}"] = nodes
+        prev = np.ascontiguousarray(d[f"depth_q{qp}"][:n].reshape(n, 256))
+        if mc:  # the reference picture's depths seen through the motion (fhevc_p_motion_compensated_depth) instead of co-located
+            seen = np.zeros_like(prev)
+            for c in range(n):
+                oracle.fho_p_motion_compensated_depth(nodes[c].ctypes.data, prev.ctypes.data, W, H, c, seen[c].ctypes.data)
+            prev = seen
+        out[f"prev_q{qp}"] = prev
         out[f"label_q{qp}"] = d[f"depth_q{qp}"][n:].reshape(n, 256)
     return seed, out
 
@@ -61,11 +70,13 @@ def main():
     ap.add_argument("--out", default="/tmp/pfit/feats.npz")
     ap.add_argument("--range", type=int, default=4)
     ap.add_argument("--workers", type=int, default=8)
+    ap.add_argument("--dist", default="satd", choices=("satd", "sad"), help="sad: HM's integer-search distortion (needed for ranges above 8)")
+    ap.add_argument("--mc", action="store_true", help="previous depths taken at the motion-compensated position")
     args = ap.parse_args()
     files = sorted(glob.glob(os.path.join(args.labels, "pic_*.npz")))
     acc = {}
     with Pool(args.workers) as pool:
-        for i, (seed, out) in enumerate(pool.imap(work, [(f, args.range) for f in files])):
+        for i, (seed, out) in enumerate(pool.imap(work, [(f, args.range, 1 if args.dist == "sad" else 0, args.mc) for f in files])):
             for k, v in out.items():
                 acc.setdefault(k, []).append(v)
             acc.setdefault("seed", []).append(np.full(out["prev_q28"].shape[0], seed))
