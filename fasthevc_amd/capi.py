@@ -24,7 +24,7 @@ SYMBOLS = [
     "fhevc_enable_kernel_timing", "fhevc_get_stats", "fhevc_last_error", "fhevc_version",
     "fhevc_expand_depth_flags_device", "fhevc_aq_parts", "fhevc_preanalyze", "fhevc_preanalyze_frames_device", "fhevc_aq_qp", "fhevc_intra_first_pass_device",
     "fhevc_predict_frame_range", "fhevc_predict_frames_device_range",
-    "fhevc_motion_search", "fhevc_motion_search_device", "fhevc_intra_first_pass_all", "fhevc_p_rule_default", "fhevc_p_depth_range", "fhevc_p_motion_compensated_depth",
+    "fhevc_motion_search", "fhevc_motion_search_device", "fhevc_intra_first_pass_all", "fhevc_p_rule_default", "fhevc_p_rule_default_wide", "fhevc_p_depth_range", "fhevc_p_motion_compensated_depth",
     "fhevc_predict_frames", "fhevc_alloc_host", "fhevc_free_host", "fhevc_set_cnn_arith", "fhevc_get_cnn_arith", "fhevc_set_motion_distortion", "fhevc_read_yuv_luma",
 ]
 CNN_ARITH = {"i8": 8, "f16": 16}
@@ -127,6 +127,8 @@ def load_library(path=None):
     lib.fhevc_motion_search_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
     lib.fhevc_p_rule_default.argtypes = [C.POINTER(PRule)]
     lib.fhevc_p_rule_default.restype = None
+    lib.fhevc_p_rule_default_wide.argtypes = [C.POINTER(PRule)]
+    lib.fhevc_p_rule_default_wide.restype = None
     lib.fhevc_p_depth_range.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(PRule), vp, vp]
     lib.fhevc_p_motion_compensated_depth.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
     lib.fhevc_predict_frames.argtypes = [vp, vp, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int, vp, vp]
@@ -162,6 +164,12 @@ def read_yuv_luma(path, file_size, file_bit_depth, out, first=0, internal_bit_de
 def p_rule_default():
     r = PRule()
     load_library().fhevc_p_rule_default(C.byref(r))
+    return r
+
+
+def p_rule_default_wide():
+    r = PRule()
+    load_library().fhevc_p_rule_default_wide(C.byref(r))
     return r
 
 

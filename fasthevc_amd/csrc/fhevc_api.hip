@@ -1344,6 +1344,14 @@ void fhevc_p_rule_default(fhevc_p_rule* rule)
   rule->window = FHEVC_P_RULE_WINDOW;
 }
 
+void fhevc_p_rule_default_wide(fhevc_p_rule* rule)
+{
+  if (!rule) return;
+  fhevc_p_rule_default(rule);   // thresholds and window as the default rule: same score semantics (a logit)
+  static const int32_t w[3][10] = FHEVC_P_RULE_WIDE_WEIGHTS;
+  std::memcpy(rule->w, w, sizeof w);
+}
+
 int fhevc_p_depth_range(const fhevc_motion_node* nodes, const uint8_t* prev_depth, int valid_w, int valid_h, int qp, const fhevc_p_rule* rule,
                         uint8_t* depth_min, uint8_t* depth_max)
 {

@@ -121,6 +121,12 @@ hipError_t fhevc_launch_motion_wide(const FhevcFrames& fr, int range, const uint
 #define FHEVC_P_RULE_T_STOP  { 786432, 262144, 131072 }
 #define FHEVC_P_RULE_WINDOW  1
 
+// the rule for the wide search (fhevc_p_rule_default_wide): fitted on SAD-mode features of the +-64 search with the reference picture's depths taken
+// at the motion-compensated position (tests/quality/p_features_gpu.py on the MI355X, fit_p_rule.py; 176 clips with motion of 0 .. 48 samples per picture)
+#define FHEVC_P_RULE_WIDE_WEIGHTS { { 6048, -127, -5256, 95, 876, 1134, 2120, 630, 1548, -447236 }, \
+                                    { 1152, -30, -842, -103, 866, 1285, 415, -455, -48, 19539 },     \
+                                    { 255, 36, -3, 16, 643, 1206, 0, -243, -177, 342124 } }
+
 // ---- adaptive-QP pre-analysis (k_preanalyze.hip) -----------------------------------------------------------
 // d_activity: per frame parts_per_frame doubles, layers concatenated (layer d: ceil(H/P) x ceil(W/P), P = 64 >> d)
 hipError_t fhevc_launch_preanalyze(const FhevcFrames& fr, int layers, long long parts_per_frame, double* d_activity,

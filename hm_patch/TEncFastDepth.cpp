@@ -53,7 +53,7 @@ void TEncFastDepth::readKnobs()
   const char* pc = std::getenv("FHEVC_P_MC");
   m_pMotionCompensated = pc != NULL ? std::atoi(pc) != 0 : m_pRange > 8;
 #ifndef FHEVC_HOOK_NO_GPU
-  fhevc_p_rule_default(P_RULE);
+  if (m_pRange > 8) fhevc_p_rule_default_wide(P_RULE); else fhevc_p_rule_default(P_RULE);
   const char* pt = std::getenv("FHEVC_P_THRESH");   // "split64,split32,split16,stop64,stop32,stop16" in score units (1.0 = 2^18)
   if (pt != NULL)
   {

@@ -254,6 +254,9 @@ typedef struct {
   int32_t window;
 } fhevc_p_rule;
 void fhevc_p_rule_default(fhevc_p_rule* rule);   /* the shipped rule (fitted on the reference's own P-picture decisions) */
+/* the same rule fitted on SAD-mode features of the +-64 search with the reference picture's depths taken at the motion-compensated position
+ * (fhevc_p_motion_compensated_depth): what goes with search ranges above 8 */
+void fhevc_p_rule_default_wide(fhevc_p_rule* rule);
 int  fhevc_p_depth_range(const fhevc_motion_node* nodes /* 85 */, const uint8_t* prev_depth /* 256, raster */, int valid_w,
                          int valid_h, int qp, const fhevc_p_rule* rule, uint8_t* depth_min /* 256 */, uint8_t* depth_max /* 256 */);
 

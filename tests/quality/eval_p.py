@@ -41,9 +41,22 @@ def load_p():
 
 
 SPEED = 3  # px / frame of the clip's two overlaid motions (--speed; 3 = the pinned clip)
+CLIP = "overlaid"   # --clip global: ONE motion -- a hetero picture panned by (SPEED, SPEED / 2) samples per picture with a little sensor noise,
+                    # the case "inter-CU depth reuse through the motion" is made for (overlaid: two transparent motions in opposite directions,
+                    # which no single vector per CU compensates)
 
 
 def pan_clip(W, H, nframes=2, seed=1234):
+    if CLIP == "global":
+        rng = np.random.default_rng(seed)
+        px, py = 8 + nframes * abs(SPEED), 8 + nframes * (abs(SPEED) // 2)
+        big = frames.hetero_luma(W + 2 * px, H + 2 * py, seed=seed)
+        out = []
+        for f in range(nframes):
+            x0, y0 = px + SPEED * f, py + (SPEED // 2) * f
+            y = big[y0:y0 + H, x0:x0 + W].astype(np.float64) + rng.normal(0, 0.7, size=(H, W)) + 0.4 * f
+            out.append(np.clip(np.rint(y), 0, 255).astype(np.uint8))
+        return out
     return frames.pan_clip(W, H, nframes, seed, v_structure=SPEED, v_noise=SPEED)
 
 
@@ -134,8 +147,8 @@ def encode_seq(lib, ys, qp, window=None, cnn=None, motion=None):
 
 def _run_qp(job):
     """one slice QP: the anchor (unrestricted search) and every variant; runs in its own process (HM is single-threaded)"""
-    global SPEED
-    qp, variants, (W, H), nframes, SPEED = job
+    global SPEED, CLIP
+    qp, variants, (W, H), nframes, SPEED, CLIP = job
     from oracle import oracle_py as op
     from fasthevc_amd import capi
     lib, oracle = load_p(), op.load_oracle()
@@ -180,6 +193,7 @@ def main():
     ap.add_argument("--json", default=None)
     ap.add_argument("--variants", default=None, help="JSON: {name: {kind: window|rule, window: ..., t_split: [3], t_stop: [3]}}")
     ap.add_argument("--workers", type=int, default=4)
+    ap.add_argument("--clip", default="overlaid", choices=("overlaid", "global"), help="overlaid: the pinned clip's two opposite motions; global: one pan of a hetero picture")
     ap.add_argument("--speed", type=int, default=3, help="px / frame of the clip's motions (beyond the search range: what the rule does when the source-only search cannot reach the true motion)")
     args = ap.parse_args()
     from multiprocessing import Pool
@@ -187,10 +201,10 @@ def main():
     variants = json.loads(args.variants) if args.variants else DEFAULT_VARIANTS
     qps = (22, 27, 32, 37)
     with Pool(args.workers) as pool:
-        res = dict(pool.map(_run_qp, [(qp, variants, (W, H), args.frames, args.speed) for qp in qps]))
+        res = dict(pool.map(_run_qp, [(qp, variants, (W, H), args.frames, args.speed, args.clip) for qp in qps]))
     ra, pa = [res[q]["anchor"][0] for q in qps], [res[q]["anchor"][1] for q in qps]
     ta = sum(res[q]["anchor"][2] for q in qps)
-    report = {"clip": f"{W}x{H} pan clip (frames.pan_clip, {args.speed} px / frame), {args.frames} frames I P P ..., P pictures at QP + 6; restricted pictures: POC >= 2 "
+    report = {"clip": f"{W}x{H} {'pan clip (frames.pan_clip: two overlaid opposite motions' if args.clip == 'overlaid' else 'hetero picture under ONE global pan ('}, {args.speed} px / frame), {args.frames} frames I P P ..., P pictures at QP + 6; restricted pictures: POC >= 2 "
                       "(their reference picture is a P picture); decision stage: bits counted by encodeCtu, luma PSNR before the in-loop filters",
               "qp": list(qps), "anchor": [res[q]["anchor"] for q in qps], "pictures": [res[q]["pictures"] for q in qps], "variants": {}, "summary": {}}
     for name, v in variants.items():

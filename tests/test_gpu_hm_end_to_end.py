@@ -130,7 +130,7 @@ def test_config4_p_pictures_driven_by_the_gpu_motion_search(oracle, size, rng, s
     cpu, gpu = _load_p(P_SO), _load_p(PGPU_SO)
     n, cw = (W // 64) * (H // 64), W // 64
     u = np.full((H // 2, W // 2), 128, np.int16)
-    rule = op.PRule.from_buffer_copy(bytes(capi.p_rule_default()))
+    rule = op.PRule.from_buffer_copy(bytes(capi.p_rule_default_wide() if rng > 8 else capi.p_rule_default()))   # as the hook picks it
     saved = {k: os.environ.get(k) for k in P_KNOBS}
     try:
         for k in P_KNOBS:
