@@ -49,9 +49,10 @@ void TEncFastDepth::readKnobs()
   if (m_pRange < 1) m_pRange = 1;
   if (m_pRange > 64) m_pRange = 64;   // above 8: HM's own integer search (SAD, xPatternSearch) over the window, 8-bit content (fasthevc.h)
   // FHEVC_P_MC=1: the reference picture's depths are taken where the motion search says the content came from
-  // (fhevc_p_motion_compensated_depth) instead of co-located; the default for search ranges above 8, where content moves by more than a CU
+  // (fhevc_p_motion_compensated_depth) instead of co-located.  Off by default: measured, a displaced map is no longer
+  // aligned to the CU grid and decides worse than the co-located one even under a global pan of 32 samples per picture
   const char* pc = std::getenv("FHEVC_P_MC");
-  m_pMotionCompensated = pc != NULL ? std::atoi(pc) != 0 : m_pRange > 8;
+  m_pMotionCompensated = pc != NULL && std::atoi(pc) != 0;
 #ifndef FHEVC_HOOK_NO_GPU
   if (m_pRange > 8) fhevc_p_rule_default_wide(P_RULE); else fhevc_p_rule_default(P_RULE);
   const char* pt = std::getenv("FHEVC_P_THRESH");   // "split64,split32,split16,stop64,stop32,stop16" in score units (1.0 = 2^18)

@@ -101,6 +101,11 @@ def motion_ranges(oracle, rule, cur, ref, prev_depth, qp, search_range=4, dist=0
     if mc:  # "inter-CU depth reuse" through the motion: the depths at the displaced position instead of the co-located ones
         prev = mc_depth(oracle, nodes, prev, W, H)
     if window_only is not None:  # no rule: the (motion-compensated) depths +- a window
+        if len(window_only) > 2:  # block form: [min, max] of the depths inside each 16x16 block +- the window (a displaced map is not aligned to the CU grid)
+            b = prev.reshape(n, 4, 4, 4, 4).astype(int)
+            lo = np.broadcast_to(b.min(axis=(2, 4), keepdims=True), b.shape).reshape(n, 256)
+            hi = np.broadcast_to(b.max(axis=(2, 4), keepdims=True), b.shape).reshape(n, 256)
+            return np.clip(lo - window_only[0], 0, 3).astype(np.uint8), np.clip(hi + window_only[1], 0, 3).astype(np.uint8)
         return np.clip(prev.astype(int) - window_only[0], 0, 3).astype(np.uint8), np.clip(prev.astype(int) + window_only[1], 0, 3).astype(np.uint8)
     for c in range(n):
         vw, vh = min(64, W - (c % cw) * 64), min(64, H - (c // cw) * 64)

@@ -171,7 +171,7 @@ def test_config4_p_pictures_driven_by_the_gpu_motion_search(oracle, size, rng, s
         # TEncFastDepth reads the I-picture knobs when the encoder object of a geometry is built: build it before FHEVC_ENABLE is
         # set, so that POC 0 runs stock RDO in both builds; the P pictures re-read the knobs (href_rdo_encode_next_p)
         op.rdo_encode(gpu, buf, org, stride, W, H, 8, QPI, chroma=(u, u))
-        os.environ.update({"FHEVC_P_MODE": "motion", "FHEVC_ENABLE": "1", "FHEVC_WEIGHTS": BLOB, "FHEVC_P_RANGE": str(rng)})
+        os.environ.update({"FHEVC_P_MODE": "motion", "FHEVC_ENABLE": "1", "FHEVC_WEIGHTS": BLOB, "FHEVC_P_RANGE": str(rng), "FHEVC_P_MC": "1" if wide else "0"})
         gpu_maps, gpu_bits = run(gpu, False)
         for f in range(4):
             assert np.array_equal(gpu_maps[f], ref_maps[f]), f
