@@ -24,7 +24,7 @@ SYMBOLS = [
     "fhevc_enable_kernel_timing", "fhevc_get_stats", "fhevc_last_error", "fhevc_version",
     "fhevc_expand_depth_flags_device", "fhevc_aq_parts", "fhevc_preanalyze", "fhevc_preanalyze_frames_device", "fhevc_aq_qp", "fhevc_intra_first_pass_device",
     "fhevc_predict_frame_range", "fhevc_predict_frames_device_range",
-    "fhevc_motion_search", "fhevc_motion_search_device", "fhevc_intra_first_pass_all", "fhevc_p_rule_default", "fhevc_p_rule_default_wide", "fhevc_p_depth_range", "fhevc_p_motion_compensated_depth",
+    "fhevc_motion_search", "fhevc_motion_search_device", "fhevc_intra_first_pass_all", "fhevc_intra_first_pass_candidates", "fhevc_p_rule_default", "fhevc_p_rule_default_wide", "fhevc_p_depth_range", "fhevc_p_motion_compensated_depth",
     "fhevc_predict_frames", "fhevc_alloc_host", "fhevc_free_host", "fhevc_set_cnn_arith", "fhevc_get_cnn_arith", "fhevc_set_motion_distortion", "fhevc_read_yuv_luma",
 ]
 CNN_ARITH = {"i8": 8, "f16": 16}
@@ -107,6 +107,7 @@ def load_library(path=None):
     lib.fhevc_satd.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32)]
     lib.fhevc_intra_first_pass.argtypes = [vp, vp, C.c_int, C.c_int, vp]
     lib.fhevc_intra_first_pass_all.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
+    lib.fhevc_intra_first_pass_candidates.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
     lib.fhevc_intra_first_pass_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_int,
                                                   C.c_int, vp, vp]
     lib.fhevc_predict_frames_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_int,
@@ -349,6 +350,14 @@ class Context:
         allm = np.zeros(self.num_ctus * NODES_PER_CTU * 35, NODE_DTYPE)
         self._check(self.lib.fhevc_intra_first_pass_all(self.h, flat.ctypes.data + 2 * origin, stride, qp, best.ctypes.data, allm.ctypes.data))
         return best.reshape(self.num_ctus, NODES_PER_CTU), allm.reshape(self.num_ctus, NODES_PER_CTU, 35)
+
+    def intra_first_pass_candidates(self, plane, origin=0, stride=None, qp=32, num_candidates=8):
+        """[numCtus, 85, num_candidates] uint8: per node the modes of smallest first-pass cost, best first (HM's candidate list)"""
+        flat = np.ascontiguousarray(plane).reshape(-1)
+        stride = stride if stride is not None else plane.shape[-1]
+        out = np.zeros(self.num_ctus * NODES_PER_CTU * num_candidates, np.uint8)
+        self._check(self.lib.fhevc_intra_first_pass_candidates(self.h, flat.ctypes.data + 2 * origin, stride, qp, num_candidates, out.ctypes.data))
+        return out.reshape(self.num_ctus, NODES_PER_CTU, num_candidates)
 
     def aq_layout(self, max_aq_depth):
         """Offsets of the AQ layers in the concatenated activity array (max_aq_depth + 1 entries)."""

@@ -1115,6 +1115,28 @@ int fhevc_intra_first_pass_all(fhevc_ctx* c, const int16_t* luma, int stride_sam
   return rc;
 }
 
+// The consumer of the first pass: HM prunes the 35 modes of a PU to numModesForFullRD candidates with exactly these costs
+// (TEncSearch::estIntraPredLumaQT, TEncSearch.cpp:2271-2320, xUpdateCandList :5385-5408: the N smallest costs, an earlier mode ahead of a later
+// one of the same cost).  modes: numCtus * 85 * num_candidates, best first; 255 in every slot of a node that crosses the picture edge.
+int fhevc_intra_first_pass_candidates(fhevc_ctx* c, const int16_t* luma, int stride_samples, int qp, int num_candidates, uint8_t* modes)
+{
+  if (!c || !luma || !modes || num_candidates < 1 || num_candidates > 35) return FHEVC_E_INVALID;
+  const size_t nodes = (size_t)c->num_ctus * FHEVC_NODES_PER_CTU;
+  std::vector<fhevc_node_cost> all(nodes * 35);
+  const int rc = fhevc_intra_first_pass_all(c, luma, stride_samples, qp, nullptr, all.data());
+  if (rc != FHEVC_OK) return rc;
+  for (size_t n = 0; n < nodes; ++n) {
+    const fhevc_node_cost* a = &all[n * 35];
+    uint8_t* out = modes + n * num_candidates;
+    if (a[0].satd == 0xFFFFFFFFu) { std::memset(out, 255, (size_t)num_candidates); continue; }
+    int order[35];
+    for (int m = 0; m < 35; ++m) order[m] = m;
+    std::stable_sort(order, order + 35, [&](int x, int y) { return a[x].cost < a[y].cost; });
+    for (int k = 0; k < num_candidates; ++k) out[k] = (uint8_t)order[k];
+  }
+  return FHEVC_OK;
+}
+
 int fhevc_aq_parts(int width, int height, int max_aq_depth, long long* layer_offsets)
 {
   if (width <= 0 || height <= 0 || max_aq_depth < 1 || max_aq_depth > 4) return FHEVC_E_INVALID;

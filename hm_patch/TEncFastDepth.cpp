@@ -17,7 +17,8 @@ static_assert(sizeof(fhevc_p_rule) == 37 * sizeof(int), "TEncFastDepth::m_pRule 
 #endif
 
 TEncFastDepth::TEncFastDepth()
-  : m_enabled(false), m_valid(false), m_external(false), m_cachePic(NULL), m_cachePoc(-1), m_cacheQp(-1), m_cacheType(-1), m_cacheFp(0), m_ctx(NULL), m_width(0), m_height(0), m_bitDepth(0), m_marginSplit(0), m_marginStop(0), m_pWindow(1), m_pMode(P_OFF), m_pRange(4)
+  : m_enabled(false), m_valid(false), m_external(false), m_cachePic(NULL), m_cachePoc(-1), m_cacheQp(-1), m_cacheType(-1), m_cacheFp(0), m_ctx(NULL), m_width(0), m_height(0), m_bitDepth(0), m_marginSplit(0), m_marginStop(0), m_pWindow(1), m_pMode(P_OFF), m_pRange(4),
+    m_pMotionCompensated(false), m_firstPass(false), m_candValid(false), m_candExternal(false)
 {
   readKnobs();
 }
@@ -37,6 +38,8 @@ void TEncFastDepth::readKnobs()
   m_marginStop  = mt ? std::atoi(mt) : (mg ? std::atoi(mg) : 64000);
   if (m_marginSplit < 0) m_marginSplit = 0;
   if (m_marginStop < 0) m_marginStop = 0;
+  const char* fpk = std::getenv("FHEVC_FIRST_PASS");
+  m_firstPass = fpk != NULL && std::atoi(fpk) != 0;
   const char* pw = std::getenv("FHEVC_P_WINDOW");
   const char* pm = std::getenv("FHEVC_P_MODE");
   m_pWindow = pw ? std::atoi(pw) : 1;
@@ -84,8 +87,33 @@ void TEncFastDepth::setExternalRange(const unsigned char* mapMin, const unsigned
   }
 }
 
+TEncFastDepth* TEncFastDepth::s_active = NULL;
+
+void TEncFastDepth::setExternalCandidates(const unsigned char* cand, int numCtus)
+{
+  m_candExternal = cand != NULL;
+  if (m_candExternal) m_cand.assign(cand, cand + (size_t)numCtus * 85 * 8);
+  s_active = this;
+}
+
+bool TEncFastDepth::candidateList(unsigned ctuRsAddr, int xInCtu, int yInCtu, int size, int numModes, unsigned* list)
+{
+  const TEncFastDepth* f = s_active;
+  if (f == NULL || !(f->m_candExternal || f->m_candValid) || numModes < 1 || numModes > 8) return false;
+  int lvl, first;
+  switch (size) { case 64: lvl = 0; first = 0; break; case 32: lvl = 1; first = 1; break; case 16: lvl = 2; first = 5; break; case 8: lvl = 3; first = 21; break; default: return false; }
+  if ((xInCtu | yInCtu) < 0 || xInCtu + size > 64 || yInCtu + size > 64 || (xInCtu % size) != 0 || (yInCtu % size) != 0) return false;
+  const size_t node = (size_t)ctuRsAddr * 85 + first + (size_t)(yInCtu / size) * (1 << lvl) + xInCtu / size;
+  if ((node + 1) * 8 > f->m_cand.size()) return false;
+  const unsigned char* c = &f->m_cand[node * 8];
+  if (c[0] > 34) return false;   // 255: the node crosses the picture edge
+  for (int i = 0; i < numModes; i++) list[i] = c[i];
+  return true;
+}
+
 bool TEncFastDepth::predictPicture(TComPic* pcPic, int sliceQp, int sliceType)
 {
+  s_active = this;
   if (m_external) return true;       // validation feed wins
   // cheap early-outs first: pictures this hook can do nothing for never pay for the fingerprint below
   // the depth-map layout (16x16 units of a 64x64 CTU, depths 0..3) is what the library produces and forcedRange() reads:
@@ -96,7 +124,7 @@ bool TEncFastDepth::predictPicture(TComPic* pcPic, int sliceQp, int sliceType)
 #ifdef FHEVC_HOOK_NO_GPU
   if (sliceType == I_SLICE || m_pMode != P_WINDOW) possible = false;   // the CPU-test build of the hook has the temporal window only
 #endif
-  if (!possible) { m_valid = false; m_cachePic = NULL; return false; }
+  if (!possible) { m_valid = false; m_candValid = false; m_cachePic = NULL; return false; }
   // compressSlice runs once per slice and once more per precompressSlice iteration (DeltaQpRD): the map of a picture is
   // computed once per (picture object, POC, slice QP, slice type, fingerprint of the original luma) and kept.  The fingerprint
   // (FNV-1a over EVERY luma sample: ~2 M multiplies per 1080p picture, nothing beside HM's seconds per picture) tells a recycled
@@ -111,6 +139,7 @@ bool TEncFastDepth::predictPicture(TComPic* pcPic, int sliceQp, int sliceType)
   }
   if (m_valid && pcPic == m_cachePic && pcPic->getPOC() == m_cachePoc && sliceQp == m_cacheQp && sliceType == m_cacheType && fp == m_cacheFp) return true;
   m_valid = false;
+  m_candValid = false;
   m_cachePic = pcPic; m_cachePoc = pcPic->getPOC(); m_cacheQp = sliceQp; m_cacheType = sliceType; m_cacheFp = fp;
   if (sliceType != I_SLICE)
   {
@@ -193,6 +222,13 @@ bool TEncFastDepth::predictPicture(TComPic* pcPic, int sliceQp, int sliceType)
   {
     std::fprintf(stderr, "[fasthevc] picture falls back to full RDO: %s\n", fhevc_last_error(m_ctx));
     return false;
+  }
+  if (m_firstPass)
+  {
+    // the candidate lists of estIntraPredLumaQT for every node of the picture, from the same original plane (one more kernel + 85 x 8 bytes per CTU)
+    m_cand.resize((size_t)pcPic->getNumberOfCtusInFrame() * 85 * 8);
+    if (fhevc_intra_first_pass_candidates(m_ctx, org->getAddr(COMPONENT_Y), org->getStride(COMPONENT_Y), sliceQp, 8, &m_cand[0]) == FHEVC_OK) m_candValid = true;
+    else std::fprintf(stderr, "[fasthevc] first-pass candidates unavailable (HM's own pass runs): %s\n", fhevc_last_error(m_ctx));
   }
   m_valid = true;
   return true;

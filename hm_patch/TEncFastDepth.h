@@ -20,6 +20,9 @@
  *                             FHEVC_ENABLE); motion = GPU motion search of every CU node in the reference's ORIGINAL picture
  *                             (FHEVC_P_RANGE = window radius 1..64, default 4; above 8: SAD search + FHEVC_P_MC depths at the motion-compensated position) + fhevc_p_depth_range (needs FHEVC_ENABLE=1);
  *                             FHEVC_P_THRESH overrides the six thresholds of the rule, FHEVC_P_WINDOW adds the +- clip to it
+ *   FHEVC_FIRST_PASS=1        intra pictures: the candidate list of TEncSearch::estIntraPredLumaQT (the numModesForFullRD modes its 35-mode
+ *                             Hadamard pass would pick) comes from the GPU's first pass over the ORIGINAL picture for PUs of 8x8 and larger
+ *                             (fhevc_intra_first_pass_candidates); HM's own 35-mode loop is skipped for them, its MPM handling stays
  */
 #ifndef __TENCFASTDEPTH__
 #define __TENCFASTDEPTH__
@@ -46,6 +49,11 @@ public:
   void setExternalMap(const unsigned char* map, int numCtus) { setExternalRange(map, map, numCtus); }
   void setExternalRange(const unsigned char* mapMin, const unsigned char* mapMax, int numCtus);
   const std::vector<unsigned char>& depthMap() const { return m_depth; }
+  /// first-pass candidate lists from another source (validation harness): numCtus * 85 * 8 modes, best first; NULL clears
+  void setExternalCandidates(const unsigned char* cand, int numCtus);
+  /// the candidate list of the square PU of `size` samples at (xInCtu, yInCtu) of CTU ctuRsAddr: numModes (<= 8) modes into list;
+  /// false -> no list (HM runs its own 35-mode pass).  Static: TEncSearch has no path to the TEncCu that owns the instance
+  static bool candidateList(unsigned ctuRsAddr, int xInCtu, int yInCtu, int size, int numModes, unsigned* list);
 
 private:
   bool       m_enabled, m_valid, m_external;
@@ -57,6 +65,9 @@ private:
   enum PMode { P_OFF, P_WINDOW, P_MOTION };
   int        m_pMode, m_pRange;
   bool       m_pMotionCompensated;  ///< reference depths taken at the motion-compensated position (FHEVC_P_MC)
+  bool       m_firstPass, m_candValid, m_candExternal;   ///< FHEVC_FIRST_PASS; m_cand holds this picture's lists; lists fed by a harness
+  std::vector<unsigned char> m_cand;    // numCtus * 85 * 8: the eight cheapest modes per node, best first (255: node crosses the picture edge)
+  static TEncFastDepth* s_active;       // the instance whose lists candidateList() reads: the one predictPicture() ran on last
   int        m_pRule[37];                     // fhevc_p_rule (include/fasthevc.h), kept opaque so that this header needs no library header
   bool       ensureContext(TComPic* pcPic);   // (re-)create the GPU context for this picture geometry
   std::vector<unsigned char> m_depth;     // numCtus * 256, raster 16x16 per CTU: depth_min

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Apply the fast-depth hook to a copy of HM-16.14's TEncCu.h / TEncCu.cpp / TEncSlice.cpp.
+"""Apply the fast-depth hook to a copy of HM-16.14's TEncCu.h / TEncCu.cpp / TEncSlice.cpp / TEncSearch.cpp.
 
 usage: apply_hook.py <TLibEncoder dir of the HM tree> <output dir>
-Reads the three files, inserts the lines below at anchors (regular expressions over HM's own identifiers) and writes
+Reads the four files, inserts the lines below at anchors (regular expressions over HM's own identifiers) and writes
 the patched copies to <output dir>; nothing else of HM is touched.  The script carries no HM source text.
 """
 import os
@@ -42,6 +42,20 @@ def patch_cu_cpp(s):
     return s
 
 
+def patch_search_cpp(s):
+    # the candidate list of estIntraPredLumaQT from the GPU's first pass (FHEVC_FIRST_PASS): HM's own 35-mode Hadamard loop runs only where
+    # no list exists (PUs of 4x4, nodes crossing the picture edge, library off); its MPM handling after the loop stays as it is
+    s = sub_once(s, r'(#include "TEncSearch.h"\n)', r'\1#include "TEncFastDepth.h"\n', "TEncSearch.cpp include")
+    s = sub_once(s, r'^(\s*)for\( Int modeIdx = 0; modeIdx < numModesAvailable; modeIdx\+\+ \)\n',
+                 r'\1const Bool bGpuList = puRect.width == puRect.height && puRect.width >= 8 &&\n'
+                 r'\1  TEncFastDepth::candidateList( pcCU->getCtuRsAddr(), Int(pcCU->getCUPelX() & 63) + Int(puRect.x0), Int(pcCU->getCUPelY() & 63) + Int(puRect.y0),\n'
+                 r'\1                                Int(puRect.width), numModesForFullRD, uiRdModeList );\n'
+                 r'\1if ( bGpuList ) CandNum = numModesForFullRD;\n'
+                 r'\1for( Int modeIdx = 0; !bGpuList && modeIdx < numModesAvailable; modeIdx++ )\n',
+                 "first-pass mode loop")
+    return s
+
+
 def patch_slice_cpp(s):
     # once per picture, before the CTU loop of compressSlice
     s = sub_once(s, r'(^\s*m_pcCuEncoder->setFastDeltaQp\(bFastDeltaQP\);\n)',
@@ -53,12 +67,14 @@ def patch_slice_cpp(s):
 def main():
     src, dst = sys.argv[1], sys.argv[2]
     os.makedirs(dst, exist_ok=True)
-    for name, fn in (("TEncCu.h", patch_cu_h), ("TEncCu.cpp", patch_cu_cpp), ("TEncSlice.cpp", patch_slice_cpp)):
+    for name, fn in (("TEncCu.h", patch_cu_h), ("TEncCu.cpp", patch_cu_cpp), ("TEncSlice.cpp", patch_slice_cpp), ("TEncSearch.cpp", patch_search_cpp)):
+        if not os.path.exists(os.path.join(src, name)) and name == "TEncSearch.cpp":
+            continue   # a staging directory that holds only the files another patch touched: the caller passes TEncSearch.cpp separately
         with open(os.path.join(src, name)) as f:
             text = f.read()
         with open(os.path.join(dst, name), "w") as f:
             f.write(fn(text))
-    print("patched TEncCu.h TEncCu.cpp TEncSlice.cpp ->", dst)
+    print("patched TEncCu.h TEncCu.cpp TEncSlice.cpp TEncSearch.cpp ->", dst)
 
 
 if __name__ == "__main__":

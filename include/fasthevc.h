@@ -146,6 +146,13 @@ int  fhevc_intra_first_pass(fhevc_ctx* ctx, const int16_t* luma, int stride_samp
 int  fhevc_intra_first_pass_all(fhevc_ctx* ctx, const int16_t* luma, int stride_samples, int qp, fhevc_node_cost* best,
                                 fhevc_node_cost* all);
 
+/* What HM's own first pass is for: the candidate list of estIntraPredLumaQT (TEncSearch.cpp:2271-2320).  Per node the num_candidates (HM: 8 for
+ * 8x8 PUs, 3 above; up to 35) modes of smallest cost, best first, an earlier mode ahead of a later one of equal cost (xUpdateCandList,
+ * TEncSearch.cpp:5385-5408); modes: numCtus * 85 * num_candidates bytes, 255 for nodes crossing the picture edge.  The costs come from ORIGINAL
+ * neighbours (HM's own pass sees reconstructed ones inside its serial loop) and the mode-bit model of fhevc_intra_first_pass; HM still appends its
+ * most-probable modes itself.  hm_patch: FHEVC_FIRST_PASS=1. */
+int  fhevc_intra_first_pass_candidates(fhevc_ctx* ctx, const int16_t* luma, int stride_samples, int qp, int num_candidates, uint8_t* modes);
+
 /* first pass over a device-resident batch (layout and band arguments as fhevc_predict_frames_device below);
  * d_out: (num_frames * band CTUs) * 85 entries in HBM.  Asynchronous with respect to the host. */
 int  fhevc_intra_first_pass_device(fhevc_ctx* ctx, const void* d_luma, int sample_bytes, int stride_samples,

@@ -489,6 +489,35 @@ void fho_first_pass_ctu(const int16_t* luma, int stride, int width, int height,
   }
 }
 
+/* the candidate lists HM's first pass exists for (include/fasthevc.h: fhevc_intra_first_pass_candidates; TEncSearch.cpp:2271-2320, xUpdateCandList
+ * :5385-5408): per node the num modes of smallest cost, best first, an earlier mode ahead of a later one of equal cost; 255 = node crosses the edge */
+void fho_first_pass_candidates_ctu(const int16_t* luma, int stride, int width, int height, int ctu_x, int ctu_y, int bit_depth,
+                                   double sqrt_lambda, int num, uint8_t* modes /* 85 * num */)
+{
+  int idx = 0;
+  for (int lvl = 0; lvl < 4; lvl++) {
+    int n = CTU >> lvl, cnt = 1 << lvl;
+    for (int by = 0; by < cnt; by++)
+      for (int bx = 0; bx < cnt; bx++, idx++) {
+        int x0 = ctu_x * CTU + bx * n, y0 = ctu_y * CTU + by * n;
+        uint8_t* out = modes + idx * num;
+        if (x0 + n > width || y0 + n > height) { memset(out, 255, (size_t)num); continue; }
+        fho_node_cost best;
+        uint32_t satd[35];
+        double cost[35];
+        int order[35];
+        fho_first_pass_node(luma, stride, width, height, x0, y0, n, bit_depth, sqrt_lambda, &best, satd);
+        for (int m = 0; m < 35; m++) { cost[m] = (double)satd[m] + (double)mode_bits_default_mpm(m) * sqrt_lambda; order[m] = m; }
+        for (int i = 1; i < 35; i++) {   /* stable insertion sort */
+          int v = order[i], j = i - 1;
+          while (j >= 0 && cost[order[j]] > cost[v]) { order[j + 1] = order[j]; j--; }
+          order[j + 1] = v;
+        }
+        for (int k = 0; k < num; k++) out[k] = (uint8_t)order[k];
+      }
+  }
+}
+
 /* ------------------------------------------------------------------------------------------
  * A13 / N4: source-only integer motion search per CU node (config 4).  Search loop as TEncSearch::xPatternSearch
  * (TEncSearch.cpp:3786-3848): y outer, x inner, strict "<"; vector cost as TComRdCost::getCostOfVectorWithPredictor

@@ -100,6 +100,10 @@ void fho_first_pass_node(const int16_t* luma, int stride, int width, int height,
 void fho_first_pass_ctu(const int16_t* luma, int stride, int width, int height,
                         int ctu_x, int ctu_y, int bit_depth, double sqrt_lambda, fho_node_cost out[85]);
 
+/* per node the num modes of smallest first-pass cost, best first (fhevc_intra_first_pass_candidates); modes: 85 * num, 255 = node crosses the edge */
+void fho_first_pass_candidates_ctu(const int16_t* luma, int stride, int width, int height, int ctu_x, int ctu_y, int bit_depth,
+                                   double sqrt_lambda, int num, uint8_t* modes);
+
 /* ---- A13 / N4 (config 4): source-only motion search per CU node -------------------------------
  * Twin of the integer full search TEncSearch::xPatternSearch (TEncSearch.cpp:3786-3848: raster order over the window,
  * strict "<", cost = distortion + TComRdCost::getCostOfVectorWithPredictor, TComRdCost.h:166-174) with the Hadamard

@@ -255,7 +255,7 @@ def split_costs(lib, num_ctus):
     return out.reshape(num_ctus, 21, 2)
 
 
-def rdo_encode(lib, plane, origin, stride, width, height, bit_depth, qp, forced_depth=None, chroma=None, forced_depth_max=None):
+def rdo_encode(lib, plane, origin, stride, width, height, bit_depth, qp, forced_depth=None, chroma=None, forced_depth_max=None, candidates=None):
     """-> (depth [numCtus,256] uint8, stats dict).  plane: int16 Pel buffer; chroma: optional (cb, cr) int16 arrays
     [H/2, W/2] at the internal bit depth (default: flat mid-grey)."""
     n = ((width + 63) // 64) * ((height + 63) // 64)
@@ -273,6 +273,12 @@ def rdo_encode(lib, plane, origin, stride, width, height, bit_depth, qp, forced_
         lib.href_rdo_set_forced_max.argtypes = [C.c_void_p]
         if lib.href_rdo_set_forced_max(C.c_void_p(fdmax.ctypes.data)) != 0:
             raise RuntimeError("soft hook needs the hook build of the reference library")
+    if candidates is not None:  # first-pass candidate lists [numCtus, 85, 8] for the hook's estIntraPredLumaQT patch
+        cand = np.ascontiguousarray(candidates, np.uint8).reshape(-1)
+        assert cand.size == n * 85 * 8
+        lib.href_rdo_set_candidates.argtypes = [C.c_void_p]
+        if lib.href_rdo_set_candidates(C.c_void_p(cand.ctypes.data)) != 0:
+            raise RuntimeError("candidate lists need the hook build of the reference library")
     if chroma is not None:
         cb, cr = (np.ascontiguousarray(c, np.int16) for c in chroma)
         assert cb.shape == (height // 2, width // 2) and cr.shape == cb.shape

@@ -344,6 +344,20 @@ int href_rdo_set_forced_max(const uint8_t* depth_max)
 #endif
 }
 
+// first-pass candidate lists (numCtus * 85 * 8 modes, best first) for the NEXT encode call: the hook's estIntraPredLumaQT patch reads them instead of
+// running HM's 35-mode pass (TEncFastDepth::setExternalCandidates); hook builds only, one-shot
+static const uint8_t* g_candidates = nullptr;
+int href_rdo_set_candidates(const uint8_t* cand)
+{
+#ifdef FHEVC_HOOK
+  g_candidates = cand;
+  return 0;
+#else
+  (void)cand;
+  return -2;
+#endif
+}
+
 int href_rdo_encode_frame(const int16_t* luma, int stride, int width, int height, int bit_depth, int qp,
                           const uint8_t* forced_depth, uint8_t* depth_out, double* stats)
 {
@@ -363,6 +377,8 @@ int href_rdo_encode_frame_yuv(const int16_t* luma, int stride, const int16_t* cb
   if (forced_depth && g_forced_max) e->cu.getFastDepth().setExternalRange(forced_depth, g_forced_max, (int)e->pic->getNumberOfCtusInFrame());
   else e->cu.getFastDepth().setExternalMap(forced_depth, forced_depth ? (int)e->pic->getNumberOfCtusInFrame() : 0);
   g_forced_max = nullptr;  // one-shot
+  e->cu.getFastDepth().setExternalCandidates(g_candidates, (int)e->pic->getNumberOfCtusInFrame());
+  g_candidates = nullptr;
 #else
   if (forced_depth) return -2;
 #endif

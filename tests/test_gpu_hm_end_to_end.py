@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BLOB = os.path.join(ROOT, "fasthevc_amd", "weights", "depthnet_v2.fhw")   # the shipped blob
 GPU_SO = os.path.join(ROOT, "oracle", "_ref", "libhmref_hookgpu.so")
-KNOBS = ("FHEVC_ENABLE", "FHEVC_WEIGHTS", "FHEVC_MARGIN", "FHEVC_MARGIN_SPLIT", "FHEVC_MARGIN_STOP", "FHEVC_DEVICE", "FHEVC_DEVICES")
+KNOBS = ("FHEVC_ENABLE", "FHEVC_WEIGHTS", "FHEVC_MARGIN", "FHEVC_MARGIN_SPLIT", "FHEVC_MARGIN_STOP", "FHEVC_DEVICE", "FHEVC_DEVICES", "FHEVC_FIRST_PASS")
 QP = 32
 
 
@@ -25,6 +25,17 @@ def _picture(W, H):
     cu, cv = frames.chroma_planes("hetero", 1920, 1080)
     chroma = (cu[:H // 2, :W // 2].astype(np.int16), cv[:H // 2, :W // 2].astype(np.int16))
     return frames.to_pel_plane(luma, 8) + (chroma,)
+
+
+def _oracle_candidates(oracle, buf, org, stride, W, H):
+    """the first-pass candidate lists [numCtus, 85, 8] from the CPU oracle (fhevc_intra_first_pass_candidates is bit-exact with it)"""
+    cw, n = W // 64, (W // 64) * (H // 64)
+    cand = np.zeros((n, 85, 8), np.uint8)
+    oracle.fho_first_pass_candidates_ctu.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p]
+    sl = oracle.fho_lambda_intra(QP, 8) ** 0.5
+    for c in range(n):
+        oracle.fho_first_pass_candidates_ctu(C.c_void_p(buf.reshape(-1).ctypes.data + 2 * org), stride, W, H, c % cw, c // cw, 8, C.c_double(sl), 8, cand[c].ctypes.data)
+    return cand
 
 
 def _oracle_maps(oracle, buf, org, stride, W, H, margin_split, margin_stop):
@@ -52,10 +63,13 @@ def test_reference_encoder_driven_by_the_gpu_library(oracle):
                                     ((576, 512), {"FHEVC_ENABLE": "1", "FHEVC_WEIGHTS": BLOB, "FHEVC_MARGIN_SPLIT": "32000", "FHEVC_MARGIN_STOP": "0"}, (32000, 0)),
                                     ((640, 448), {"FHEVC_ENABLE": "1", "FHEVC_WEIGHTS": BLOB, "FHEVC_MARGIN": "8000"}, (8000, 8000)),
                                     # a multi-device context behind the hook (FHEVC_DEVICES): CTU-row bands over two queues of the one MI355X here
-                                    ((896, 448), {"FHEVC_ENABLE": "1", "FHEVC_WEIGHTS": BLOB, "FHEVC_MARGIN": "8000", "FHEVC_DEVICES": "0,0"}, (8000, 8000))):
+                                    ((896, 448), {"FHEVC_ENABLE": "1", "FHEVC_WEIGHTS": BLOB, "FHEVC_MARGIN": "8000", "FHEVC_DEVICES": "0,0"}, (8000, 8000)),
+                                    # the first pass consumed: estIntraPredLumaQT takes its candidate lists from the GPU (FHEVC_FIRST_PASS)
+                                    ((960, 448), {"FHEVC_ENABLE": "1", "FHEVC_WEIGHTS": BLOB, "FHEVC_MARGIN": "8000", "FHEVC_FIRST_PASS": "1"}, (8000, 8000))):
             buf, org, stride, chroma = _picture(W, H)
             dmin, dmax = _oracle_maps(oracle, buf, org, stride, W, H, *margins)
-            d_ref, s_ref = op.rdo_encode(hook, buf, org, stride, W, H, 8, QP, forced_depth=dmin, forced_depth_max=dmax, chroma=chroma)
+            cand = _oracle_candidates(oracle, buf, org, stride, W, H) if env.get("FHEVC_FIRST_PASS") else None
+            d_ref, s_ref = op.rdo_encode(hook, buf, org, stride, W, H, 8, QP, forced_depth=dmin, forced_depth_max=dmax, chroma=chroma, candidates=cand)
             d_full, s_full = op.rdo_encode(hook, buf, org, stride, W, H, 8, QP, chroma=chroma)
             for k in KNOBS:
                 os.environ.pop(k, None)

@@ -433,3 +433,27 @@ def test_first_pass_all_35_modes_per_node(oracle, bd):
     # the winner is the first minimum of those costs
     assert np.array_equal(best["mode"][valid], allm["cost"][valid].argmin(axis=1).astype(np.uint32))
     ctx.close()
+
+
+def test_first_pass_candidate_lists_vs_oracle(oracle):
+    """fhevc_intra_first_pass_candidates (what HM's estIntraPredLumaQT consumes under FHEVC_FIRST_PASS=1): per node the eight modes of smallest
+    cost, best first, ties to the earlier mode -- against the oracle's lists, ragged picture, 8 and 10 bit; the head of every list is the
+    first pass's best mode."""
+    import ctypes as C
+    oracle.fho_first_pass_candidates_ctu.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p]
+    W, H = 416, 240
+    for bd, qp in ((8, 32), (10, 22)):
+        y = frames.hetero_luma(W, H, seed=40 + bd)
+        buf, org, stride = frames.to_pel_plane(y, bd)
+        ctx = capi.Context(W, H, bd)
+        got = ctx.intra_first_pass_candidates(buf, org, stride, qp=qp, num_candidates=8)
+        best = ctx.intra_first_pass(buf, org, stride, qp=qp)
+        cw, n = 7, 28
+        exp = np.zeros((n, 85, 8), np.uint8)
+        sl = oracle.fho_lambda_intra(qp, bd) ** 0.5
+        for c in range(n):
+            oracle.fho_first_pass_candidates_ctu(C.c_void_p(buf.reshape(-1).ctypes.data + 2 * org), stride, W, H, c % cw, c // cw, bd, C.c_double(sl), 8, exp[c].ctypes.data)
+        assert np.array_equal(got, exp)
+        inside = best["mode"] != 255
+        assert np.array_equal(got[..., 0][inside], best["mode"][inside].astype(np.uint8)) and (got[~inside] == 255).all()
+        ctx.close()
