@@ -57,6 +57,7 @@ struct fhevc_ctx {
   double* d_act = nullptr;
   int16_t* d_pair = nullptr;          // two staging planes (reference, current) of fhevc_motion_search
   FhevcMotionNode* d_motion = nullptr;
+  FhevcNodeCost* d_cand_all = nullptr; uint8_t* d_cand = nullptr;   // fhevc_intra_first_pass_candidates: every (node, mode) cost, the lists
   uint32_t* d_mvtab = nullptr;        // vector costs of the wide search (k_motion_wide.hip), rebuilt when (qp, range) changes
   int mvtab_qp = -1, mvtab_range = -1;
   std::vector<uint32_t> mvtab_host;
@@ -607,7 +608,7 @@ void fhevc_destroy(fhevc_ctx* c)
   (void)hipFree(c->d_frag); (void)hipFree(c->d_bias); (void)hipFree(c->d_whead); (void)hipFree(c->d_bhead);
   (void)hipFree(c->d_frag_i8); (void)hipFree(c->d_bias_i8);
   (void)hipFree(c->f_frag1); (void)hipFree(c->f_bias1); (void)hipFree(c->f_frag2); (void)hipFree(c->f_frag3); (void)hipFree(c->f_bias_i8); (void)hipFree(c->f_whead); (void)hipFree(c->f_headm); (void)hipFree(c->f_bhead);
-  (void)hipFree(c->d_luma); (void)hipFree(c->d_depth); (void)hipFree(c->d_had); (void)hipFree(c->d_nodes); (void)hipFree(c->d_satd); (void)hipFree(c->d_satd_out); (void)hipFree(c->d_act); (void)hipFree(c->d_depth_max); (void)hipFree(c->d_pair); (void)hipFree(c->d_motion); (void)hipFree(c->d_mvtab);
+  (void)hipFree(c->d_luma); (void)hipFree(c->d_depth); (void)hipFree(c->d_had); (void)hipFree(c->d_nodes); (void)hipFree(c->d_satd); (void)hipFree(c->d_satd_out); (void)hipFree(c->d_act); (void)hipFree(c->d_depth_max); (void)hipFree(c->d_pair); (void)hipFree(c->d_motion); (void)hipFree(c->d_mvtab); (void)hipFree(c->d_cand_all); (void)hipFree(c->d_cand);
   for (auto& sl : c->slot) {  // the host-batch ring of fhevc_predict_frames: stream, device buffers, pinned staging
     if (sl.st) { (void)hipStreamSynchronize(sl.st); (void)hipStreamDestroy(sl.st); }
     (void)hipFree(sl.d_in); (void)hipFree(sl.d_depth); (void)hipFree(sl.d_had);
@@ -1120,20 +1121,25 @@ int fhevc_intra_first_pass_all(fhevc_ctx* c, const int16_t* luma, int stride_sam
 // one of the same cost).  modes: numCtus * 85 * num_candidates, best first; 255 in every slot of a node that crosses the picture edge.
 int fhevc_intra_first_pass_candidates(fhevc_ctx* c, const int16_t* luma, int stride_samples, int qp, int num_candidates, uint8_t* modes)
 {
-  if (!c || !luma || !modes || num_candidates < 1 || num_candidates > 35) return FHEVC_E_INVALID;
+  if (!c || !luma || !modes || num_candidates < 1 || num_candidates > 8 || stride_samples < c->cfg.width || qp < 0 || qp > 51) return FHEVC_E_INVALID;
+  (void)hipSetDevice(c->device);
   const size_t nodes = (size_t)c->num_ctus * FHEVC_NODES_PER_CTU;
-  std::vector<fhevc_node_cost> all(nodes * 35);
-  const int rc = fhevc_intra_first_pass_all(c, luma, stride_samples, qp, nullptr, all.data());
+  if (!c->d_cand_all) HIP_TRY(c, hipMalloc(&c->d_cand_all, nodes * 35 * sizeof(FhevcNodeCost)));
+  if (!c->d_cand) HIP_TRY(c, hipMalloc(&c->d_cand, nodes * 8));
+  int rc = upload_frame(c, luma, stride_samples);
   if (rc != FHEVC_OK) return rc;
-  for (size_t n = 0; n < nodes; ++n) {
-    const fhevc_node_cost* a = &all[n * 35];
-    uint8_t* out = modes + n * num_candidates;
-    if (a[0].satd == 0xFFFFFFFFu) { std::memset(out, 255, (size_t)num_candidates); continue; }
-    int order[35];
-    for (int m = 0; m < 35; ++m) order[m] = m;
-    std::stable_sort(order, order + 35, [&](int x, int y) { return a[x].cost < a[y].cost; });
-    for (int k = 0; k < num_candidates; ++k) out[k] = (uint8_t)order[k];
-  }
+  const double sqrt_lambda = std::sqrt(0.57 * std::pow(2.0, ((double)qp - 12.0) / 3.0));
+  const FhevcFrames fr = frames_of(c, c->d_luma, 2, c->dev_stride, 0, 1, 0, c->ctus_y);
+  time_begin(c, c->stream, 2);
+  hipError_t e = fhevc_launch_first_pass(fr, sqrt_lambda, c->d_nodes, c->d_cand_all, c->stream);
+  time_end(c, c->stream);
+  // the sort runs on the device: 85 x K bytes per CTU come back instead of 85 x 35 x 16
+  if (e == hipSuccess) e = fhevc_launch_first_pass_topk(c->d_cand_all, (long long)nodes, num_candidates, c->d_cand, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(modes, c->d_cand, nodes * num_candidates, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (e != hipSuccess) return fail(c, FHEVC_E_HIP, "first-pass candidates", e);
+  c->stats.kernels_launched += 2;
+  c->stats.bytes_d2h += nodes * num_candidates;
   return FHEVC_OK;
 }
 

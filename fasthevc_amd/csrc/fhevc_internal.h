@@ -96,6 +96,9 @@ struct FhevcNodeCost { uint32_t satd; uint32_t mode; double cost; };
 // d_all (optional): every (node, mode) pair, [CTU][85][35] -- the parity output behind fhevc_intra_first_pass_all
 hipError_t fhevc_launch_first_pass(const FhevcFrames& fr, double sqrt_lambda, FhevcNodeCost* d_out, FhevcNodeCost* d_all, hipStream_t stream);
 
+// the K (<= 8) cheapest modes per node out of d_all, best first (candidate lists of fhevc_intra_first_pass_candidates)
+hipError_t fhevc_launch_first_pass_topk(const FhevcNodeCost* d_all, long long nodes, int k, uint8_t* d_modes, hipStream_t stream);
+
 // ---- source-only motion search per CU node (k_motion.hip; config 4) -----------------------------------------
 #define FHEVC_NODES 85
 #define FHEVC_MOTION_MAX_RANGE 8

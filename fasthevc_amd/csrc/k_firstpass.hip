@@ -539,7 +539,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PACKED ? 3 
   }
 }
 
+// candidate lists (fhevc_intra_first_pass_candidates): one thread per node picks the K modes of smallest cost out of its 35 (node, mode) entries,
+// best first, an earlier mode ahead of a later one of equal cost (TEncSearch::xUpdateCandList, TEncSearch.cpp:5385-5408); 255 for edge nodes
+__global__ __launch_bounds__(256) void fhevc_first_pass_topk_kernel(const FhevcNodeCost* __restrict__ all, long long nodes, int k, uint8_t* __restrict__ modes)
+{
+  const long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= nodes) return;
+  const FhevcNodeCost* a = all + n * 35;
+  double cost[8];
+  uint8_t mode[8];
+  for (int i = 0; i < 8; ++i) { cost[i] = 1e300; mode[i] = 255; }
+  const bool edge = a[0].satd == 0xFFFFFFFFu;
+  for (int m = 0; m < 35 && !edge; ++m) {
+    const double c = a[m].cost;
+    // insert behind every entry of smaller or EQUAL cost: the earlier mode keeps its place
+    int pos = 8;
+#pragma unroll
+    for (int i = 7; i >= 0; --i) if (c < cost[i]) pos = i;
+#pragma unroll
+    for (int i = 7; i > 0; --i) if (i > pos) { cost[i] = cost[i - 1]; mode[i] = mode[i - 1]; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) if (i == pos) { cost[i] = c; mode[i] = (uint8_t)m; }
+  }
+  for (int i = 0; i < k; ++i) modes[n * k + i] = mode[i];
+}
+
 }  // namespace
+
+hipError_t fhevc_launch_first_pass_topk(const FhevcNodeCost* d_all, long long nodes, int k, uint8_t* d_modes, hipStream_t stream)
+{
+  if (nodes <= 0) return hipSuccess;
+  hipLaunchKernelGGL(fhevc_first_pass_topk_kernel, dim3((unsigned)((nodes + 255) / 256)), dim3(256), 0, stream, d_all, nodes, k, d_modes);
+  return hipGetLastError();
+}
 
 hipError_t fhevc_launch_first_pass(const FhevcFrames& fr, double sqrt_lambda, FhevcNodeCost* d_out, FhevcNodeCost* d_all, hipStream_t stream)
 {

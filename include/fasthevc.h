@@ -146,11 +146,11 @@ int  fhevc_intra_first_pass(fhevc_ctx* ctx, const int16_t* luma, int stride_samp
 int  fhevc_intra_first_pass_all(fhevc_ctx* ctx, const int16_t* luma, int stride_samples, int qp, fhevc_node_cost* best,
                                 fhevc_node_cost* all);
 
-/* What HM's own first pass is for: the candidate list of estIntraPredLumaQT (TEncSearch.cpp:2271-2320).  Per node the num_candidates (HM: 8 for
- * 8x8 PUs, 3 above; up to 35) modes of smallest cost, best first, an earlier mode ahead of a later one of equal cost (xUpdateCandList,
+/* What HM's own first pass is for: the candidate list of estIntraPredLumaQT (TEncSearch.cpp:2271-2320).  Per node the num_candidates (1..8; HM: 8 for
+ * 8x8 PUs, 3 above) modes of smallest cost, best first, an earlier mode ahead of a later one of equal cost (xUpdateCandList,
  * TEncSearch.cpp:5385-5408); modes: numCtus * 85 * num_candidates bytes, 255 for nodes crossing the picture edge.  The costs come from ORIGINAL
  * neighbours (HM's own pass sees reconstructed ones inside its serial loop) and the mode-bit model of fhevc_intra_first_pass; HM still appends its
- * most-probable modes itself.  hm_patch: FHEVC_FIRST_PASS=1. */
+ * most-probable modes itself.  The selection runs on the device (85 x num_candidates bytes per CTU come back).  hm_patch: FHEVC_FIRST_PASS=1. */
 int  fhevc_intra_first_pass_candidates(fhevc_ctx* ctx, const int16_t* luma, int stride_samples, int qp, int num_candidates, uint8_t* modes);
 
 /* first pass over a device-resident batch (layout and band arguments as fhevc_predict_frames_device below);
