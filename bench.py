@@ -127,7 +127,7 @@ def cpu_baseline_port(width, height, bit_depth, w, seconds=10.0):
             "sample": f"{done} CTUs of the same 1080p hetero frame through oracle/fhevc_oracle.c (depth CNN + source Hadamard, 1 thread, {dt:.1f} s)"}
 
 
-def gpu_hook_leg(width, height, bit_depth, crops, margins=None):
+def gpu_hook_leg(width, height, bit_depth, crops, margins=None, first_pass=False):
     """the same compressSlice with the hm_patch hook linked to the GPU library (oracle/_ref/libhmref_hookgpu.so): HM's decision
     stage end to end, GPU call (H2D + kernels + D2H) included, on the same crops.  margins None: the hook's SHIPPED defaults
     (depthnet_v2.fhw at 100000 : 64000, the calibration that keeps every content family within 1 % BD-rate); (split, stop): that setting"""
@@ -139,7 +139,9 @@ def gpu_hook_leg(width, height, bit_depth, crops, margins=None):
     knobs = {"FHEVC_ENABLE": "1", "FHEVC_WEIGHTS": blob}
     if margins is not None:
         knobs.update({"FHEVC_MARGIN_SPLIT": str(margins[0]), "FHEVC_MARGIN_STOP": str(margins[1])})
-    clear = ("FHEVC_MARGIN", "FHEVC_MARGIN_SPLIT", "FHEVC_MARGIN_STOP")
+    if first_pass:  # estIntraPredLumaQT's candidate lists from the GPU's first pass as well (fhevc_intra_first_pass_candidates)
+        knobs["FHEVC_FIRST_PASS"] = "1"
+    clear = ("FHEVC_MARGIN", "FHEVC_MARGIN_SPLIT", "FHEVC_MARGIN_STOP", "FHEVC_FIRST_PASS")
     saved = {k: os.environ.get(k) for k in set(knobs) | set(clear)}
     for k in clear:
         os.environ.pop(k, None)
@@ -151,7 +153,7 @@ def gpu_hook_leg(width, height, bit_depth, crops, margins=None):
         luma = frames.hetero_luma(width, height)
         cu, cv = frames.chroma_planes("hetero", width, height)
         # TEncFastDepth reads its knobs when the harness constructs the encoder of a geometry: the second setting runs on crops 8 px narrower
-        cw_ = CROP_W if margins is None else CROP_W - 64
+        cw_ = CROP_W - 128 if first_pass else (CROP_W if margins is None else CROP_W - 64)
         for (ox, oy) in [c for c in CROPS if c[1] + CROP_H <= height and c[0] + CROP_W <= width][:crops]:
             buf, org, stride = frames.to_pel_plane(luma[oy:oy + CROP_H, ox:ox + cw_].copy(), bit_depth)
             chroma = tuple((c[oy // 2:(oy + CROP_H) // 2, ox // 2:(ox + cw_) // 2].astype(np.int16) << (bit_depth - 8)) for c in (cu, cv))
@@ -160,6 +162,8 @@ def gpu_hook_leg(width, height, bit_depth, crops, margins=None):
             spent += st["seconds"]
         what = "the hook's shipped defaults 100000:64000 (every content family within 1 % BD-rate)" if margins is None else \
             f"margins {margins[0]}:{margins[1]} (content-matched: +0.15 % BD-rate on this family, more on others)"
+        if first_pass:
+            what += " + FHEVC_FIRST_PASS=1 (candidate lists of estIntraPredLumaQT from the GPU's 35-mode first pass)"
         return {"value": done / spent, "unit": "CTUs/s through compressSlice", "margins": "100000:64000" if margins is None else f"{margins[0]}:{margins[1]}",
                 "sample": f"{done} CTUs, crops of the same picture, hm_patch hook -> fhevc_predict_frame_range at {what}, {spent:.1f} s of 1 thread incl. the GPU calls"}
     finally:
@@ -628,6 +632,10 @@ def main():
                 if hook:
                     hook["speedup"] = hook["value"] / cpu["value"]
                     cpu["with_gpu_hook"] = hook
+                    fp = gpu_hook_leg(1920, 1080, bd, crops=6, first_pass=True)   # shipped margins + the first pass consumed
+                    if fp:
+                        fp["speedup"] = fp["value"] / cpu["value"]
+                        cpu["with_gpu_hook_first_pass"] = fp
                     matched = gpu_hook_leg(1920, 1080, bd, crops=6, margins=(48000, 16000))   # the content-matched setting, beside it
                     if matched:
                         matched["speedup"] = matched["value"] / cpu["value"]
