@@ -30,4 +30,7 @@ for b in (pairs["pmc_bench.json"], pairs["pmc_kernels.json"]):
 stats = sorted(glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
 assert stats, "no kernel stats"
 shutil.copyfile(stats[-1], os.path.join(dst, f"{tag}_kernel_stats_bench_default.csv"))  # gpurun merges runs: newest wins
+stats2 = sorted(glob.glob(os.path.join(src, "stats_kernels", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
+if stats2:
+    shutil.copyfile(stats2[-1], os.path.join(dst, f"{tag}_kernel_stats_bench_kernels.csv"))
 print("collected", sorted(os.listdir(dst)))

@@ -11,6 +11,8 @@ timeout -k 10 500 python3 bench.py > "$OUT/bench_default.log" 2> "$OUT/bench_def
 timeout -k 10 200 python3 tools/bench_kernels.py > "$OUT/bench_kernels.json" 2> "$OUT/bench_kernels.err" || exit 1
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$GRAFT_REPO_ROOT/bench.py" --no-cpu-baseline --no-host-path --no-stages > "$OUT/bench_under_rocprof.json" 2> "$OUT/bench_under_rocprof.err" || exit 1
+# the secondary kernels (first pass, pre-analysis, both motion searches ...) under the same profiler
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_kernels" -- python3 "$GRAFT_REPO_ROOT/tools/bench_kernels.py" > "$OUT/bench_kernels_under_rocprof.json" 2> "$OUT/bench_kernels_under_rocprof.err" || exit 1
 cd "$GRAFT_REPO_ROOT"
 bash tools/pmc_run.sh "$OUT/pmc_bench" "FETCH_SIZE" "WRITE_SIZE" \
   "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES" \
