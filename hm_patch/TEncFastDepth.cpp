@@ -18,7 +18,7 @@ static_assert(sizeof(fhevc_p_rule) == 37 * sizeof(int), "TEncFastDepth::m_pRule 
 
 TEncFastDepth::TEncFastDepth()
   : m_enabled(false), m_valid(false), m_external(false), m_cachePic(NULL), m_cachePoc(-1), m_cacheQp(-1), m_cacheType(-1), m_cacheFp(0), m_ctx(NULL), m_width(0), m_height(0), m_bitDepth(0), m_marginSplit(0), m_marginStop(0), m_pWindow(1), m_pMode(P_OFF), m_pRange(4),
-    m_pMotionCompensated(false), m_firstPass(false), m_candValid(false), m_candExternal(false)
+    m_pMotionCompensated(false), m_firstPassExtra(0), m_firstPass(false), m_candValid(false), m_candExternal(false)
 {
   readKnobs();
 }
@@ -40,6 +40,10 @@ void TEncFastDepth::readKnobs()
   if (m_marginStop < 0) m_marginStop = 0;
   const char* fpk = std::getenv("FHEVC_FIRST_PASS");
   m_firstPass = fpk != NULL && std::atoi(fpk) != 0;
+  const char* fpe = std::getenv("FHEVC_FIRST_PASS_EXTRA");
+  m_firstPassExtra = fpe != NULL ? std::atoi(fpe) : 0;
+  if (m_firstPassExtra < 0) m_firstPassExtra = 0;
+  if (m_firstPassExtra > 5) m_firstPassExtra = 5;
   const char* pw = std::getenv("FHEVC_P_WINDOW");
   const char* pm = std::getenv("FHEVC_P_MODE");
   m_pWindow = pw ? std::atoi(pw) : 1;
@@ -94,6 +98,11 @@ void TEncFastDepth::setExternalCandidates(const unsigned char* cand, int numCtus
   m_candExternal = cand != NULL;
   if (m_candExternal) m_cand.assign(cand, cand + (size_t)numCtus * 85 * 8);
   s_active = this;
+}
+
+int TEncFastDepth::candidateExtra()
+{
+  return s_active != NULL ? s_active->m_firstPassExtra : 0;
 }
 
 bool TEncFastDepth::candidateList(unsigned ctuRsAddr, int xInCtu, int yInCtu, int size, int numModes, unsigned* list)

@@ -54,6 +54,9 @@ public:
   /// the candidate list of the square PU of `size` samples at (xInCtu, yInCtu) of CTU ctuRsAddr: numModes (<= 8) modes into list;
   /// false -> no list (HM runs its own 35-mode pass).  Static: TEncSearch has no path to the TEncCu that owns the instance
   static bool candidateList(unsigned ctuRsAddr, int xInCtu, int yInCtu, int size, int numModes, unsigned* list);
+  /// FHEVC_FIRST_PASS_EXTRA=<n>: that many more candidates than HM's numModesForFullRD go to the full RD check where the list comes from the
+  /// GPU (the list is built from original, not reconstructed, neighbours: a wider list buys the difference back); total clamped to 8
+  static int  candidateExtra();
 
 private:
   bool       m_enabled, m_valid, m_external;
@@ -65,6 +68,7 @@ private:
   enum PMode { P_OFF, P_WINDOW, P_MOTION };
   int        m_pMode, m_pRange;
   bool       m_pMotionCompensated;  ///< reference depths taken at the motion-compensated position (FHEVC_P_MC)
+  int        m_firstPassExtra;
   bool       m_firstPass, m_candValid, m_candExternal;   ///< FHEVC_FIRST_PASS; m_cand holds this picture's lists; lists fed by a harness
   std::vector<unsigned char> m_cand;    // numCtus * 85 * 8: the eight cheapest modes per node, best first (255: node crosses the picture edge)
   static TEncFastDepth* s_active;       // the instance whose lists candidateList() reads: the one predictPicture() ran on last

@@ -47,10 +47,11 @@ def patch_search_cpp(s):
     # no list exists (PUs of 4x4, nodes crossing the picture edge, library off); its MPM handling after the loop stays as it is
     s = sub_once(s, r'(#include "TEncSearch.h"\n)', r'\1#include "TEncFastDepth.h"\n', "TEncSearch.cpp include")
     s = sub_once(s, r'^(\s*)for\( Int modeIdx = 0; modeIdx < numModesAvailable; modeIdx\+\+ \)\n',
+                 r'\1const Int  iGpuModes = std::min( 8, numModesForFullRD + TEncFastDepth::candidateExtra() );   // FHEVC_FIRST_PASS_EXTRA\n'
                  r'\1const Bool bGpuList = puRect.width == puRect.height && puRect.width >= 8 &&\n'
                  r'\1  TEncFastDepth::candidateList( pcCU->getCtuRsAddr(), Int(pcCU->getCUPelX() & 63) + Int(puRect.x0), Int(pcCU->getCUPelY() & 63) + Int(puRect.y0),\n'
-                 r'\1                                Int(puRect.width), numModesForFullRD, uiRdModeList );\n'
-                 r'\1if ( bGpuList ) CandNum = numModesForFullRD;\n'
+                 r'\1                                Int(puRect.width), iGpuModes, uiRdModeList );\n'
+                 r'\1if ( bGpuList ) { numModesForFullRD = iGpuModes; CandNum = numModesForFullRD; }\n'
                  r'\1for( Int modeIdx = 0; !bGpuList && modeIdx < numModesAvailable; modeIdx++ )\n',
                  "first-pass mode loop")
     return s

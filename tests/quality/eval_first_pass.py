@@ -27,7 +27,8 @@ MARGINS = (100000, 64000)
 
 
 def work(job):
-    family, k, (W, H), blob = job
+    family, k, (W, H), blob, extra = job
+    os.environ["FHEVC_FIRST_PASS_EXTRA"] = str(extra)   # read when the harness builds the encoder of a geometry: before the first encode of this process
     from oracle import oracle_py as op
     ref, hook, oracle = op.bind_rdo(op.load_ref()), op.bind_rdo(op.load_ref(hook=True)), op.load_oracle()
     oracle.fho_first_pass_candidates_ctu.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p]
@@ -64,10 +65,11 @@ def main():
     ap.add_argument("--pictures", type=int, default=3)
     ap.add_argument("--workers", type=int, default=8)
     ap.add_argument("--json", default=None)
+    ap.add_argument("--extra", type=int, default=0, help="FHEVC_FIRST_PASS_EXTRA: that many more candidates than HM's numModesForFullRD go to the full RD check")
     args = ap.parse_args()
     from eval_rd import bd_rate
     W, H = (int(v) for v in args.size.split("x"))
-    jobs = [(f, k, (W, H), args.weights) for f in FAMILIES for k in range(args.pictures)]
+    jobs = [(f, k, (W, H), args.weights, args.extra) for f in FAMILIES for k in range(args.pictures)]
     res = {}
     with Pool(args.workers) as pool:
         for i, (family, k, out) in enumerate(pool.imap_unordered(work, jobs)):
@@ -76,7 +78,7 @@ def main():
     variants = ("first_pass", "depth", "depth+first_pass")
     report = {"what": f"{args.pictures} unseen {W}x{H} pictures per family, QP {list(QPS)}: HM's estIntraPredLumaQT fed with the candidate lists of the source-only "
                       f"first pass (PUs of 8x8 and larger; 4x4 PUs keep HM's own pass), alone and with the depth hook ({os.path.basename(args.weights)} at "
-                      f"{MARGINS[0]}:{MARGINS[1]}); decision-stage BD-rate and time in compressSlice vs the reference's full RDO", "families": {}, "summary": {}}
+                      f"{MARGINS[0]}:{MARGINS[1]}); FHEVC_FIRST_PASS_EXTRA={args.extra}; decision-stage BD-rate and time in compressSlice vs the reference's full RDO", "families": {}, "summary": {}}
     for f in FAMILIES:
         curve = lambda v: [(sum(res[(f, k)][(v, qp)][0] for k in range(args.pictures)), float(np.mean([res[(f, k)][(v, qp)][1] for k in range(args.pictures)])),
                             sum(res[(f, k)][(v, qp)][2] for k in range(args.pictures))) for qp in QPS]
