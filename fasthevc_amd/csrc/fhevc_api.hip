@@ -32,6 +32,9 @@ struct fhevc_ctx {
   uint4* d_frag_i8 = nullptr; int32_t* d_bias_i8 = nullptr;  // the i8 variant of conv2 / conv3 (k_cnn.hip)
   // a member of the reference's Bayesian-optimisation network family (FHW3 blob; k_cnn_family.inc): set instead of the arrays above
   bool family = false;
+  bool fam_layers = false;            // ... run layer by layer through HBM (k_cnn_layers.inc): every member the two fused kernels do not cover
+  FhevcLayersWeights lw = {};
+  std::vector<void*> lw_bufs;         // everything lw points to (freed with the context / the next blob)
   int fam_c[3] = { 0, 0, 0 };
   uint4* f_frag1 = nullptr; float* f_bias1 = nullptr; uint4* f_frag2 = nullptr; uint4* f_frag3 = nullptr; int32_t* f_bias_i8 = nullptr;
   uint8_t* f_whead = nullptr; uint8_t* f_headm = nullptr; int32_t* f_bhead = nullptr;
@@ -303,6 +306,104 @@ int build_weight_image(fhevc_ctx* c, const BlobView& b)
   return FHEVC_OK;
 }
 
+// FHW3 member without a fused kernel: one image per convolution for k_cnn_layers.inc + the activation tensors of a chunk of CTUs in HBM
+int build_layers_image(fhevc_ctx* c, const uint8_t* blob, size_t bytes, int C1, int C2, int C3, int depth)
+{
+  const int C[3] = { C1, C2, C3 };
+  for (int b = 0; b < 3; ++b) if (C[b] < 1 || C[b] > 128) return fail(c, FHEVC_E_WEIGHTS, "family widths must be 1..128");
+  if (depth < 1 || depth > 3 || (C3 & 3)) return fail(c, FHEVC_E_WEIGHTS, "family members: 1..3 convolutions per block, last width a multiple of 4");
+  size_t need = 24 + 36, ci = 1;
+  for (int b = 0; b < 3; ++b) for (int j = 0; j < depth; ++j) { need += (size_t)C[b] * ci * 9 + 4 * (size_t)C[b]; ci = (size_t)C[b]; }
+  need += (size_t)(2 * 64 + 2 * 64 + 2 * 16) * C3 + 24 + 3 * 52 * 4;
+  if (bytes != need) return fail(c, FHEVC_E_WEIGHTS, "FHW3 blob has the wrong size");
+  size_t off = 24;
+  auto take = [&](size_t n) { const uint8_t* q = blob + off; off += n; return q; };
+  auto i32at = [](const uint8_t* p, int i) { int32_t v; std::memcpy(&v, p + 4 * (size_t)i, 4); return v; };
+  int32_t shift33[9];
+  std::memcpy(shift33, take(36), 36);
+  for (void* q : c->lw_bufs) (void)hipFree(q);
+  c->lw_bufs.clear();
+  FhevcLayersWeights lw = {};
+  // a chunk of CTUs whose activations live in HBM at once: up to 16 pictures of 1080p (3.2 GB for 23/46/92 x 2), at least one picture row
+  lw.chunk = std::min(c->num_ctus * std::max(1, c->cfg.max_frames), 8192);
+  if (lw.chunk < 64) lw.chunk = 64;
+  auto dev = [&](size_t n, int fill) -> void* { void* q = nullptr; if (hipMalloc(&q, n) != hipSuccess) return nullptr; c->lw_bufs.push_back(q); (void)hipMemset(q, fill, n); return q; };
+  if (!(lw.in0 = static_cast<int8_t*>(dev((size_t)lw.chunk * 66 * 66, 0)))) return fail(c, FHEVC_E_HIP, "layer buffers");
+  int H = 64, cin = 1, li = 0;
+  for (int b = 0; b < 3; ++b)
+    for (int j = 0; j < depth; ++j, ++li) {
+      const int co = C[b], first = (b == 0 && j == 0);
+      const int8_t* w = reinterpret_cast<const int8_t*>(take((size_t)co * cin * 9));
+      const uint8_t* bp = take(4 * (size_t)co);
+      for (size_t i = 0; i < (size_t)co * cin * 9; ++i) if (w[i] == -128) return fail(c, FHEVC_E_WEIGHTS, "weight -128 not allowed");
+      const int sh = shift33[b * 3 + j];
+      if (sh < 0 || sh > 14) return fail(c, FHEVC_E_WEIGHTS, "shift out of range (0..14)");
+      const int kc = first ? 0 : (cin + 31) / 32, cout_pad = 32 * ((co + 31) / 32), MT = cout_pad / 32, NF = first ? 1 : kc * 9;
+      // A fragments: lane (m, h) of (M tile, fragment): row m carries channel 32 mt + 16 m[2] + 4 m[4:3] + m[1:0] (so that a lane's 16 accumulators are 16
+      // consecutive channels); byte jj of lane half h = input channel 32 kc + 16 h + jj at the fragment's tap (first layer: tap jj of the one channel, h = 0)
+      std::vector<int8_t> frag((size_t)MT * NF * 64 * 16, 0);
+      for (int mt = 0; mt < MT; ++mt)
+        for (int f = 0; f < NF; ++f)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int m = lane & 31, h = lane >> 5;
+            const int oc = 32 * mt + 16 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3);
+            if (oc >= co) continue;
+            for (int jj = 0; jj < 16; ++jj) {
+              int8_t v = 0;
+              if (first) { if (h == 0 && jj < 9) v = w[(size_t)oc * 9 + jj]; }
+              else { const int ic = 32 * (f / 9) + 16 * h + jj; if (ic < cin) v = w[((size_t)oc * cin + ic) * 9 + f % 9]; }
+              frag[(((size_t)mt * NF + f) * 64 + lane) * 16 + jj] = v;
+            }
+          }
+      std::vector<int32_t> bias((size_t)cout_pad, 0);
+      for (int oc = 0; oc < co; ++oc) {
+        int sw = 0;
+        for (int i = 0; i < cin * 9; ++i) sw += w[(size_t)oc * cin * 9 + i];
+        bias[(size_t)oc] = i32at(bp, oc) + (first ? 0 : 128 * sw);   // activations travel as a - 128; the first layer's input IS centred
+      }
+      const int pool = (j == depth - 1) && b < 2, Ho = pool ? H / 2 : H;
+      FhevcLayer& L = lw.l[li];
+      void* dfrag = dev(frag.size(), 0); void* dbias = dev(bias.size() * 4, 0);
+      L.out = static_cast<int8_t*>(dev((size_t)lw.chunk * (Ho + 2) * (Ho + 2) * cout_pad, 0x80));   // halo = "activation 0", written here once
+      if (!dfrag || !dbias || !L.out) return fail(c, FHEVC_E_HIP, "layer buffers");
+      HIP_TRY(c, hipMemcpy(dfrag, frag.data(), frag.size(), hipMemcpyHostToDevice));
+      HIP_TRY(c, hipMemcpy(dbias, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
+      L.frag = static_cast<const uint4*>(dfrag); L.bias = static_cast<const int32_t*>(dbias);
+      L.shift = sh; L.kc = kc; L.cout_pad = cout_pad; L.H = H; L.pool = pool;
+      H = Ho; cin = co;
+    }
+  lw.num_layers = li; lw.c3 = C3; lw.c3_pad = 32 * ((C3 + 31) / 32);
+  const int8_t* wh64 = reinterpret_cast<const int8_t*>(take((size_t)2 * 64 * C3));
+  const uint8_t* bh64p = take(8);
+  const int8_t* wh32 = reinterpret_cast<const int8_t*>(take((size_t)2 * 64 * C3));
+  const uint8_t* bh32p = take(8);
+  const int8_t* wh16 = reinterpret_cast<const int8_t*>(take((size_t)2 * 16 * C3));
+  const uint8_t* bh16p = take(8);
+  const uint8_t* qpb = take(3 * 52 * 4);
+  std::vector<uint8_t> whead((size_t)(2 * 64 + 2 * 64 + 2 * 16) * C3);
+  std::memcpy(whead.data(), wh64, (size_t)2 * 64 * C3);
+  std::memcpy(whead.data() + (size_t)2 * 64 * C3, wh32, (size_t)2 * 64 * C3);
+  std::memcpy(whead.data() + (size_t)4 * 64 * C3, wh16, (size_t)2 * 16 * C3);
+  for (uint8_t v : whead) if (v == 0x80) return fail(c, FHEVC_E_WEIGHTS, "weight -128 not allowed");
+  int32_t bhead[6 + 3 * 52] = { i32at(bh64p, 0), i32at(bh64p, 1), i32at(bh32p, 0), i32at(bh32p, 1), i32at(bh16p, 0), i32at(bh16p, 1) };
+  for (int cls = 0; cls < 2; ++cls) {
+    int s64 = 0, s32 = 0, s16 = 0;
+    for (int i = 0; i < 64 * C3; ++i) { s64 += wh64[(size_t)cls * 64 * C3 + i]; s32 += wh32[(size_t)cls * 64 * C3 + i]; }
+    for (int i = 0; i < 16 * C3; ++i) s16 += wh16[(size_t)cls * 16 * C3 + i];
+    bhead[0 + cls] += 128 * 4 * s64; bhead[2 + cls] += 128 * s32; bhead[4 + cls] += 128 * s16;   // the last map travels as a - 128
+  }
+  for (int i = 0; i < 3 * 52; ++i) bhead[6 + i] = i32at(qpb, i);
+  void* dwh = dev(whead.size(), 0); void* dbh = dev(sizeof bhead, 0);
+  if (!dwh || !dbh) return fail(c, FHEVC_E_HIP, "layer buffers");
+  HIP_TRY(c, hipMemcpy(dwh, whead.data(), whead.size(), hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(dbh, bhead, sizeof bhead, hipMemcpyHostToDevice));
+  lw.whead = static_cast<const uint8_t*>(dwh); lw.bhead = static_cast<const int32_t*>(dbh);
+  c->lw = lw;
+  c->fam_c[0] = C1; c->fam_c[1] = C2; c->fam_c[2] = C3;
+  c->family = true; c->fam_layers = true; c->have_weights = true;
+  return FHEVC_OK;
+}
+
 // FHW3: a member of the reference's Bayesian-optimisation network family (fasthevc_amd/weights.py: family_fields); this round the
 // kernel runs the members with one convolution per block whose widths it is instantiated for (fhevc_cnn_family_supported)
 int build_family_image(fhevc_ctx* c, const uint8_t* blob, size_t bytes)
@@ -314,8 +415,9 @@ int build_family_image(fhevc_ctx* c, const uint8_t* blob, size_t bytes)
   std::memcpy(hdr, blob + 8, 16);
   const int C1 = hdr[0], C2 = hdr[1], C3 = hdr[2], depth = hdr[3];
   if (ver != 1) return fail(c, FHEVC_E_WEIGHTS, "unsupported FHW3 version");
-  if (depth != 1 || !fhevc_cnn_family_supported(C1, C2, C3))
-    return fail(c, FHEVC_E_WEIGHTS, "this build runs the family members 32/64/128 x 1 (and 16/32/64 x 1); deeper members are oracle-only so far");
+  if (depth != 1 || !fhevc_cnn_family_supported(C1, C2, C3) || std::getenv("FHEVC_FAMILY_LAYERS"))   // (the knob: the generic path for a fused member too)
+    return build_layers_image(c, blob, bytes, C1, C2, C3, depth);
+  c->fam_layers = false;
   const size_t need = 24 + 36 + (size_t)C1 * 9 + 4 * (size_t)C1 + (size_t)C2 * C1 * 9 + 4 * (size_t)C2 + (size_t)C3 * C2 * 9 + 4 * (size_t)C3 +
                       (size_t)(2 * 64 + 2 * 64 + 2 * 16) * C3 + 24 + 3 * 52 * 4;
   if (bytes != need) return fail(c, FHEVC_E_WEIGHTS, "FHW3 blob has the wrong size");
@@ -609,6 +711,7 @@ void fhevc_destroy(fhevc_ctx* c)
   (void)hipFree(c->d_frag_i8); (void)hipFree(c->d_bias_i8);
   (void)hipFree(c->f_frag1); (void)hipFree(c->f_bias1); (void)hipFree(c->f_frag2); (void)hipFree(c->f_frag3); (void)hipFree(c->f_bias_i8); (void)hipFree(c->f_whead); (void)hipFree(c->f_headm); (void)hipFree(c->f_bhead);
   (void)hipFree(c->d_luma); (void)hipFree(c->d_depth); (void)hipFree(c->d_had); (void)hipFree(c->d_nodes); (void)hipFree(c->d_satd); (void)hipFree(c->d_satd_out); (void)hipFree(c->d_act); (void)hipFree(c->d_depth_max); (void)hipFree(c->d_pair); (void)hipFree(c->d_motion); (void)hipFree(c->d_mvtab); (void)hipFree(c->d_cand_all); (void)hipFree(c->d_cand);
+  for (void* q : c->lw_bufs) (void)hipFree(q);
   for (auto& sl : c->slot) {  // the host-batch ring of fhevc_predict_frames: stream, device buffers, pinned staging
     if (sl.st) { (void)hipStreamSynchronize(sl.st); (void)hipStreamDestroy(sl.st); }
     (void)hipFree(sl.d_in); (void)hipFree(sl.d_depth); (void)hipFree(sl.d_had);
@@ -698,7 +801,8 @@ int fhevc_predict_frames_device_range(fhevc_ctx* c, const void* d_luma, int samp
     c->stats.kernels_launched++;
   }
   time_begin(c, s, 0);
-  if (c->family) HIP_TRY(c, fhevc_launch_cnn_family(fr, family_weights(c), d_depth_map, d_logits, d_flags, d_depth_max, margin_split, margin_stop, c->num_cus, s));
+  if (c->family && c->fam_layers) HIP_TRY(c, fhevc_launch_cnn_layers(fr, c->lw, d_depth_map, d_logits, d_flags, d_depth_max, margin_split, margin_stop, c->num_cus, s));
+  else if (c->family) HIP_TRY(c, fhevc_launch_cnn_family(fr, family_weights(c), d_depth_map, d_logits, d_flags, d_depth_max, margin_split, margin_stop, c->num_cus, s));
   else HIP_TRY(c, fhevc_launch_cnn(fr, cnn_weights(c), d_depth_map, fuse ? d_hadamard : nullptr, d_logits, d_flags, d_depth_max, margin_split, margin_stop, c->num_cus, s));
   time_end(c, s);
   c->stats.kernels_launched++;

@@ -74,6 +74,24 @@ hipError_t fhevc_launch_cnn_family(const FhevcFrames& fr, const FhevcFamilyWeigh
                                    uint8_t* d_depth_max, int margin_split, int margin_stop, int num_cus, hipStream_t stream);
 bool fhevc_cnn_family_supported(int c1, int c2, int c3);
 
+// any member of the family, layer by layer through HBM (k_cnn_layers.inc)
+struct FhevcLayer {
+  const uint4* frag;     // [M tile][K chunk][tap 9][64 lanes] (first layer: [M tile][64]: K = the nine taps of the one input channel)
+  const int32_t* bias;   // [cout_pad], + 128 * sum of the filter's weights (not for the first layer: its input is centred samples)
+  int8_t* out;           // [chunk CTUs][Ho + 2][Ho + 2][cout_pad]
+  int shift, kc, cout_pad, H, pool;   // kc = Cin_pad / 32 (0: first layer); H = input size (64 / 32 / 16)
+};
+struct FhevcLayersWeights {
+  int num_layers, chunk, c3, c3_pad;
+  FhevcLayer l[9];
+  int8_t* in0;             // [chunk CTUs][66][66]
+  const uint8_t* whead;    // wh64[2][8][8][c3], wh32[2][8][8][c3], wh16[2][4][4][c3]
+  const int32_t* bhead;    // as FhevcCnnWeights::bhead
+};
+
+hipError_t fhevc_launch_cnn_layers(const FhevcFrames& fr, const FhevcLayersWeights& w, uint8_t* d_depth, int32_t* d_logits, uint32_t* d_flags,
+                                   uint8_t* d_depth_max, int margin_split, int margin_stop, int num_cus, hipStream_t stream);
+
 hipError_t fhevc_cnn_prepare_device();  // LDS opt-in of the depth kernel on the current device (once per context)
 // d_depth_max / margins: soft decisions (nullptr / 0, 0 = the plain map only)
 // d_had != nullptr: the per-CTU source Hadamard is computed inside the depth kernel from the samples it loads anyway (one

@@ -1936,6 +1936,7 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_pipe_kernel(FhevcFrame
 }
 
 #include "k_cnn_family.inc"
+#include "k_cnn_layers.inc"
 
 // split-flag words -> depth maps (whole pictures, CTU raster order): one thread per row of 16 units = one 16-byte store,
 // 16 threads per CTU, 16 CTUs per workgroup and sweep (HBM-write-bound: 256 B per CTU)
@@ -2092,5 +2093,36 @@ hipError_t fhevc_launch_cnn_family(const FhevcFrames& fr, const FhevcFamilyWeigh
   else if (w.c[0] == 16 && w.c[1] == 32 && w.c[2] == 64)
     hipLaunchKernelGGL((fhevc_cnn_family_kernel<16, 32, 64>), dim3(grid), dim3(256), (LdsFam<16, 32, 64>::LDS_BYTES), stream, fr, w, d_depth, d_logits, d_flags, d_depth_max, margin_split, margin_stop);
   else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+// ---- any member of the family, layer by layer through HBM (k_cnn_layers.inc) ----
+hipError_t fhevc_launch_cnn_layers(const FhevcFrames& fr, const FhevcLayersWeights& w, uint8_t* d_depth, int32_t* d_logits, uint32_t* d_flags,
+                                   uint8_t* d_depth_max, int margin_split, int margin_stop, int num_cus, hipStream_t stream)
+{
+  const int total = (fr.row_end - fr.row_begin) * fr.ctus_x * fr.num_frames;
+  const int grid = 3 * num_cus;   // x 4 waves: a multiple of 12 waves (M tiles of 1 .. 4 divide it)
+  for (int first = 0; first < total; first += w.chunk) {
+    const int count = total - first < w.chunk ? total - first : w.chunk;
+    if (fr.sample_bytes == 2) hipLaunchKernelGGL((fhevc_layers_stage_kernel<int16_t>), dim3(count < 4096 ? count : 4096), dim3(256), 0, stream, fr, first, count, w.in0);
+    else hipLaunchKernelGGL((fhevc_layers_stage_kernel<uint8_t>), dim3(count < 4096 ? count : 4096), dim3(256), 0, stream, fr, first, count, w.in0);
+    const int8_t* in = w.in0;
+    for (int i = 0; i < w.num_layers; ++i) {
+      const FhevcLayer& L = w.l[i];
+#define FHEVC_LAYER(KCV, POOLV) hipLaunchKernelGGL((fhevc_layer_conv_kernel<KCV, POOLV>), dim3(grid), dim3(256), 0, stream, in, L.out, L.frag, L.bias, L.shift, L.H, L.cout_pad, count)
+      switch (L.kc * 2 + (L.pool ? 1 : 0)) {
+        case 0: FHEVC_LAYER(0, false); break; case 1: FHEVC_LAYER(0, true); break;
+        case 2: FHEVC_LAYER(1, false); break; case 3: FHEVC_LAYER(1, true); break;
+        case 4: FHEVC_LAYER(2, false); break; case 5: FHEVC_LAYER(2, true); break;
+        case 6: FHEVC_LAYER(3, false); break; case 7: FHEVC_LAYER(3, true); break;
+        case 8: FHEVC_LAYER(4, false); break; case 9: FHEVC_LAYER(4, true); break;
+        default: return hipErrorInvalidValue;
+      }
+#undef FHEVC_LAYER
+      in = L.out;
+    }
+    hipLaunchKernelGGL(fhevc_layers_heads_kernel, dim3(count < 8 * num_cus ? count : 8 * num_cus), dim3(256), 0, stream, fr, in, w.c3, w.c3_pad, w.whead, w.bhead,
+                       first, count, d_depth, d_logits, d_flags, d_depth_max, margin_split, margin_stop);
+  }
   return hipGetLastError();
 }

@@ -87,8 +87,47 @@ def test_family_code_path_reproduces_the_base_network(oracle):
     ctx.close()
 
 
-def test_deeper_family_members_are_refused_with_a_status():
-    fam = weights.random_family(weights.family_widths(2), 2, seed=1)
+@pytest.mark.parametrize("widths,depth,W,H,bd,seed", [((23, 46, 92), 2, 416, 240, 8, 0), ((18, 36, 72), 3, 416, 240, 8, 1), ((23, 46, 92), 2, 200, 136, 10, 2),
+                                                      ((32, 64, 128), 1, 416, 240, 8, 3), ((20, 44, 100), 2, 256, 192, 8, 4), ((12, 24, 48), 3, 320, 256, 12, 5)])
+def test_every_family_member_through_the_layered_path(oracle, monkeypatch, widths, depth, W, H, bd, seed):
+    """The members without a fused kernel -- NetworkDepth 2 (23 / 46 / 92) and 3 (18 / 36 / 72) of the reference's family, and odd widths -- run layer by
+    layer through HBM (k_cnn_layers.inc): depth maps, logits, soft ranges and split-flag words against the oracle's plain loops, ragged pictures,
+    8 / 10 / 12 bit.  FHEVC_FAMILY_LAYERS sends a fused member (32 / 64 / 128) through the same generic path."""
+    import torch
+    monkeypatch.setenv("FHEVC_FAMILY_LAYERS", "1")
+    fam = weights.random_family(widths, depth, seed=seed)
+    qp = 22 + 5 * seed
+    lumas = [frames.hetero_luma(W, H, seed=80 + seed), frames.texture16_luma(W, H, seed=90 + seed)]
+    refs = [_oracle_family(oracle, fam, y, bd, qp) for y in lumas]
+    ctx = capi.Context(W, H, bd, fam, max_frames=2)
+    for y, (buf, org, stride, depth_ref, logits_ref, had_ref) in zip(lumas, refs):
+        d, had = ctx.predict_frame(buf, org, stride, qp=qp)
+        bad = np.nonzero((d != depth_ref).any(axis=1))[0]
+        assert bad.size == 0, f"CTUs with a differing depth map: {bad[:10]}"
+        assert np.array_equal(had, had_ref)
+    # device batch of both pictures: logits, flag words, soft ranges
+    dev = torch.device("cuda:0")
+    planes = np.stack([r[0] for r in refs])
+    d16 = torch.from_numpy(planes).to(dev)
+    org, stride = refs[0][1], refs[0][2]
+    n = ctx.num_ctus
+    depth = torch.zeros((2, n, 256), dtype=torch.uint8, device=dev)
+    logits = torch.zeros((2, n, 42), dtype=torch.int32, device=dev)
+    flags = torch.zeros((2, n), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ctx.predict_frames_device(d16.data_ptr() + 2 * org, 2, stride, planes.shape[1] * planes.shape[2], 2, depth.data_ptr(), None, logits.data_ptr(), qp=qp, d_flags=flags.data_ptr())
+    expanded = torch.zeros_like(depth)
+    ctx.expand_depth_flags_device(flags.data_ptr(), 2, expanded.data_ptr())
+    torch.cuda.synchronize()
+    for f in range(2):
+        assert np.array_equal(logits[f].cpu().numpy(), refs[f][4]), f
+        assert np.array_equal(depth[f].cpu().numpy(), refs[f][3]), f
+        assert np.array_equal(expanded[f].cpu().numpy(), refs[f][3]), f
+    ctx.close()
+
+
+def test_family_members_the_build_cannot_run_are_refused_with_a_status():
+    fam = weights.random_family((23, 46, 94), 2, seed=1)   # last width not a multiple of 4: the heads' four-byte dot products
     with pytest.raises(capi.FastHevcError) as e:
         capi.Context(416, 240, 8, fam)
     assert e.value.code == capi.E_WEIGHTS
