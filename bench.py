@@ -550,6 +550,36 @@ def main():
                        "roofline": {"bound": "mfma", "kernel": "fhevc_cnn_family_kernel<32, 64, 128>", "achieved": fach, "peak": PEAK_I8_TOPS, "unit": "TOP/s (2 per MAC)",
                                     "frac": fach / PEAK_I8_TOPS if fach else None, "avg_launch_ms": f_ms, "launches": f_n}}
 
+        # the deeper members (no fused kernel: layer by layer through HBM, k_cnn_layers.inc), random weights, the first 16 pictures of the GOP
+        deeper = {}
+        nfd = min(nf_local, 16)
+        for widths, depth in (((23, 46, 92), 2), ((18, 36, 72), 3)):
+            dctx = capi.Context(W, H, bd, weights.random_family(widths, depth, seed=0), device=local, max_frames=nfd)
+            dctx.enable_kernel_timing(True)
+            for _ in range(2):
+                dctx.predict_frames_device(luma_ptr, args.sample_bytes, stride, frame_stride, nfd, fdepth.data_ptr(), None, None, stream=stream)
+            torch.cuda.synchronize()
+            dctx.kernel_timing(0, reset=True)
+            for _ in range(5):
+                dctx.predict_frames_device(luma_ptr, args.sample_bytes, stride, frame_stride, nfd, fdepth.data_ptr(), None, None, stream=stream)
+            torch.cuda.synchronize()
+            d_ms, d_n = dctx.kernel_timing(0, reset=True)
+            dctx.close()
+            mac, ci, n = 0, 1, 64
+            for b in range(3):
+                for j in range(depth):
+                    mac += n * n * 9 * ci * widths[b]
+                    ci = widths[b]
+                if b < 2:
+                    n //= 2
+            mac += (64 * 4 + 4 * 64 + 16 * 16) * widths[2] * 2
+            ach = 2 * mac * nfd * n_ctus / (d_ms * 1e-3) / 1e12
+            deeper[f"{widths[0]}/{widths[1]}/{widths[2]} x {depth}"] = {
+                "value": nfd * n_ctus / (d_ms * 1e-3), "unit": "CTU/s", "ms_per_16_pictures": d_ms, "op_per_ctu": 2 * mac,
+                "roofline": {"bound": "mfma", "kernels": f"{3 * depth} x fhevc_layer_conv_kernel + stage + heads", "achieved": ach, "peak": PEAK_I8_TOPS,
+                             "unit": "TOP/s (2 per MAC, unpadded)", "frac": ach / PEAK_I8_TOPS}}
+        family_line["deeper_members_layer_by_layer"] = deeper
+
     if rank == 0:
         ctus_per_step = total_frames * n_ctus
         thr = sorted(ctus_per_step * args.steps / t for t in regions)

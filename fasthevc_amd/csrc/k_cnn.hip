@@ -1989,6 +1989,12 @@ hipError_t fhevc_cnn_prepare_device()
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_pipe_kernel<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LdsPipe::LDS_BYTES);
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_pipe_kernel<0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LdsPipe::LDS_BYTES);
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_pipe_kernel<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LdsPipe::LDS_BYTES);
+  // the layer kernels that stage a 32 x 32 map of up to 64 channels (+ halo) in LDS: 34 x 34 x 64 B = 73 984 B
+#define FHEVC_LAYER_LDS(KCV) \
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_layer_conv_kernel<KCV, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_layer_conv_kernel<KCV, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+  FHEVC_LAYER_LDS(1) FHEVC_LAYER_LDS(2) FHEVC_LAYER_LDS(3) FHEVC_LAYER_LDS(4)
+#undef FHEVC_LAYER_LDS
   return e;
 }
 
@@ -2109,7 +2115,14 @@ hipError_t fhevc_launch_cnn_layers(const FhevcFrames& fr, const FhevcLayersWeigh
     const int8_t* in = w.in0;
     for (int i = 0; i < w.num_layers; ++i) {
       const FhevcLayer& L = w.l[i];
-#define FHEVC_LAYER(KCV, POOLV) hipLaunchKernelGGL((fhevc_layer_conv_kernel<KCV, POOLV>), dim3(grid), dim3(256), 0, stream, in, L.out, L.frag, L.bias, L.shift, L.H, L.cout_pad, count)
+      // the input map (or, at 64 x 64, a strip of 32 rows of it) staged in LDS per workgroup item where it fits 80 KB; the first layer reads HBM directly
+      int strip = L.H;
+      while (strip > 8 && (size_t)(strip + 2) * (L.H + 2) * (L.kc * 32) > 80 * 1024) strip >>= 1;
+      const size_t map_bytes = (size_t)(strip + 2) * (L.H + 2) * (L.kc * 32);
+      const bool use_lds = L.kc > 0 && map_bytes <= 80 * 1024;
+      const int litems = count * (L.H / strip), lgrid = litems < 2048 ? litems : 2048;
+#define FHEVC_LAYER(KCV, POOLV) do { if (use_lds) hipLaunchKernelGGL((fhevc_layer_conv_kernel<KCV, POOLV, KCV != 0>), dim3(lgrid), dim3(256), map_bytes, stream, in, L.out, L.frag, L.bias, L.shift, L.H, L.cout_pad, count, strip); \
+                                      else hipLaunchKernelGGL((fhevc_layer_conv_kernel<KCV, POOLV, false>), dim3(grid), dim3(256), 0, stream, in, L.out, L.frag, L.bias, L.shift, L.H, L.cout_pad, count, L.H); } while (0)
       switch (L.kc * 2 + (L.pool ? 1 : 0)) {
         case 0: FHEVC_LAYER(0, false); break; case 1: FHEVC_LAYER(0, true); break;
         case 2: FHEVC_LAYER(1, false); break; case 3: FHEVC_LAYER(1, true); break;

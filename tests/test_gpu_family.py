@@ -1,6 +1,7 @@
-"""The reference's Bayesian-optimisation network family on the MI355X (k_cnn_family.inc) against the CPU oracle (fho_cnn_ctu_family),
-bit for bit: the NetworkDepth-1 member 32 / 64 / 128 (Optimize...Example.m:103-106, 233-259), and the 16 / 32 / 64 widths through the same
-code path, which must reproduce the tuned base-network kernel's output."""
+"""The reference's Bayesian-optimisation network family on the MI355X against the CPU oracle (fho_cnn_ctu_family), bit for bit: the NetworkDepth-1
+member 32 / 64 / 128 (Optimize...Example.m:103-106, 233-259) in its fused kernel (k_cnn_family.inc), the 16 / 32 / 64 widths through the same code
+path (must reproduce the tuned base-network kernel's output), and every other member -- NetworkDepth 2 and 3, odd widths -- through the
+layer-by-layer path (k_cnn_layers.inc)."""
 import ctypes as C
 
 import numpy as np
