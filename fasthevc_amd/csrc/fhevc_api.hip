@@ -323,6 +323,7 @@ int build_layers_image(fhevc_ctx* c, const uint8_t* blob, size_t bytes, int C1, 
   std::memcpy(shift33, take(36), 36);
   for (void* q : c->lw_bufs) (void)hipFree(q);
   c->lw_bufs.clear();
+  if (c->fam_layers) { c->fam_layers = false; c->family = false; c->have_weights = false; }   // the image being replaced is gone: a failure below leaves NO weights
   FhevcLayersWeights lw = {};
   // a chunk of CTUs whose activations live in HBM at once: up to 16 pictures of 1080p (3.2 GB for 23/46/92 x 2), at least one picture row
   lw.chunk = std::min(c->num_ctus * std::max(1, c->cfg.max_frames), 8192);

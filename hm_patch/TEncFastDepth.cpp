@@ -75,6 +75,7 @@ void TEncFastDepth::readKnobs()
 
 TEncFastDepth::~TEncFastDepth()
 {
+  if (s_active == this) s_active = NULL;
 #ifndef FHEVC_HOOK_NO_GPU
   if (m_ctx != NULL) fhevc_destroy(m_ctx);
 #endif
