@@ -80,3 +80,19 @@ def test_a_device_that_does_not_exist_is_left_out_at_create():
     d1, _ = ref.predict_frame(buf, org, stride)
     assert np.array_equal(d, d1)
     ctx.close(); ref.close()
+
+
+def test_a_family_member_on_the_layer_path_over_devices():
+    """A multi-device context with a member of the reference's network family that runs layer by layer through HBM (23 / 46 / 92 x 2): every device
+    builds its own images and activation tensors; the sharded maps equal the single-device ones."""
+    W, H = 416, 240
+    fam = weights.random_family((23, 46, 92), 2, seed=3)
+    luma = frames.hetero_luma(W, H, seed=81)
+    buf, org, stride = frames.to_pel_plane(luma, 8)
+    one = capi.Context(W, H, 8, fam)
+    d1, h1 = one.predict_frame(buf, org, stride, qp=30)
+    one.close()
+    ctx = capi.Context(W, H, 8, fam, devices=[0, 0, 0])
+    d, h = ctx.predict_frame(buf, org, stride, qp=30)
+    assert np.array_equal(d, d1) and np.array_equal(h, h1) and len(np.unique(d)) >= 2
+    ctx.close()
