@@ -178,7 +178,7 @@ def quoted_bd_rate():
     """the quality half of BASELINE's metric, quoted from the committed evaluations under profiles/ (tests/quality/eval_rd.py,
     eval_p.py: minutes of CPU each, not re-run here)"""
     out = {}
-    for tag, name in (("intra", "bdrate_generalization"), ("intra_family_32_64_128", "bdrate_family_d1"), ("p_slices", "p_slice_motion_rule"),
+    for tag, name in (("intra", "bdrate_generalization"), ("intra_family_32_64_128", "bdrate_family_d1"), ("intra_family_23_46_92_x2", "bdrate_family_d2"), ("p_slices", "p_slice_motion_rule"),
                       ("p_slices_large_motion", "p_slice_motion_speed32_832x480")):
         for rnd in ("r03", "r02", "r01"):
             path = os.path.join(ROOT, "profiles", f"{rnd}_{name}.json")
@@ -554,7 +554,9 @@ def main():
         deeper = {}
         nfd = min(nf_local, 16)
         for widths, depth in (((23, 46, 92), 2), ((18, 36, 72), 3)):
-            dctx = capi.Context(W, H, bd, weights.random_family(widths, depth, seed=0), device=local, max_frames=nfd)
+            dblob = os.path.join(ROOT, "fasthevc_amd", "weights", f"depthnet_family_d{depth}.fhw")
+            dw = weights.load_any(dblob) if (depth == 2 and os.path.exists(dblob)) else weights.random_family(widths, depth, seed=0)
+            dctx = capi.Context(W, H, bd, dw, device=local, max_frames=nfd)
             dctx.enable_kernel_timing(True)
             for _ in range(2):
                 dctx.predict_frames_device(luma_ptr, args.sample_bytes, stride, frame_stride, nfd, fdepth.data_ptr(), None, None, stream=stream)
@@ -575,6 +577,7 @@ def main():
             mac += (64 * 4 + 4 * 64 + 16 * 16) * widths[2] * 2
             ach = 2 * mac * nfd * n_ctus / (d_ms * 1e-3) / 1e12
             deeper[f"{widths[0]}/{widths[1]}/{widths[2]} x {depth}"] = {
+                "weights": "trained (" + os.path.basename(dblob) + ")" if (depth == 2 and os.path.exists(dblob)) else "random-init",
                 "value": nfd * n_ctus / (d_ms * 1e-3), "unit": "CTU/s", "ms_per_16_pictures": d_ms, "op_per_ctu": 2 * mac,
                 "roofline": {"bound": "mfma", "kernels": f"{3 * depth} x fhevc_layer_conv_kernel + stage + heads", "achieved": ach, "peak": PEAK_I8_TOPS,
                              "unit": "TOP/s (2 per MAC, unpadded)", "frac": ach / PEAK_I8_TOPS}}
