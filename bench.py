@@ -579,7 +579,7 @@ def main():
             deeper[f"{widths[0]}/{widths[1]}/{widths[2]} x {depth}"] = {
                 "weights": "trained (" + os.path.basename(dblob) + ")" if (depth == 2 and os.path.exists(dblob)) else "random-init",
                 "value": nfd * n_ctus / (d_ms * 1e-3), "unit": "CTU/s", "ms_per_16_pictures": d_ms, "op_per_ctu": 2 * mac,
-                "roofline": {"bound": "mfma", "kernels": f"{3 * depth} x fhevc_layer_conv_kernel + stage + heads", "achieved": ach, "peak": PEAK_I8_TOPS,
+                "roofline": {"bound": "mfma", "kernels": f"{3 * depth - 1} x fhevc_layer_conv_kernel (the first convolution inside the second) + stage + heads", "achieved": ach, "peak": PEAK_I8_TOPS,
                              "unit": "TOP/s (2 per MAC, unpadded)", "frac": ach / PEAK_I8_TOPS}}
         family_line["deeper_members_layer_by_layer"] = deeper
 

@@ -1995,6 +1995,11 @@ hipError_t fhevc_cnn_prepare_device()
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_layer_conv_kernel<KCV, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
   FHEVC_LAYER_LDS(1) FHEVC_LAYER_LDS(2) FHEVC_LAYER_LDS(3) FHEVC_LAYER_LDS(4)
 #undef FHEVC_LAYER_LDS
+#define FHEVC_LAYER_FUSE(KCV) \
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_layer_conv_kernel<KCV, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_layer_conv_kernel<KCV, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+  FHEVC_LAYER_FUSE(1) FHEVC_LAYER_FUSE(2)
+#undef FHEVC_LAYER_FUSE
   return e;
 }
 
@@ -2113,16 +2118,22 @@ hipError_t fhevc_launch_cnn_layers(const FhevcFrames& fr, const FhevcLayersWeigh
     if (fr.sample_bytes == 2) hipLaunchKernelGGL((fhevc_layers_stage_kernel<int16_t>), dim3(count < 4096 ? count : 4096), dim3(256), 0, stream, fr, first, count, w.in0);
     else hipLaunchKernelGGL((fhevc_layers_stage_kernel<uint8_t>), dim3(count < 4096 ? count : 4096), dim3(256), 0, stream, fr, first, count, w.in0);
     const int8_t* in = w.in0;
-    for (int i = 0; i < w.num_layers; ++i) {
+    // members with two or three convolutions per block: the first convolution is computed inside the second one's LDS staging (FUSE0) where the
+    // second one's strips fit LDS and its width is at most 64
+    const bool no_fuse = std::getenv("FHEVC_LAYERS_NO_FUSE") != nullptr;   // (tests: the unfused form of the same member)
+    const bool fuse0 = !no_fuse && w.num_layers > 3 && w.l[0].kc == 0 && !w.l[0].pool && w.l[1].kc >= 1 && w.l[1].kc <= 2 && w.l[0].cout_pad == w.l[1].kc * 32;
+    for (int i = fuse0 ? 1 : 0; i < w.num_layers; ++i) {
       const FhevcLayer& L = w.l[i];
+      const FhevcFirstConv first = { w.in0, w.l[0].frag, w.l[0].bias, w.l[0].shift };
       // the input map (or, at 64 x 64, a strip of 32 rows of it) staged in LDS per workgroup item where it fits 80 KB; the first layer reads HBM directly
       int strip = L.H;
       while (strip > 8 && (size_t)(strip + 2) * (L.H + 2) * (L.kc * 32) > 80 * 1024) strip >>= 1;
       const size_t map_bytes = (size_t)(strip + 2) * (L.H + 2) * (L.kc * 32);
       const bool use_lds = L.kc > 0 && map_bytes <= 80 * 1024;
       const int litems = count * (L.H / strip), lgrid = litems < 2048 ? litems : 2048;
-#define FHEVC_LAYER(KCV, POOLV) do { if (use_lds) hipLaunchKernelGGL((fhevc_layer_conv_kernel<KCV, POOLV, KCV != 0>), dim3(lgrid), dim3(256), map_bytes, stream, in, L.out, L.frag, L.bias, L.shift, L.H, L.cout_pad, count, strip); \
-                                      else hipLaunchKernelGGL((fhevc_layer_conv_kernel<KCV, POOLV, false>), dim3(grid), dim3(256), 0, stream, in, L.out, L.frag, L.bias, L.shift, L.H, L.cout_pad, count, L.H); } while (0)
+#define FHEVC_LAYER(KCV, POOLV) do { if (use_lds && fuse0 && i == 1) hipLaunchKernelGGL((fhevc_layer_conv_kernel<KCV, POOLV, KCV != 0, KCV == 1 || KCV == 2>), dim3(lgrid), dim3(256), map_bytes, stream, in, L.out, L.frag, L.bias, L.shift, L.H, L.cout_pad, count, strip, first); \
+                                      else if (use_lds) hipLaunchKernelGGL((fhevc_layer_conv_kernel<KCV, POOLV, KCV != 0>), dim3(lgrid), dim3(256), map_bytes, stream, in, L.out, L.frag, L.bias, L.shift, L.H, L.cout_pad, count, strip, first); \
+                                      else hipLaunchKernelGGL((fhevc_layer_conv_kernel<KCV, POOLV, false>), dim3(grid), dim3(256), 0, stream, in, L.out, L.frag, L.bias, L.shift, L.H, L.cout_pad, count, L.H, first); } while (0)
       switch (L.kc * 2 + (L.pool ? 1 : 0)) {
         case 0: FHEVC_LAYER(0, false); break; case 1: FHEVC_LAYER(0, true); break;
         case 2: FHEVC_LAYER(1, false); break; case 3: FHEVC_LAYER(1, true); break;
