@@ -554,8 +554,12 @@ def main():
         deeper = {}
         nfd = min(nf_local, 16)
         for widths, depth in (((23, 46, 92), 2), ((18, 36, 72), 3)):
+          try:   # (a secondary line: a failure here is reported in place, it never takes the headline down)
             dblob = os.path.join(ROOT, "fasthevc_amd", "weights", f"depthnet_family_d{depth}.fhw")
-            dw = weights.load_any(dblob) if (depth == 2 and os.path.exists(dblob)) else weights.random_family(widths, depth, seed=0)
+            dw = weights.load_any(dblob) if os.path.exists(dblob) else None
+            trained = dw is not None and tuple(int(v) for v in dw.get("widths", ())) == widths and int(dw.get("depth", 0)) == depth
+            if not trained:
+                dw = weights.random_family(widths, depth, seed=0)
             dctx = capi.Context(W, H, bd, dw, device=local, max_frames=nfd)
             dctx.enable_kernel_timing(True)
             for _ in range(2):
@@ -577,10 +581,12 @@ def main():
             mac += (64 * 4 + 4 * 64 + 16 * 16) * widths[2] * 2
             ach = 2 * mac * nfd * n_ctus / (d_ms * 1e-3) / 1e12
             deeper[f"{widths[0]}/{widths[1]}/{widths[2]} x {depth}"] = {
-                "weights": "trained (" + os.path.basename(dblob) + ")" if (depth == 2 and os.path.exists(dblob)) else "random-init",
+                "weights": "trained (" + os.path.basename(dblob) + ")" if trained else "random-init",
                 "value": nfd * n_ctus / (d_ms * 1e-3), "unit": "CTU/s", "ms_per_16_pictures": d_ms, "op_per_ctu": 2 * mac,
                 "roofline": {"bound": "mfma", "kernels": f"{3 * depth - 1} x fhevc_layer_conv_kernel (the first convolution inside the second) + stage + heads", "achieved": ach, "peak": PEAK_I8_TOPS,
                              "unit": "TOP/s (2 per MAC, unpadded)", "frac": ach / PEAK_I8_TOPS}}
+          except Exception as exc:   # noqa: BLE001
+            deeper[f"{widths[0]}/{widths[1]}/{widths[2]} x {depth}"] = {"error": repr(exc)}
         family_line["deeper_members_layer_by_layer"] = deeper
 
     if rank == 0:
