@@ -178,7 +178,7 @@ def quoted_bd_rate():
     """the quality half of BASELINE's metric, quoted from the committed evaluations under profiles/ (tests/quality/eval_rd.py,
     eval_p.py: minutes of CPU each, not re-run here)"""
     out = {}
-    for tag, name in (("intra", "bdrate_generalization"), ("intra_family_32_64_128", "bdrate_family_d1"), ("intra_family_23_46_92_x2", "bdrate_family_d2"), ("p_slices", "p_slice_motion_rule"),
+    for tag, name in (("intra", "bdrate_generalization"), ("intra_family_32_64_128", "bdrate_family_d1"), ("intra_family_23_46_92_x2", "bdrate_family_d2"), ("intra_family_18_36_72_x3", "bdrate_family_d3"), ("p_slices", "p_slice_motion_rule"),
                       ("p_slices_large_motion", "p_slice_motion_speed32_832x480")):
         for rnd in ("r03", "r02", "r01"):
             path = os.path.join(ROOT, "profiles", f"{rnd}_{name}.json")
