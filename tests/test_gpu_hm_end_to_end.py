@@ -127,6 +127,43 @@ def _next_p(lib, y, W, H, qp, poc, fmin=None, fmax=None):
     return d.reshape(n, 256), s
 
 
+@pytest.mark.skipif(not os.path.exists(GPU_SO), reason="oracle/_ref/libhmref_hookgpu.so is built where /root/reference exists")
+def test_reference_encoder_driven_by_a_family_member_on_the_layer_path(oracle):
+    """FHEVC_WEIGHTS may name any member of the reference's network family (FHW3): here the trained NetworkDepth-2 member 23 / 46 / 92 x 2, which the
+    library runs layer by layer through HBM (k_cnn_layers.inc).  The reference's compressSlice driven by it through the hook == the CPU hook fed with
+    the oracle's ranges for the same blob."""
+    blob = os.path.join(ROOT, "fasthevc_amd", "weights", "depthnet_family_d2.fhw")
+    fam_arrays = weights.load_any(blob)
+    assert int(fam_arrays["depth"]) == 2
+    hook = op.bind_rdo(op.load_ref(hook=True))
+    gpu = op.bind_rdo(op.load_ref(hook="gpu"))
+    W, H, margin = 512, 384, 8000
+    buf, org, stride, chroma = _picture(W, H)
+    n = (W // 64) * (H // 64)
+    fam = op.family_from_arrays(fam_arrays)
+    pred, logits = np.zeros(n * 256, np.uint8), np.zeros(n * 42, np.int32)
+    oracle.fho_predict_frame_family(C.byref(fam), op.ptr(buf.reshape(-1), org), stride, W, H, 8, QP, pred.ctypes.data, logits.ctypes.data)
+    dmin, dmax = np.zeros((n, 256), np.uint8), np.zeros((n, 256), np.uint8)
+    for c in range(n):
+        oracle.fho_depth_range_from_logits(np.ascontiguousarray(logits[c * 42:(c + 1) * 42]), 64, 64, margin, margin, dmin[c], dmax[c])
+    d_ref, s_ref = op.rdo_encode(hook, buf, org, stride, W, H, 8, QP, forced_depth=dmin, forced_depth_max=dmax, chroma=chroma)
+    d_full, _ = op.rdo_encode(hook, buf, org, stride, W, H, 8, QP, chroma=chroma)
+    saved = {k: os.environ.get(k) for k in KNOBS}
+    try:
+        for k in KNOBS:
+            os.environ.pop(k, None)
+        os.environ.update({"FHEVC_ENABLE": "1", "FHEVC_WEIGHTS": blob, "FHEVC_MARGIN": str(margin)})
+        d_gpu, s_gpu = op.rdo_encode(gpu, buf, org, stride, W, H, 8, QP, chroma=chroma)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert np.array_equal(d_gpu, d_ref) and s_gpu["bits"] == s_ref["bits"] and s_gpu["dist"] == s_ref["dist"]
+    assert not np.array_equal(d_gpu, d_full)
+
+
 @pytest.mark.parametrize("size,rng,speeds", [((640, 448), 4, (3, 3)), ((576, 384), 64, (21, -17))])
 @pytest.mark.skipif(not os.path.exists(PGPU_SO), reason="oracle/_ref/libhmref_pgpu.so is built where /root/reference exists")
 def test_config4_p_pictures_driven_by_the_gpu_motion_search(oracle, size, rng, speeds):
