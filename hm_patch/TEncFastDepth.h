@@ -7,7 +7,8 @@
  *
  * Knobs arrive through the environment so that TAppEncCfg stays untouched:
  *   FHEVC_ENABLE=1            turn the path on
- *   FHEVC_WEIGHTS=<file>      FHW1 weight blob
+ *   FHEVC_WEIGHTS=<file>      weight blob: FHW1 (the 16 / 32 / 64 network) or FHW3 (any member of the reference's network family, e.g.
+ *                             depthnet_family_d2.fhw = 23 / 46 / 92 x 2, the best classifier shipped)
  *   FHEVC_DEVICE=<ordinal>    HIP device (default 0)
  *   FHEVC_MARGIN=<int>        soft decisions: logit margin inside which a split decision is left to HM's RDO;
  *   FHEVC_MARGIN_SPLIT / FHEVC_MARGIN_STOP set the two sides separately (not forcing unsure splits is almost free,
