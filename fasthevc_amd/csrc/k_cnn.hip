@@ -2131,7 +2131,7 @@ hipError_t fhevc_launch_cnn_layers(const FhevcFrames& fr, const FhevcLayersWeigh
       const size_t map_bytes = (size_t)(strip + 2) * (L.H + 2) * (L.kc * 32);
       const bool use_lds = L.kc > 0 && map_bytes <= 80 * 1024;
       const int litems = count * (L.H / strip), lgrid = litems < 2048 ? litems : 2048;
-#define FHEVC_LAYER(KCV, POOLV) do { if (use_lds && fuse0 && i == 1) hipLaunchKernelGGL((fhevc_layer_conv_kernel<KCV, POOLV, KCV != 0, KCV == 1 || KCV == 2>), dim3(lgrid), dim3(256), map_bytes, stream, in, L.out, L.frag, L.bias, L.shift, L.H, L.cout_pad, count, strip, first); \
+#define FHEVC_LAYER(KCV, POOLV) do { if (use_lds && fuse0 && i == 1) hipLaunchKernelGGL((fhevc_layer_conv_kernel<KCV, POOLV, KCV != 0, KCV == 1 || KCV == 2>), dim3(lgrid), dim3(256), map_bytes + 16 + 36 * 66, stream, in, L.out, L.frag, L.bias, L.shift, L.H, L.cout_pad, count, strip, first); \
                                       else if (use_lds) hipLaunchKernelGGL((fhevc_layer_conv_kernel<KCV, POOLV, KCV != 0>), dim3(lgrid), dim3(256), map_bytes, stream, in, L.out, L.frag, L.bias, L.shift, L.H, L.cout_pad, count, strip, first); \
                                       else hipLaunchKernelGGL((fhevc_layer_conv_kernel<KCV, POOLV, false>), dim3(grid), dim3(256), 0, stream, in, L.out, L.frag, L.bias, L.shift, L.H, L.cout_pad, count, L.H, first); } while (0)
       switch (L.kc * 2 + (L.pool ? 1 : 0)) {
