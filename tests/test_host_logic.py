@@ -117,3 +117,29 @@ def test_p_motion_compensated_depth_equals_the_oracle(oracle):
     for c in range(cw * ch):
         inside[c, :min(16, (H - (c // cw) * 64) // 4), :min(16, (W - (c % cw) * 64) // 4)] = True
     assert np.array_equal(still.reshape(-1, 16, 16)[inside], prev.reshape(-1, 16, 16)[inside])
+
+
+def test_cost_sensitive_training_utilities():
+    """fasthevc_amd/train/train.py: the z-order -> raster mapping of the recorded node costs, and the tree regret (0 for the cheapest tree, the cost
+    difference for a single wrong decision)."""
+    from fasthevc_amd.train import train
+    rng = np.random.default_rng(5)
+    cost = rng.uniform(100, 1000, size=(6, 21, 2)).astype(np.float32)
+    g = train.cost_grids(cost)
+    # node 5 + b (z-order) = block (by, bx): b = 4 q + s, by = 2 (q >> 1) + (s >> 1), bx = 2 (q & 1) + (s & 1)
+    for b in range(16):
+        q, s = b >> 2, b & 3
+        assert np.array_equal(g["ns16"][:, 2 * (q >> 1) + (s >> 1), 2 * (q & 1) + (s & 1)], cost[:, 5 + b, 0])
+    for q in range(4):
+        assert np.array_equal(g["sp32"][:, q >> 1, q & 1], cost[:, 1 + q, 1])
+    # the cheapest tree under the metric's own approximation, bottom-up
+    o16 = g["sp16"] < g["ns16"]
+    j16 = np.where(o16, g["sp16"], g["ns16"]).reshape(-1, 2, 2, 2, 2).sum(axis=(2, 4))
+    o32 = j16 < g["ns32"]
+    o64 = np.where(o32, j16, g["ns32"]).sum(axis=(1, 2)) < g["ns64"]
+    chosen, best = train.tree_regret(o64, o32, o16, g)
+    assert abs(chosen - best) < 1e-3 * best
+    worse, _ = train.tree_regret(~o64, o32, o16, g)
+    assert worse > best
+    flipped = train.flip_costs(g)
+    assert np.array_equal(flipped["ns16"][:, :, ::-1], g["ns16"]) and np.array_equal(flipped["ns64"], g["ns64"])
