@@ -2127,9 +2127,10 @@ hipError_t fhevc_launch_cnn_layers(const FhevcFrames& fr, const FhevcLayersWeigh
       const FhevcFirstConv first = { w.in0, w.l[0].frag, w.l[0].bias, w.l[0].shift };
       // the input map (or, at 64 x 64, a strip of 32 rows of it) staged in LDS per workgroup item where it fits 80 KB; the first layer reads HBM directly
       int strip = L.H;
-      while (strip > 8 && (size_t)(strip + 2) * (L.H + 2) * (L.kc * 32) > 80 * 1024) strip >>= 1;
+      static const size_t lds_limit = std::getenv("FHEVC_LAYERS_LDS_KB") ? (size_t)std::atoi(std::getenv("FHEVC_LAYERS_LDS_KB")) * 1024 : 80 * 1024;   // (experiments)
+      while (strip > 8 && (size_t)(strip + 2) * (L.H + 2) * (L.kc * 32) > lds_limit) strip >>= 1;
       const size_t map_bytes = (size_t)(strip + 2) * (L.H + 2) * (L.kc * 32);
-      const bool use_lds = L.kc > 0 && map_bytes <= 80 * 1024;
+      const bool use_lds = L.kc > 0 && map_bytes <= lds_limit;
       const int litems = count * (L.H / strip), lgrid = litems < 2048 ? litems : 2048;
 #define FHEVC_LAYER(KCV, POOLV) do { if (use_lds && fuse0 && i == 1) hipLaunchKernelGGL((fhevc_layer_conv_kernel<KCV, POOLV, KCV != 0, KCV == 1 || KCV == 2>), dim3(lgrid), dim3(256), map_bytes + 16 + 36 * 66, stream, in, L.out, L.frag, L.bias, L.shift, L.H, L.cout_pad, count, strip, first); \
                                       else if (use_lds) hipLaunchKernelGGL((fhevc_layer_conv_kernel<KCV, POOLV, KCV != 0>), dim3(lgrid), dim3(256), map_bytes, stream, in, L.out, L.frag, L.bias, L.shift, L.H, L.cout_pad, count, strip, first); \
