@@ -194,3 +194,23 @@ def test_wide_sad_search_extremes_and_uint8_batch(oracle):
     with pytest.raises(capi.FastHevcError):
         ctx.motion_search(cb, rb, org, stride, qp=qp, search_range=9)
     ctx.close()
+
+
+def test_wide_sad_search_on_a_ctu_row_band():
+    """The +-64 search over a CTU-row band of a device-resident batch (fhevc_band partitions) equals the same rows of the whole-picture search."""
+    import torch
+    W, H, rng, qp = 320, 256, 64, 33
+    ys = frames.pan_clip(W, H, 3, seed=11, v_structure=-27, v_noise=14)
+    d8 = torch.from_numpy(np.stack(ys)).cuda()
+    ctx = capi.Context(W, H, 8)
+    ctx.set_motion_distortion("sad")
+    n, cw = ctx.num_ctus, 5
+    full = torch.zeros((2, n, 85, 16), dtype=torch.uint8, device="cuda")
+    ctx.motion_search_device(d8.data_ptr(), 1, W, W * H, 3, full.data_ptr(), qp=qp, search_range=rng)
+    band = torch.zeros((2, 2 * cw, 85, 16), dtype=torch.uint8, device="cuda")
+    ctx.motion_search_device(d8.data_ptr(), 1, W, W * H, 3, band.data_ptr(), rows=(1, 3), qp=qp, search_range=rng)
+    torch.cuda.synchronize()
+    f, b = full.cpu().numpy(), band.cpu().numpy()
+    assert np.array_equal(b, f[:, cw:3 * cw])
+    assert (f.view(capi.MOTION_DTYPE)["mvx"] != 0).any()
+    ctx.close()
