@@ -128,6 +128,17 @@ def test_every_family_member_through_the_layered_path(oracle, monkeypatch, width
         assert np.array_equal(depth[f].cpu().numpy(), refs[f][3]), f
         assert np.array_equal(expanded[f].cpu().numpy(), refs[f][3]), f
     ctx.close()
+    # a batch larger than the chunk of CTUs whose activations live in HBM at once (max_frames = 1 -> 64 CTUs): several passes over the layers
+    small = capi.Context(W, H, bd, fam, max_frames=1)
+    order = [0, 1, 0, 1, 1, 0, 0][:max(3, 200 // n + 2)]
+    d16b = torch.from_numpy(np.stack([refs[i][0] for i in order])).to(dev)
+    depthb = torch.zeros((len(order), n, 256), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    small.predict_frames_device(d16b.data_ptr() + 2 * org, 2, stride, planes.shape[1] * planes.shape[2], len(order), depthb.data_ptr(), None, None, qp=qp)
+    torch.cuda.synchronize()
+    for k, i in enumerate(order):
+        assert np.array_equal(depthb[k].cpu().numpy(), refs[i][3]), (k, i)
+    small.close()
 
 
 def test_family_members_the_build_cannot_run_are_refused_with_a_status():
