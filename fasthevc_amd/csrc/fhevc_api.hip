@@ -365,7 +365,13 @@ int build_layers_image(fhevc_ctx* c, const uint8_t* blob, size_t bytes, int C1, 
       const int pool = (j == depth - 1) && b < 2, Ho = pool ? H / 2 : H;
       FhevcLayer& L = lw.l[li];
       void* dfrag = dev(frag.size(), 0); void* dbias = dev(bias.size() * 4, 0);
-      L.out = static_cast<int8_t*>(dev((size_t)lw.chunk * (Ho + 2) * (Ho + 2) * cout_pad, 0x80));   // halo = "activation 0", written here once
+      // the tensor's row pitch carries the padding its consumer's LDS image wants (the last map goes to the heads kernel: none)
+      const int ni = li + 1, nb = ni / depth, nj = ni % depth;
+      int in_pad = 0, swz = 0, out_pad = 0, unused = 0;
+      if (!first) fhevc_layer_lds_image(kc, pool, H, &in_pad, &swz);
+      if (ni < 3 * depth) fhevc_layer_lds_image(cout_pad / 32, (nj == depth - 1) && nb < 2, Ho, &out_pad, &unused);
+      L.in_pad = in_pad; L.out_pad = out_pad; L.swz = swz;
+      L.out = static_cast<int8_t*>(dev((size_t)lw.chunk * (Ho + 2) * ((size_t)(Ho + 2) * cout_pad + out_pad), 0x80));   // halo = "activation 0", written here once
       if (!dfrag || !dbias || !L.out) return fail(c, FHEVC_E_HIP, "layer buffers");
       HIP_TRY(c, hipMemcpy(dfrag, frag.data(), frag.size(), hipMemcpyHostToDevice));
       HIP_TRY(c, hipMemcpy(dbias, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));

@@ -78,9 +78,12 @@ bool fhevc_cnn_family_supported(int c1, int c2, int c3);
 struct FhevcLayer {
   const uint4* frag;     // [M tile][K chunk][tap 9][64 lanes] (first layer: [M tile][64]: K = the nine taps of the one input channel)
   const int32_t* bias;   // [cout_pad], + 128 * sum of the filter's weights (not for the first layer: its input is centred samples)
-  int8_t* out;           // [chunk CTUs][Ho + 2][Ho + 2][cout_pad]
+  int8_t* out;           // [chunk CTUs][Ho + 2] rows of ([Ho + 2][cout_pad] + out_pad bytes)
   int shift, kc, cout_pad, H, pool;   // kc = Cin_pad / 32 (0: first layer); H = input size (64 / 32 / 16)
+  int in_pad, out_pad, swz;           // bytes added to the row pitch of the input / output tensor; XOR mask of the LDS image (fhevc_layer_lds_image)
 };
+// the row-pitch padding and XOR mask that make the layer kernel's LDS reads conflict-free for an input of kc x 32 channels at H x H (tools/lds_swizzle_search.py)
+void fhevc_layer_lds_image(int kc, int pool, int H, int* pad, int* mask);
 struct FhevcLayersWeights {
   int num_layers, chunk, c3, c3_pad;
   FhevcLayer l[9];

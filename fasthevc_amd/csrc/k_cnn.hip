@@ -2108,6 +2108,21 @@ hipError_t fhevc_launch_cnn_family(const FhevcFrames& fr, const FhevcFamilyWeigh
 }
 
 // ---- any member of the family, layer by layer through HBM (k_cnn_layers.inc) ----
+void fhevc_layer_lds_image(int kc, int pool, int H, int* pad, int* mask)
+{
+  // tools/lds_swizzle_search.py: (pad bytes, mask) per [kc - 1][pool][H == 16, 32, 64]; every entry reads at 4 LDS cycles per ds_read_b128 (conflict-free)
+  static const unsigned char T[4][2][3][2] = {
+    { { { 16, 0 }, { 0, 1 }, { 0, 1 } }, { { 192, 3 }, { 16, 1 }, { 0, 3 } } },
+    { { { 32, 1 }, { 0, 3 }, { 0, 3 } }, { { 16, 1 }, { 32, 3 }, { 0, 7 } } },
+    { { { 16, 0 }, { 0, 1 }, { 0, 1 } }, { { 64, 3 }, { 16, 1 }, { 0, 3 } } },
+    { { { 64, 3 }, { 0, 7 }, { 0, 7 } }, { { 32, 3 }, { 64, 7 }, { 0, 15 } } } };
+  *pad = 0; *mask = 0;
+  if (kc < 1 || kc > 4 || (H != 16 && H != 32 && H != 64)) return;
+  if (!(kc == 2 || kc == 4 || (kc == 3 && pool))) return;   // two-way conflicted plain images stay plain (the kernel's SWZ)
+  const unsigned char* e = T[kc - 1][pool ? 1 : 0][H == 16 ? 0 : (H == 32 ? 1 : 2)];
+  *pad = e[0]; *mask = e[1];
+}
+
 hipError_t fhevc_launch_cnn_layers(const FhevcFrames& fr, const FhevcLayersWeights& w, uint8_t* d_depth, int32_t* d_logits, uint32_t* d_flags,
                                    uint8_t* d_depth_max, int margin_split, int margin_stop, int num_cus, hipStream_t stream)
 {
@@ -2128,13 +2143,23 @@ hipError_t fhevc_launch_cnn_layers(const FhevcFrames& fr, const FhevcLayersWeigh
       // the input map (or, at 64 x 64, a strip of 32 rows of it) staged in LDS per workgroup item where it fits 80 KB; the first layer reads HBM directly
       int strip = L.H;
       static const size_t lds_limit = std::getenv("FHEVC_LAYERS_LDS_KB") ? (size_t)std::atoi(std::getenv("FHEVC_LAYERS_LDS_KB")) * 1024 : 80 * 1024;   // (experiments)
-      while (strip > 8 && (size_t)(strip + 2) * (L.H + 2) * (L.kc * 32) > lds_limit) strip >>= 1;
-      const size_t map_bytes = (size_t)(strip + 2) * (L.H + 2) * (L.kc * 32);
-      const bool use_lds = L.kc > 0 && map_bytes <= lds_limit;
-      const int litems = count * (L.H / strip), lgrid = litems < 2048 ? litems : 2048;
-#define FHEVC_LAYER(KCV, POOLV) do { if (use_lds && fuse0 && i == 1) hipLaunchKernelGGL((fhevc_layer_conv_kernel<KCV, POOLV, KCV != 0, KCV == 1 || KCV == 2>), dim3(lgrid), dim3(256), map_bytes + 16 + 36 * 66, stream, in, L.out, L.frag, L.bias, L.shift, L.H, L.cout_pad, count, strip, first); \
-                                      else if (use_lds) hipLaunchKernelGGL((fhevc_layer_conv_kernel<KCV, POOLV, KCV != 0>), dim3(lgrid), dim3(256), map_bytes, stream, in, L.out, L.frag, L.bias, L.shift, L.H, L.cout_pad, count, strip, first); \
-                                      else hipLaunchKernelGGL((fhevc_layer_conv_kernel<KCV, POOLV, false>), dim3(grid), dim3(256), 0, stream, in, L.out, L.frag, L.bias, L.shift, L.H, L.cout_pad, count, L.H, first); } while (0)
+      // maps that come from HBM: two buffers where a strip of at least 16 rows fits twice (the next item streams in behind the current one's MFMAs)
+      const bool no_dbuf = std::getenv("FHEVC_LAYERS_NO_DBUF") != nullptr;   // (tests, experiments: the single-buffered staging)
+      const bool fused_here = fuse0 && i == 1;
+      const size_t in_pitch = (size_t)(L.H + 2) * (L.kc * 32) + L.in_pad, extra = fused_here ? 16 + 36 * 66 : 0;
+      auto image = [&](int rows) { return (((size_t)(rows + 2) * in_pitch + 255) & ~(size_t)255); };   // a strip's LDS image: whole 256-byte rows (the XOR stays inside one)
+      int strip2 = L.H;
+      while (strip2 > 8 && 2 * image(strip2) > lds_limit) strip2 >>= 1;
+      const int dbuf = (!no_dbuf && !fused_here && L.kc > 0 && strip2 >= 16 && 2 * image(strip2) <= lds_limit) ? 1 : 0;
+      if (dbuf) strip = strip2;
+      else while (strip > 8 && image(strip) + extra > lds_limit) strip >>= 1;
+      const size_t map_bytes = image(strip);
+      const bool use_lds = L.kc > 0 && map_bytes + extra <= lds_limit;
+      static const int lcap = std::getenv("FHEVC_LAYERS_GRID") ? std::atoi(std::getenv("FHEVC_LAYERS_GRID")) : 2048;   // (experiments)
+      const int litems = count * (L.H / strip), lgrid = litems < lcap ? litems : lcap;
+#define FHEVC_LAYER(KCV, POOLV) do { if (use_lds && fuse0 && i == 1) hipLaunchKernelGGL((fhevc_layer_conv_kernel<KCV, POOLV, KCV != 0, KCV == 1 || KCV == 2>), dim3(lgrid), dim3(256), map_bytes + 16 + 36 * 66, stream, in, L.out, L.frag, L.bias, L.shift, L.H, L.cout_pad, count, strip, first, 0, L.in_pad, L.out_pad, L.swz); \
+                                      else if (use_lds) hipLaunchKernelGGL((fhevc_layer_conv_kernel<KCV, POOLV, KCV != 0>), dim3(lgrid), dim3(256), map_bytes << dbuf, stream, in, L.out, L.frag, L.bias, L.shift, L.H, L.cout_pad, count, strip, first, dbuf, L.in_pad, L.out_pad, L.swz); \
+                                      else hipLaunchKernelGGL((fhevc_layer_conv_kernel<KCV, POOLV, false>), dim3(grid), dim3(256), 0, stream, in, L.out, L.frag, L.bias, L.shift, L.H, L.cout_pad, count, L.H, first, 0, L.in_pad, L.out_pad, 0); } while (0)
       switch (L.kc * 2 + (L.pool ? 1 : 0)) {
         case 0: FHEVC_LAYER(0, false); break; case 1: FHEVC_LAYER(0, true); break;
         case 2: FHEVC_LAYER(1, false); break; case 3: FHEVC_LAYER(1, true); break;

@@ -90,7 +90,11 @@ def test_family_code_path_reproduces_the_base_network(oracle):
 
 @pytest.mark.parametrize("widths,depth,W,H,bd,seed,fuse", [((23, 46, 92), 2, 416, 240, 8, 0, True), ((18, 36, 72), 3, 416, 240, 8, 1, True), ((23, 46, 92), 2, 200, 136, 10, 2, False),
                                                            ((32, 64, 128), 1, 416, 240, 8, 3, True), ((20, 44, 100), 2, 256, 192, 8, 4, True), ((12, 24, 48), 3, 320, 256, 12, 5, True),
-                                                           ((40, 60, 100), 2, 416, 240, 8, 6, True), ((18, 36, 72), 3, 256, 192, 8, 7, False), ((70, 80, 96), 2, 200, 136, 8, 8, True)])
+                                                           ((40, 60, 100), 2, 416, 240, 8, 6, True), ((18, 36, 72), 3, 256, 192, 8, 7, False), ((70, 80, 96), 2, 200, 136, 8, 8, True),
+                                                           # every LDS image of the layer kernel: 96 / 128 channels in (three- and four-chunk K, pooled and not), and the
+                                                           # single-buffered staging ("1buf": FHEVC_LAYERS_NO_DBUF) next to the default double-buffered LDS-direct one
+                                                           ((96, 128, 128), 2, 256, 192, 8, 9, True), ((100, 70, 96), 3, 200, 136, 8, 10, True), ((23, 46, 92), 2, 256, 192, 8, 11, "1buf"),
+                                                           ((64, 128, 64), 3, 200, 136, 10, 12, "1buf")])
 def test_every_family_member_through_the_layered_path(oracle, monkeypatch, widths, depth, W, H, bd, seed, fuse):
     """The members without a fused kernel -- NetworkDepth 2 (23 / 46 / 92) and 3 (18 / 36 / 72) of the reference's family, and odd widths -- run layer by
     layer through HBM (k_cnn_layers.inc): depth maps, logits, soft ranges and split-flag words against the oracle's plain loops, ragged pictures,
@@ -99,6 +103,8 @@ def test_every_family_member_through_the_layered_path(oracle, monkeypatch, width
     monkeypatch.setenv("FHEVC_FAMILY_LAYERS", "1")
     if not fuse:   # the first convolution as its own launch instead of inside the second one's LDS staging
         monkeypatch.setenv("FHEVC_LAYERS_NO_FUSE", "1")
+    if fuse == "1buf":
+        monkeypatch.setenv("FHEVC_LAYERS_NO_DBUF", "1")
     fam = weights.random_family(widths, depth, seed=seed)
     qp = 22 + 5 * seed
     lumas = [frames.hetero_luma(W, H, seed=80 + seed), frames.texture16_luma(W, H, seed=90 + seed)]
