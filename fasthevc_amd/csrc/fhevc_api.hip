@@ -387,10 +387,12 @@ int build_layers_image(fhevc_ctx* c, const uint8_t* blob, size_t bytes, int C1, 
   const int8_t* wh16 = reinterpret_cast<const int8_t*>(take((size_t)2 * 16 * C3));
   const uint8_t* bh16p = take(8);
   const uint8_t* qpb = take(3 * 52 * 4);
-  std::vector<uint8_t> whead((size_t)(2 * 64 + 2 * 64 + 2 * 16) * C3);
-  std::memcpy(whead.data(), wh64, (size_t)2 * 64 * C3);
-  std::memcpy(whead.data() + (size_t)2 * 64 * C3, wh32, (size_t)2 * 64 * C3);
-  std::memcpy(whead.data() + (size_t)4 * 64 * C3, wh16, (size_t)2 * 16 * C3);
+  // rows of c3_pad bytes (zeros behind the C3 weights): the heads kernel reads activations and weights 16 bytes at a time
+  const size_t cp = lw.c3_pad;
+  std::vector<uint8_t> whead((size_t)(2 * 64 + 2 * 64 + 2 * 16) * cp, 0);
+  for (int r = 0; r < 2 * 64; ++r) std::memcpy(whead.data() + (size_t)r * cp, wh64 + (size_t)r * C3, (size_t)C3);
+  for (int r = 0; r < 2 * 64; ++r) std::memcpy(whead.data() + (size_t)(2 * 64 + r) * cp, wh32 + (size_t)r * C3, (size_t)C3);
+  for (int r = 0; r < 2 * 16; ++r) std::memcpy(whead.data() + (size_t)(4 * 64 + r) * cp, wh16 + (size_t)r * C3, (size_t)C3);
   for (uint8_t v : whead) if (v == 0x80) return fail(c, FHEVC_E_WEIGHTS, "weight -128 not allowed");
   int32_t bhead[6 + 3 * 52] = { i32at(bh64p, 0), i32at(bh64p, 1), i32at(bh32p, 0), i32at(bh32p, 1), i32at(bh16p, 0), i32at(bh16p, 1) };
   for (int cls = 0; cls < 2; ++cls) {

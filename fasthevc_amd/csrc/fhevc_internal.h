@@ -88,7 +88,7 @@ struct FhevcLayersWeights {
   int num_layers, chunk, c3, c3_pad;
   FhevcLayer l[9];
   int8_t* in0;             // [chunk CTUs][66][66]
-  const uint8_t* whead;    // wh64[2][8][8][c3], wh32[2][8][8][c3], wh16[2][4][4][c3]
+  const uint8_t* whead;    // wh64[2][8][8][c3_pad], wh32[2][8][8][c3_pad], wh16[2][4][4][c3_pad] (zeros behind the c3 weights)
   const int32_t* bhead;    // as FhevcCnnWeights::bhead
 };
 
