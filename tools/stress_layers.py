@@ -29,6 +29,10 @@ for seed in range(2000, 2000 + N):
         os.environ["FHEVC_LAYERS_NO_FUSE"] = "1"
     else:
         os.environ.pop("FHEVC_LAYERS_NO_FUSE", None)
+    if seed % 5 == 0:   # the single-buffered staging instead of the double-buffered LDS-direct one
+        os.environ["FHEVC_LAYERS_NO_DBUF"] = "1"
+    else:
+        os.environ.pop("FHEVC_LAYERS_NO_DBUF", None)
     luma = frames.fractal_luma(W + 8, H + 8, seed=seed)[:H, :W].copy() if seed % 2 else frames.texture16_luma(W, H, seed=seed)
     buf, org, stride = frames.to_pel_plane(luma, bd)
     n = ((W + 63) // 64) * ((H + 63) // 64)
@@ -42,4 +46,6 @@ for seed in range(2000, 2000 + N):
     if not ok:
         bad += 1
         print("MISMATCH", seed, widths, depth, W, H, bd, qp, flush=True)
+    if (seed - 2000) % 20 == 19:
+        print(seed - 2000 + 1, "configurations,", bad, "mismatches", flush=True)
 print("done, mismatches:", bad)
