@@ -11,6 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from fasthevc_amd import capi, frames, weights  # noqa: E402
 
+if os.environ.get("FHEVC_AB_LIB"):   # a variant library built by tools/build_variant.sh
+    capi.LIB_PATH = os.environ["FHEVC_AB_LIB"]
 widths = tuple(int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "23,46,92").split(","))
 depth = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 W, H, NF = 1920, 1080, 16
