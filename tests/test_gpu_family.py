@@ -152,3 +152,31 @@ def test_family_members_the_build_cannot_run_are_refused_with_a_status():
     with pytest.raises(capi.FastHevcError) as e:
         capi.Context(416, 240, 8, fam)
     assert e.value.code == capi.E_WEIGHTS
+
+
+@pytest.mark.parametrize("blob,bd,qp", [("depthnet_family_d1.fhw", 8, 32), ("depthnet_family_d2.fhw", 8, 27), ("depthnet_family_d2.fhw", 10, 37), ("depthnet_family_d3.fhw", 8, 32)])
+def test_the_shipped_family_blobs_equal_the_oracle(oracle, blob, bd, qp):
+    """The TRAINED members as shipped (fasthevc_amd/weights/): their weight statistics differ from the random members of the other tests (small sums of
+    |w| per filter, shifts 6 / 8) -- depth maps and logits of two pictures through the library's default dispatch (fused kernel for 32 / 64 / 128 x 1,
+    the layer path for the x 2 and x 3 members) against the oracle, bit for bit."""
+    import os
+    import torch
+    fam = weights.load_any(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fasthevc_amd", "weights", blob))
+    W, H = 416, 240
+    lumas = [frames.hetero_luma(W, H, seed=7), frames.texture16_luma(W, H, seed=8)]
+    refs = [_oracle_family(oracle, fam, y, bd, qp) for y in lumas]
+    ctx = capi.Context(W, H, bd, fam, max_frames=2)
+    dev = torch.device("cuda:0")
+    planes = np.stack([r[0] for r in refs])
+    d16 = torch.from_numpy(planes).to(dev)
+    org, stride, n = refs[0][1], refs[0][2], ctx.num_ctus
+    depth = torch.zeros((2, n, 256), dtype=torch.uint8, device=dev)
+    logits = torch.zeros((2, n, 42), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ctx.predict_frames_device(d16.data_ptr() + 2 * org, 2, stride, planes.shape[1] * planes.shape[2], 2, depth.data_ptr(), None, logits.data_ptr(), qp=qp)
+    torch.cuda.synchronize()
+    for f in range(2):
+        assert np.array_equal(logits[f].cpu().numpy(), refs[f][4]), f
+        assert np.array_equal(depth[f].cpu().numpy(), refs[f][3]), f
+    assert len(np.unique(depth.cpu().numpy())) >= 3
+    ctx.close()
