@@ -2171,8 +2171,9 @@ hipError_t fhevc_launch_cnn_layers(const FhevcFrames& fr, const FhevcLayersWeigh
 #undef FHEVC_LAYER
       in = L.out;
     }
-    hipLaunchKernelGGL(fhevc_layers_heads_kernel, dim3(count < 8 * num_cus ? count : 8 * num_cus), dim3(256), 0, stream, fr, in, w.c3, w.c3_pad, w.whead, w.bhead,
-                       first, count, d_depth, d_logits, d_flags, d_depth_max, margin_split, margin_stop);
+#define FHEVC_HEADS(CPV) hipLaunchKernelGGL((fhevc_layers_heads_kernel<CPV>), dim3(count < 2 * num_cus ? count : 2 * num_cus), dim3(256), (size_t)18 * 18 * w.c3_pad, stream, fr, in, w.c3, w.c3_pad, w.whead, w.bhead, first, count, d_depth, d_logits, d_flags, d_depth_max, margin_split, margin_stop)
+    switch (w.c3_pad >> 5) { case 1: FHEVC_HEADS(1); break; case 2: FHEVC_HEADS(2); break; case 3: FHEVC_HEADS(3); break; case 4: FHEVC_HEADS(4); break; default: return hipErrorInvalidValue; }
+#undef FHEVC_HEADS
   }
   return hipGetLastError();
 }
