@@ -222,13 +222,41 @@ def main():
     ap.add_argument("--no-variants", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only prove the N-rank launch: rendezvous, one barrier and one all-gather of the ranks over the host group, then exit "
+                         "(no GPU is touched: the CPU test of the self-launcher uses this with --backend gloo)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Plain `python bench.py --gpus N`: start the N ranks ourselves, one process per GPU, exactly as the driver's launcher would
+        # (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...).  This parent has not touched the GPU and never
+        # does: it only relays the children's output (rank 0 prints the JSON line) and their exit code -- no exec of a GPU process.
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        raise SystemExit(subprocess.call(cmd, env=env))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}, "
+                         f"or run `python bench.py --gpus {args.gpus}` without WORLD_SIZE set and it starts the ranks itself")
+    if args.launch_check:
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.barrier()
+        got = [None] * world
+        dist.all_gather_object(got, (rank, local, os.getpid()))
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "world": world, "ranks": sorted(g[0] for g in got), "distinct_processes": len({g[2] for g in got})}), flush=True)
+        dist.destroy_process_group()
+        return
     mode = "bands" if args.bands else "frames"
     scaling = "strong" if args.bands else args.scaling
     W = args.width or (3840 if args.bands else 1920)

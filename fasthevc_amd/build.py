@@ -29,7 +29,9 @@ def build_hip(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     objdir = os.path.join(LIBDIR, "obj")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "fhevc_internal.h"), os.path.join(os.path.dirname(HERE), "include", "fasthevc.h")]
+    # every header and every .inc fragment under csrc/ (k_cnn.hip includes k_cnn_family.inc, k_cnn_layers.inc, ...): an edit to any of them rebuilds
+    headers = [os.path.join(os.path.dirname(HERE), "include", "fasthevc.h")]
+    headers += sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc")))
     jobs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)

@@ -35,6 +35,9 @@ struct fhevc_ctx {
   bool fam_layers = false;            // ... run layer by layer through HBM (k_cnn_layers.inc): every member the two fused kernels do not cover
   FhevcLayersWeights lw = {};
   std::vector<void*> lw_bufs;         // everything lw points to (freed with the context / the next blob)
+  // the layer path's activation tensors are ONE set per context: a launch on another stream than the previous one waits for that one's last kernel
+  // (the host batch alternates two streams; callers may pass any stream per call)
+  hipEvent_t lw_done = nullptr; hipStream_t lw_last_stream = nullptr; bool lw_in_flight = false;
   int fam_c[3] = { 0, 0, 0 };
   uint4* f_frag1 = nullptr; float* f_bias1 = nullptr; uint4* f_frag2 = nullptr; uint4* f_frag3 = nullptr; int32_t* f_bias_i8 = nullptr;
   uint8_t* f_whead = nullptr; uint8_t* f_headm = nullptr; int32_t* f_bhead = nullptr;
@@ -52,6 +55,7 @@ struct fhevc_ctx {
   bool cnn_pipe = false;      // FHEVC_CNN_PIPE=1: the i8 form as the two-stage software pipeline over CTUs (k_cnn.hip: fhevc_cnn_depth_pipe_kernel)
   bool had_valu = true;       // FHEVC_HADAMARD_FORM=mfma: the fused Hadamard of 8-bit content on the bf16 MFMA from the staged tile instead of packed
                               // 16-bit VALU (parity-green, and measured 7 % SLOWER in round 3: profiles/r03_ab_hadamard_forms.log) -- kept for A/B and tests
+  FhevcKnobs knobs;           // the environment's tuning / test switches, read once in fhevc_create
   bool timing = false;
   std::vector<TimedLaunch> pending;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
@@ -63,6 +67,7 @@ struct fhevc_ctx {
   FhevcNodeCost* d_cand_all = nullptr; uint8_t* d_cand = nullptr;   // fhevc_intra_first_pass_candidates: every (node, mode) cost, the lists
   uint32_t* d_mvtab = nullptr;        // vector costs of the wide search (k_motion_wide.hip), rebuilt when (qp, range) changes
   int mvtab_qp = -1, mvtab_range = -1;
+  hipEvent_t mvtab_used = nullptr;    // recorded behind every launch that reads d_mvtab, on whatever stream the caller passed: the rebuild waits for it
   std::vector<uint32_t> mvtab_host;
   // host-batch ring (fhevc_predict_frames): two slots, each with its own stream, device buffers and pinned staging
   struct Slot {
@@ -145,11 +150,11 @@ inline int32_t rd32(const int32_t* p, int i)  // unaligned-safe read
 // Build the device weight image: MFMA A-operand fragments in lane order (k_cnn.hip header comment).
 int build_weight_image(fhevc_ctx* c, const BlobView& b)
 {
+  int new_shift[3], new_mode[3] = { 0, 0, 0 };
   for (int l = 0; l < 3; ++l) {
     const int s = rd32(b.shift, l);
     if (s < 0 || s > 14) return fail(c, FHEVC_E_WEIGHTS, "shift out of range (0..14)");
-    c->scale[l] = std::ldexp(1.0f, -s);
-    c->shift[l] = s;
+    new_shift[l] = s;
   }
   std::vector<uint16_t> frag((size_t)FHEVC_FRAG_TOTAL * 8, 0);
   // all conv weights carry their layer's 2^-shift: w * 2^-s is still exact in bf16 (a power-of-two scaling of an 8-bit integer)
@@ -256,10 +261,9 @@ int build_weight_image(fhevc_ctx* c, const BlobView& b)
     bound[2] = std::max(bound[2], (long long)std::abs(bias8[48 + oc]) + 128LL * sa);
   }
   // the requant's form per layer (k_cnn.hip: requant4_i8); FHEVC_CNN_REQUANT=general keeps the general one (A/B, tests)
-  const char* rq = std::getenv("FHEVC_CNN_REQUANT");
   for (int l = 1; l < 3; ++l) {
     const int sh = rd32(b.shift, l);
-    c->requant_mode[l] = (rq && std::strcmp(rq, "general") == 0) ? 0 : (sh == 8 && bound[l] < (1LL << 23)) ? 2 : (sh <= 7 ? 1 : 0);
+    new_mode[l] = c->knobs.requant_general ? 0 : (sh == 8 && bound[l] < (1LL << 23)) ? 2 : (sh <= 7 ? 1 : 0);
   }
   std::vector<float> bias(112);
   for (int i = 0; i < 16; ++i) {  // the kernel feeds conv1 the samples x, not x - 128: sum w (x - 128) + b = sum w x + (b - 128 sum w)
@@ -288,6 +292,10 @@ int build_weight_image(fhevc_ctx* c, const BlobView& b)
   }
   for (int i = 0; i < 3 * 52; ++i) bhead[6 + i] = rd32(b.qp_bias, i);
 
+  // everything above validated the blob without touching the context.  From here the base image is overwritten in place: if it is the one in
+  // use, a HIP failure below leaves the context WITHOUT weights (predict then fails with FHEVC_E_STATE) rather than with a torn image; if a family
+  // member is in use it stays in use until the last copy has succeeded
+  if (c->have_weights && !c->family) c->have_weights = false;
   if (!c->d_frag) {
     HIP_TRY(c, hipMalloc(&c->d_frag, frag.size() * 2));
     HIP_TRY(c, hipMalloc(&c->d_bias, bias.size() * 4));
@@ -302,6 +310,8 @@ int build_weight_image(fhevc_ctx* c, const BlobView& b)
   HIP_TRY(c, hipMemcpy(c->d_bias, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(c->d_whead, whead.data(), whead.size(), hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(c->d_bhead, bhead, sizeof bhead, hipMemcpyHostToDevice));
+  for (int l = 0; l < 3; ++l) { c->shift[l] = new_shift[l]; c->scale[l] = std::ldexp(1.0f, -new_shift[l]); c->requant_mode[l] = new_mode[l]; }
+  c->family = false; c->fam_layers = false;   // the dispatch flips only now, with the image complete
   c->have_weights = true;
   return FHEVC_OK;
 }
@@ -321,9 +331,25 @@ int build_layers_image(fhevc_ctx* c, const uint8_t* blob, size_t bytes, int C1, 
   auto i32at = [](const uint8_t* p, int i) { int32_t v; std::memcpy(&v, p + 4 * (size_t)i, 4); return v; };
   int32_t shift33[9];
   std::memcpy(shift33, take(36), 36);
+  {  // validate the whole blob before the image in use is touched: a rejected blob leaves the context exactly as it was
+    size_t o = off, cin_v = 1;
+    for (int b = 0; b < 3; ++b)
+      for (int j = 0; j < depth; ++j) {
+        const size_t nw = (size_t)C[b] * cin_v * 9;
+        for (size_t i = 0; i < nw; ++i) if (static_cast<int8_t>(blob[o + i]) == -128) return fail(c, FHEVC_E_WEIGHTS, "weight -128 not allowed");
+        o += nw + 4 * (size_t)C[b];
+        cin_v = (size_t)C[b];
+        if (shift33[b * 3 + j] < 0 || shift33[b * 3 + j] > 14) return fail(c, FHEVC_E_WEIGHTS, "shift out of range (0..14)");
+      }
+    const size_t head_bytes[3] = { (size_t)2 * 64 * C3, (size_t)2 * 64 * C3, (size_t)2 * 16 * C3 };
+    for (int hd = 0; hd < 3; ++hd) {
+      for (size_t i = 0; i < head_bytes[hd]; ++i) if (blob[o + i] == 0x80) return fail(c, FHEVC_E_WEIGHTS, "weight -128 not allowed");
+      o += head_bytes[hd] + 8;
+    }
+  }
   for (void* q : c->lw_bufs) (void)hipFree(q);
   c->lw_bufs.clear();
-  if (c->fam_layers) { c->fam_layers = false; c->family = false; c->have_weights = false; }   // the image being replaced is gone: a failure below leaves NO weights
+  if (c->family && c->fam_layers) c->have_weights = false;   // the layered image in use is gone: a HIP failure below leaves NO weights (never a torn image)
   FhevcLayersWeights lw = {};
   // a chunk of CTUs whose activations live in HBM at once: up to 16 pictures of 1080p (3.2 GB for 23/46/92 x 2), at least one picture row
   lw.chunk = std::min(c->num_ctus * std::max(1, c->cfg.max_frames), 8192);
@@ -424,9 +450,8 @@ int build_family_image(fhevc_ctx* c, const uint8_t* blob, size_t bytes)
   std::memcpy(hdr, blob + 8, 16);
   const int C1 = hdr[0], C2 = hdr[1], C3 = hdr[2], depth = hdr[3];
   if (ver != 1) return fail(c, FHEVC_E_WEIGHTS, "unsupported FHW3 version");
-  if (depth != 1 || !fhevc_cnn_family_supported(C1, C2, C3) || std::getenv("FHEVC_FAMILY_LAYERS"))   // (the knob: the generic path for a fused member too)
+  if (depth != 1 || !fhevc_cnn_family_supported(C1, C2, C3) || c->knobs.family_layers)   // (the knob: the generic path for a fused member too)
     return build_layers_image(c, blob, bytes, C1, C2, C3, depth);
-  c->fam_layers = false;
   const size_t need = 24 + 36 + (size_t)C1 * 9 + 4 * (size_t)C1 + (size_t)C2 * C1 * 9 + 4 * (size_t)C2 + (size_t)C3 * C2 * 9 + 4 * (size_t)C3 +
                       (size_t)(2 * 64 + 2 * 64 + 2 * 16) * C3 + 24 + 3 * 52 * 4;
   if (bytes != need) return fail(c, FHEVC_E_WEIGHTS, "FHW3 blob has the wrong size");
@@ -532,6 +557,8 @@ int build_family_image(fhevc_ctx* c, const uint8_t* blob, size_t bytes)
     bhead[4 + cls] += 128 * s16;
   }
   for (int i = 0; i < 3 * 52; ++i) bhead[6 + i] = i32at(qpb, i);
+  // validated; the fused member's image is replaced now: if it is the one in use, a HIP failure below leaves NO weights
+  if (c->family && !c->fam_layers) c->have_weights = false;
   (void)hipFree(c->f_frag1); (void)hipFree(c->f_bias1); (void)hipFree(c->f_frag2); (void)hipFree(c->f_frag3); (void)hipFree(c->f_bias_i8); (void)hipFree(c->f_whead); (void)hipFree(c->f_headm); (void)hipFree(c->f_bhead);
   c->f_frag1 = nullptr; c->f_headm = nullptr; c->f_bias1 = nullptr; c->f_frag2 = nullptr; c->f_frag3 = nullptr; c->f_bias_i8 = nullptr; c->f_whead = nullptr; c->f_bhead = nullptr;
   HIP_TRY(c, hipMalloc(&c->f_frag1, frag1.size() * 2)); HIP_TRY(c, hipMalloc(&c->f_bias1, bias1.size() * 4));
@@ -547,7 +574,7 @@ int build_family_image(fhevc_ctx* c, const uint8_t* blob, size_t bytes)
   HIP_TRY(c, hipMemcpy(c->f_bhead, bhead, sizeof bhead, hipMemcpyHostToDevice));
   c->fam_c[0] = C1; c->fam_c[1] = C2; c->fam_c[2] = C3;
   c->shift[0] = sh[0]; c->shift[1] = sh[1]; c->shift[2] = sh[2];
-  c->family = true;
+  c->family = true; c->fam_layers = false;
   c->have_weights = true;
   return FHEVC_OK;
 }
@@ -655,6 +682,7 @@ int fhevc_create(fhevc_ctx** out, const fhevc_cfg* cfg)
   if (hipSetDevice(c->device) != hipSuccess || hipGetDeviceProperties(&prop, c->device) != hipSuccess) { delete c; return FHEVC_E_NO_DEVICE; }
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) { delete c; return FHEVC_E_NO_DEVICE; }  // code object is gfx950-only
   c->num_cus = prop.multiProcessorCount;
+  c->knobs = fhevc_read_knobs();   // every environment switch of the library is read here, once per context
   if (const char* fz = std::getenv("FHEVC_FUSE_HADAMARD")) c->fuse_hadamard = fz[0] != '0';
   if (const char* pp = std::getenv("FHEVC_CNN_PIPE")) c->cnn_pipe = pp[0] == '1';
   if (const char* hf = std::getenv("FHEVC_HADAMARD_FORM")) c->had_valu = std::strcmp(hf, "mfma") != 0;
@@ -716,6 +744,8 @@ void fhevc_destroy(fhevc_ctx* c)
   time_resolve(c);
   for (auto& p : c->pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+  if (c->lw_done) (void)hipEventDestroy(c->lw_done);
+  if (c->mvtab_used) (void)hipEventDestroy(c->mvtab_used);
   (void)hipFree(c->d_frag); (void)hipFree(c->d_bias); (void)hipFree(c->d_whead); (void)hipFree(c->d_bhead);
   (void)hipFree(c->d_frag_i8); (void)hipFree(c->d_bias_i8);
   (void)hipFree(c->f_frag1); (void)hipFree(c->f_bias1); (void)hipFree(c->f_frag2); (void)hipFree(c->f_frag3); (void)hipFree(c->f_bias_i8); (void)hipFree(c->f_whead); (void)hipFree(c->f_headm); (void)hipFree(c->f_bhead);
@@ -735,27 +765,33 @@ void fhevc_destroy(fhevc_ctx* c)
 int fhevc_set_weights(fhevc_ctx* c, const void* blob, size_t bytes)
 {
   if (!c || !blob) return FHEVC_E_INVALID;
-  if (bytes >= 4 && std::memcmp(blob, "FHW3", 4) == 0) {  // a member of the reference's Bayesian-optimisation network family
+  // The primary validates and builds first (a rejected blob changes nothing anywhere); only then do the peers get the blob.  A peer that fails after
+  // the primary succeeded would leave devices with different weights: the whole context then reports "weights not set" until a blob is accepted by all
+  auto push_to_peers = [&]() {
     for (fhevc_ctx* peer : c->peers) {
       const int rc = fhevc_set_weights(peer, blob, bytes);
-      if (rc != FHEVC_OK) return fail(c, rc, "weights rejected by a peer device");
+      if (rc != FHEVC_OK) {
+        c->have_weights = false;
+        for (fhevc_ctx* p2 : c->peers) p2->have_weights = false;
+        return fail(c, rc, "weights rejected by a peer device");
+      }
     }
     (void)hipSetDevice(c->device);
-    return build_family_image(c, static_cast<const uint8_t*>(blob), bytes);
+    return (int)FHEVC_OK;
+  };
+  (void)hipSetDevice(c->device);
+  if (bytes >= 4 && std::memcmp(blob, "FHW3", 4) == 0) {  // a member of the reference's Bayesian-optimisation network family
+    const int rc = build_family_image(c, static_cast<const uint8_t*>(blob), bytes);
+    return rc != FHEVC_OK ? rc : push_to_peers();
   }
-  c->family = false;
   BlobView v;
   std::vector<uint8_t> copy;
   if (!parse_blob(static_cast<const uint8_t*>(blob), bytes, v, copy)) return fail(c, FHEVC_E_WEIGHTS, "not an FHW1 blob");
   const struct { const int8_t* p; size_t n; } i8s[6] = { { v.w1, 144 }, { v.w2, 4608 }, { v.w3, 18432 }, { v.wh64, 8192 }, { v.wh32, 8192 }, { v.wh16, 2048 } };
   for (const auto& a : i8s)
     for (size_t i = 0; i < a.n; ++i) if (a.p[i] == -128) return fail(c, FHEVC_E_WEIGHTS, "weight -128 not allowed");
-  for (fhevc_ctx* peer : c->peers) {
-    const int rc = fhevc_set_weights(peer, blob, bytes);
-    if (rc != FHEVC_OK) return fail(c, rc, "weights rejected by a peer device");
-  }
-  (void)hipSetDevice(c->device);
-  return build_weight_image(c, v);
+  const int rc = build_weight_image(c, v);
+  return rc != FHEVC_OK ? rc : push_to_peers();
 }
 
 int fhevc_enable_kernel_timing(fhevc_ctx* c, int on)
@@ -810,9 +846,16 @@ int fhevc_predict_frames_device_range(fhevc_ctx* c, const void* d_luma, int samp
     c->stats.kernels_launched++;
   }
   time_begin(c, s, 0);
-  if (c->family && c->fam_layers) HIP_TRY(c, fhevc_launch_cnn_layers(fr, c->lw, d_depth_map, d_logits, d_flags, d_depth_max, margin_split, margin_stop, c->num_cus, s));
+  if (c->family && c->fam_layers) {
+    if (!c->lw_done) HIP_TRY(c, hipEventCreateWithFlags(&c->lw_done, hipEventDisableTiming));
+    if (c->lw_in_flight && c->lw_last_stream != s) HIP_TRY(c, hipStreamWaitEvent(s, c->lw_done, 0));   // the scratch tensors are still being read there
+    const hipError_t le = fhevc_launch_cnn_layers(fr, c->lw, d_depth_map, d_logits, d_flags, d_depth_max, margin_split, margin_stop, c->num_cus, c->knobs, s);
+    (void)hipEventRecord(c->lw_done, s);   // also after a failed launch: whatever did get queued on s still owns the scratch
+    c->lw_last_stream = s; c->lw_in_flight = true;
+    if (le != hipSuccess) return fail(c, FHEVC_E_HIP, "fhevc_launch_cnn_layers", le);
+  }
   else if (c->family) HIP_TRY(c, fhevc_launch_cnn_family(fr, family_weights(c), d_depth_map, d_logits, d_flags, d_depth_max, margin_split, margin_stop, c->num_cus, s));
-  else HIP_TRY(c, fhevc_launch_cnn(fr, cnn_weights(c), d_depth_map, fuse ? d_hadamard : nullptr, d_logits, d_flags, d_depth_max, margin_split, margin_stop, c->num_cus, s));
+  else HIP_TRY(c, fhevc_launch_cnn(fr, cnn_weights(c), d_depth_map, fuse ? d_hadamard : nullptr, d_logits, d_flags, d_depth_max, margin_split, margin_stop, c->num_cus, c->knobs, s));
   time_end(c, s);
   c->stats.kernels_launched++;
   c->stats.frames += (uint64_t)num_frames;
@@ -1392,7 +1435,7 @@ int fhevc_motion_search_device(fhevc_ctx* c, const void* d_luma, int sample_byte
     auto eg = [](int v) { unsigned len = 1, u = (v <= 0) ? (((unsigned)(-v)) << 1) + 1 : ((unsigned)v) << 1; while (u != 1) { u >>= 1; len += 2; } return len; };
     const int side = 2 * search_range + 1;
     if (!c->d_mvtab) HIP_TRY(c, hipMalloc(&c->d_mvtab, sizeof(uint32_t) * (2 * FHEVC_MOTION_WIDE_MAX_RANGE + 1) * (2 * FHEVC_MOTION_WIDE_MAX_RANGE + 1)));
-    HIP_TRY(c, hipStreamSynchronize(st));  // a launch in flight may still read the old table
+    if (c->mvtab_used) HIP_TRY(c, hipEventSynchronize(c->mvtab_used));  // the last launch that read the old table, on ANY stream (the per-call stream may differ)
     c->mvtab_host.resize((size_t)side * side);
     for (int m = 0; m < side * side; ++m)
       c->mvtab_host[m] = (uint32_t)((motion_lambda * (eg(((m % side) - search_range) << 2) + eg(((m / side) - search_range) << 2))) / 65536.0);
@@ -1400,7 +1443,11 @@ int fhevc_motion_search_device(fhevc_ctx* c, const void* d_luma, int sample_byte
     c->mvtab_qp = qp; c->mvtab_range = search_range;
   }
   time_begin(c, st, 4);
-  if (wide) HIP_TRY(c, fhevc_launch_motion_wide(fr, search_range, c->d_mvtab, reinterpret_cast<FhevcMotionNode*>(d_out), c->num_cus, st));
+  if (wide) {
+    HIP_TRY(c, fhevc_launch_motion_wide(fr, search_range, c->d_mvtab, reinterpret_cast<FhevcMotionNode*>(d_out), c->num_cus, st));
+    if (!c->mvtab_used) HIP_TRY(c, hipEventCreateWithFlags(&c->mvtab_used, hipEventDisableTiming));
+    HIP_TRY(c, hipEventRecord(c->mvtab_used, st));
+  }
   else HIP_TRY(c, fhevc_launch_motion(fr, search_range, mv_cost_table(qp, search_range), reinterpret_cast<FhevcMotionNode*>(d_out), c->num_cus, c->motion_sad, st));
   time_end(c, st);
   c->stats.kernels_launched++;
@@ -1550,7 +1597,7 @@ int fhevc_debug_cnn_phase_cycles(fhevc_ctx* c, const void* d_luma, int sample_by
   HIP_TRY(c, hipMalloc(&d_st, (size_t)max_grid * 8 * sizeof(unsigned long long)));
   HIP_TRY(c, hipMemset(d_st, 0, (size_t)max_grid * 8 * sizeof(unsigned long long)));
   int grid = 0;
-  HIP_TRY(c, fhevc_launch_cnn_stamped(fr, cnn_weights(c), d_depth_map, c->num_cus, d_st, &grid, c->stream));
+  HIP_TRY(c, fhevc_launch_cnn_stamped(fr, cnn_weights(c), d_depth_map, c->num_cus, c->knobs, d_st, &grid, c->stream));
   std::vector<unsigned long long> h((size_t)max_grid * 8);
   HIP_TRY(c, hipMemcpyAsync(h.data(), d_st, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));

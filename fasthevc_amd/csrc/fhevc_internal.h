@@ -28,6 +28,22 @@
 #define FHEVC_FRAGI8_CONV3 (6 * 64)
 #define FHEVC_FRAGI8_TOTAL (6 * 64 + 2 * 9 * 64)
 
+// Tuning / test switches read from the environment ONCE, at fhevc_create (fhevc_read_knobs), and kept in the context: nothing on a launch path
+// calls getenv.  None of them changes results; FHEVC_CNN_ARITH / FHEVC_CNN_REQUANT / FHEVC_HADAMARD_FORM / FHEVC_CNN_PIPE / FHEVC_FUSE_HADAMARD
+// select between forms that the parity suite runs side by side.
+struct FhevcKnobs {
+  int wg_per_cu = 0;            // FHEVC_CNN_WG_PER_CU=1..4: workgroups per CU of the depth kernel's persistent grid (0: the form's own)
+  int debug_wg_per_cu = 0;      // FHEVC_DEBUG_WG_PER_CU=1..4: the same for the stamped diagnostic build only
+  bool requant_general = false; // FHEVC_CNN_REQUANT=general: the i8 form's general requant instead of the short forms
+  bool family_layers = false;   // FHEVC_FAMILY_LAYERS: a member with a fused kernel runs layer by layer all the same (tests)
+  bool fused_d2 = true;         // FHEVC_FUSED_D2=0: the two-convolutions-per-block members run layer by layer instead of through k_cnn_d2.inc (tests, A/B)
+  bool layers_no_fuse = false;  // FHEVC_LAYERS_NO_FUSE: the layer path without the first convolution fused into the second (tests)
+  bool layers_no_dbuf = false;  // FHEVC_LAYERS_NO_DBUF: the layer path's single-buffered staging (tests)
+  size_t layers_lds_limit = 80 * 1024;  // FHEVC_LAYERS_LDS_KB (experiments)
+  int layers_grid = 2048;       // FHEVC_LAYERS_GRID (experiments)
+};
+FhevcKnobs fhevc_read_knobs();
+
 struct FhevcFrames {
   const void* luma;          // device pointer to sample (0,0) of frame 0
   int sample_bytes;          // 1 or 2
@@ -93,7 +109,7 @@ struct FhevcLayersWeights {
 };
 
 hipError_t fhevc_launch_cnn_layers(const FhevcFrames& fr, const FhevcLayersWeights& w, uint8_t* d_depth, int32_t* d_logits, uint32_t* d_flags,
-                                   uint8_t* d_depth_max, int margin_split, int margin_stop, int num_cus, hipStream_t stream);
+                                   uint8_t* d_depth_max, int margin_split, int margin_stop, int num_cus, const FhevcKnobs& knobs, hipStream_t stream);
 
 hipError_t fhevc_cnn_prepare_device();  // LDS opt-in of the depth kernel on the current device (once per context)
 // d_depth_max / margins: soft decisions (nullptr / 0, 0 = the plain map only)
@@ -101,10 +117,10 @@ hipError_t fhevc_cnn_prepare_device();  // LDS opt-in of the depth kernel on the
 // pass over the frame); allowed only where fhevc_cnn_can_fuse_hadamard(fr), otherwise use fhevc_launch_src_hadamard
 bool fhevc_cnn_can_fuse_hadamard(const FhevcFrames& fr);
 hipError_t fhevc_launch_cnn(const FhevcFrames& fr, const FhevcCnnWeights& w, uint8_t* d_depth, int32_t* d_had, int32_t* d_logits,
-                            uint32_t* d_flags, uint8_t* d_depth_max, int margin_split, int margin_stop, int num_cus, hipStream_t stream);
+                            uint32_t* d_flags, uint8_t* d_depth_max, int margin_split, int margin_stop, int num_cus, const FhevcKnobs& knobs, hipStream_t stream);
 hipError_t fhevc_launch_expand_flags(const FhevcFrames& fr, const uint32_t* d_flags, uint8_t* d_depth, hipStream_t stream);
 
-hipError_t fhevc_launch_cnn_stamped(const FhevcFrames& fr, const FhevcCnnWeights& w, uint8_t* d_depth, int num_cus,
+hipError_t fhevc_launch_cnn_stamped(const FhevcFrames& fr, const FhevcCnnWeights& w, uint8_t* d_depth, int num_cus, const FhevcKnobs& knobs,
                                     unsigned long long* d_stamps, int* grid_out, hipStream_t stream);
 
 // ---- source Hadamard + SATD (k_hadamard.hip) ---------------------------------------------------------------

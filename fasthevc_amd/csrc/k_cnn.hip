@@ -24,7 +24,9 @@
 // Round 3 adds, after the kernel: fhevc_cnn_depth_pipe_kernel, the i8 form as a two-stage software pipeline over CTUs (opt-in, measured
 // slower), and k_cnn_family.inc, the reference's Bayesian-optimisation network family (NetworkDepth 1: 32 / 64 / 128 filters).
 #include "fhevc_internal.h"
+#include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8;   // 8 x 16-bit operand slots of an MFMA fragment (bf16 for conv1, f16 for conv2/conv3)
@@ -77,8 +79,32 @@ constexpr int IN_PITCH = 68;                      // dwords per input row PAIR (
 #endif                         // 0.5199 at 0x0122, 0.5093 at 0x0123 (0x0133 0.5124, 0x0022 0.5216, 0x0112 0.5251); the i8 form measures equal across these
 // phase: 0 conv1, 1 conv2, 2 conv3, 3 heads
 #define FHEVC_PRIO_OF(phase) (((I8 ? FHEVC_I8_PRIO : FHEVC_F16_PRIO) >> (4 * (phase))) & 3)
+// (round-4 experiment, FHEVC_SLOT_PRIO = 1 / 2 / 3: the priority also depends on WHICH of the CU's workgroups the wave belongs to -- slot = blockIdx /
+// number of CUs under round-robin dispatch -- so that waves of different workgroups in the same phase do not tie: 1 = static slot priority, no phase
+// levels; 2 = conv phases at 1 + slot, the rest at 0; 3 = conv phases at 1 + slot, the rest at slot.  Measured: see HISTORY.md)
+#ifndef FHEVC_SLOT_PRIO
+#define FHEVC_SLOT_PRIO 0
+#endif
+#define FHEVC_SETPRIO_DYN(p) { const int p_ = (p); if (p_ == 1) __builtin_amdgcn_s_setprio(1); else if (p_ == 2) __builtin_amdgcn_s_setprio(2); else if (p_ >= 3) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); }
+#if FHEVC_SLOT_PRIO == 0
 #define FHEVC_PRIO_ON(phase)  if (FHEVC_PRIO_OF(phase)) __builtin_amdgcn_s_setprio(FHEVC_PRIO_OF(phase));
 #define FHEVC_PRIO_OFF(phase) if (FHEVC_PRIO_OF(phase)) __builtin_amdgcn_s_setprio(0);
+#elif FHEVC_SLOT_PRIO == 1
+#define FHEVC_PRIO_ON(phase)
+#define FHEVC_PRIO_OFF(phase)
+#elif FHEVC_SLOT_PRIO == 2
+#define FHEVC_PRIO_ON(phase)  if (FHEVC_PRIO_OF(phase)) FHEVC_SETPRIO_DYN(1 + prio_slot)
+#define FHEVC_PRIO_OFF(phase) if (FHEVC_PRIO_OF(phase)) __builtin_amdgcn_s_setprio(0);
+#elif FHEVC_SLOT_PRIO == 3
+#define FHEVC_PRIO_ON(phase)  if (FHEVC_PRIO_OF(phase)) FHEVC_SETPRIO_DYN(1 + prio_slot)
+#define FHEVC_PRIO_OFF(phase) if (FHEVC_PRIO_OF(phase)) FHEVC_SETPRIO_DYN(prio_slot)
+#else  // 4: a table, one 16-bit group 0x<heads><conv3><conv2><conv1> per slot (slot 0 in the low bits)
+#ifndef FHEVC_SLOT_TABLE
+#define FHEVC_SLOT_TABLE 0x033302220111ULL
+#endif
+#define FHEVC_PRIO_ON(phase)  FHEVC_SETPRIO_DYN((int)((FHEVC_SLOT_TABLE >> (16 * prio_slot + 4 * (phase))) & 3))
+#define FHEVC_PRIO_OFF(phase) __builtin_amdgcn_s_setprio(0);
+#endif
 // tuning knobs of the i8 form's pipeline descriptions (VALU instructions offered per MFMA group of a chain; fences around the pools).
 // conv2 measured best with the chains pinned as (MFMA, DS read) groups only and the epilogue VALU left to the scheduler, without
 // fences: 0.4322 ms (fences, 2 / 5 VALU per group) -> 0.4226 (no fences) -> 0.4212 (no fences, no VALU groups), same-box A/B
@@ -898,6 +924,9 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   constexpr bool I8 = ARITH != 0, FASTRQ = ARITH == 2;
+  const int prio_slot = (FHEVC_SLOT_PRIO && I8 && gridDim.x % 3 == 0) ? (int)(blockIdx.x / (gridDim.x / 3)) : 0;   // (experiment: see FHEVC_SLOT_PRIO)
+  (void)prio_slot;
+  if (FHEVC_SLOT_PRIO == 1 || FHEVC_SLOT_PRIO == 3) FHEVC_SETPRIO_DYN(prio_slot)
   constexpr bool MFMA_HEADS = FHEVC_MFMA_HEADS_F16 || I8;  // the two smaller FC heads as an i8 MFMA GEMM (P4)
   (void)FASTRQ;
   using L = Lds<I8>;
@@ -2027,20 +2056,36 @@ void launch_depth_kernel(int grid, hipStream_t stream, const FhevcFrames& fr, co
 int cnn_arith(const FhevcCnnWeights& w) { return !w.i8 ? 0 : (w.requant_mode[1] == 1 && w.requant_mode[2] == 2) ? 2 : 1; }
 }  // namespace
 
-// workgroups per CU of the persistent grid (FHEVC_CNN_WG_PER_CU overrides: a tuning knob)
-static int cnn_wg_per_cu(const FhevcCnnWeights& w)
+// the switches of FhevcKnobs, read once per context (fhevc_create)
+FhevcKnobs fhevc_read_knobs()
 {
-  const char* e = getenv("FHEVC_CNN_WG_PER_CU");
-  if (e && e[0] >= '1' && e[0] <= '4') return e[0] - '0';
+  FhevcKnobs k;
+  auto digit = [](const char* e) { return (e && e[0] >= '1' && e[0] <= '4') ? e[0] - '0' : 0; };
+  k.wg_per_cu = digit(std::getenv("FHEVC_CNN_WG_PER_CU"));
+  k.debug_wg_per_cu = digit(std::getenv("FHEVC_DEBUG_WG_PER_CU"));
+  if (const char* rq = std::getenv("FHEVC_CNN_REQUANT")) k.requant_general = std::strcmp(rq, "general") == 0;
+  k.family_layers = std::getenv("FHEVC_FAMILY_LAYERS") != nullptr;
+  if (const char* fd = std::getenv("FHEVC_FUSED_D2")) k.fused_d2 = fd[0] != '0';
+  k.layers_no_fuse = std::getenv("FHEVC_LAYERS_NO_FUSE") != nullptr;
+  k.layers_no_dbuf = std::getenv("FHEVC_LAYERS_NO_DBUF") != nullptr;
+  if (const char* kb = std::getenv("FHEVC_LAYERS_LDS_KB")) k.layers_lds_limit = (size_t)std::min(80, std::max(8, std::atoi(kb))) * 1024;   // <= the opt-in of fhevc_cnn_prepare_device
+  if (const char* lg = std::getenv("FHEVC_LAYERS_GRID")) k.layers_grid = std::atoi(lg);
+  return k;
+}
+
+// workgroups per CU of the persistent grid (FHEVC_CNN_WG_PER_CU overrides: a tuning knob)
+static int cnn_wg_per_cu(const FhevcCnnWeights& w, const FhevcKnobs& knobs)
+{
+  if (knobs.wg_per_cu) return knobs.wg_per_cu;
   return w.i8 ? FHEVC_I8_WG_PER_CU : 2;  // what the variants' LDS and register budgets are sized for
 }
 
 hipError_t fhevc_launch_cnn(const FhevcFrames& fr, const FhevcCnnWeights& w, uint8_t* d_depth, int32_t* d_had, int32_t* d_logits,
-                            uint32_t* d_flags, uint8_t* d_depth_max, int margin_split, int margin_stop, int num_cus, hipStream_t stream)
+                            uint32_t* d_flags, uint8_t* d_depth_max, int margin_split, int margin_stop, int num_cus, const FhevcKnobs& knobs, hipStream_t stream)
 {
   const long long total = (long long)(fr.row_end - fr.row_begin) * fr.ctus_x * fr.num_frames;
   if (total <= 0) return hipSuccess;
-  int grid = cnn_wg_per_cu(w) * num_cus;
+  int grid = cnn_wg_per_cu(w, knobs) * num_cus;
   if (total < grid) grid = (int)total;
 #define FHEVC_LAUNCH(HAD, ARITH) launch_depth_kernel<false, HAD, ARITH>(grid, stream, fr, w, d_depth, d_had, d_logits, d_flags, nullptr, d_depth_max, margin_split, margin_stop)
   // the fused source Hadamard's form: on the MFMA from the staged tile for 8-bit content (the tile IS the samples), on packed
@@ -2048,7 +2093,7 @@ hipError_t fhevc_launch_cnn(const FhevcFrames& fr, const FhevcCnnWeights& w, uin
   const int had = d_had == nullptr ? 0 : (fr.bit_depth == 8 && !w.had_valu) ? 2 : 1;
   if (w.i8 && w.pipe && had != 2) {  // the software-pipelined form of the i8 kernel: two workgroups per CU
     int pgrid = 2 * num_cus;
-    if (const char* e = getenv("FHEVC_CNN_WG_PER_CU")) if (e[0] == '1') pgrid = num_cus;
+    if (knobs.wg_per_cu == 1) pgrid = num_cus;
     if (total < pgrid) pgrid = (int)total;
 #define FHEVC_LAUNCH_PIPE(HAD, ARITH) hipLaunchKernelGGL((fhevc_cnn_depth_pipe_kernel<HAD, ARITH>), dim3(pgrid), dim3(256), LdsPipe::LDS_BYTES, stream, fr, w, d_depth, d_had, \
                                                          d_logits, d_flags, d_depth_max, margin_split, margin_stop)
@@ -2069,13 +2114,12 @@ hipError_t fhevc_launch_cnn(const FhevcFrames& fr, const FhevcCnnWeights& w, uin
 }
 
 // diagnostic build of the same kernel with s_memtime stamps; d_stamps: grid * 8 cycle sums (phases P0..P5)
-hipError_t fhevc_launch_cnn_stamped(const FhevcFrames& fr, const FhevcCnnWeights& w, uint8_t* d_depth, int num_cus,
+hipError_t fhevc_launch_cnn_stamped(const FhevcFrames& fr, const FhevcCnnWeights& w, uint8_t* d_depth, int num_cus, const FhevcKnobs& knobs,
                                     unsigned long long* d_stamps, int* grid_out, hipStream_t stream)
 {
   const long long total = (long long)(fr.row_end - fr.row_begin) * fr.ctus_x * fr.num_frames;
   // FHEVC_DEBUG_WG_PER_CU=1: one workgroup per CU, i.e. the phase times without a second workgroup on the same SIMDs
-  const char* per_cu = getenv("FHEVC_DEBUG_WG_PER_CU");
-  int grid = ((per_cu && per_cu[0] >= '1' && per_cu[0] <= '4') ? per_cu[0] - '0' : cnn_wg_per_cu(w)) * num_cus;
+  int grid = (knobs.debug_wg_per_cu ? knobs.debug_wg_per_cu : cnn_wg_per_cu(w, knobs)) * num_cus;
   if (total < grid) grid = (int)total;
   *grid_out = grid;
   if (total <= 0) return hipSuccess;
@@ -2124,7 +2168,7 @@ void fhevc_layer_lds_image(int kc, int pool, int H, int* pad, int* mask)
 }
 
 hipError_t fhevc_launch_cnn_layers(const FhevcFrames& fr, const FhevcLayersWeights& w, uint8_t* d_depth, int32_t* d_logits, uint32_t* d_flags,
-                                   uint8_t* d_depth_max, int margin_split, int margin_stop, int num_cus, hipStream_t stream)
+                                   uint8_t* d_depth_max, int margin_split, int margin_stop, int num_cus, const FhevcKnobs& knobs, hipStream_t stream)
 {
   const int total = (fr.row_end - fr.row_begin) * fr.ctus_x * fr.num_frames;
   const int grid = 3 * num_cus;   // x 4 waves: a multiple of 12 waves (M tiles of 1 .. 4 divide it)
@@ -2132,19 +2176,20 @@ hipError_t fhevc_launch_cnn_layers(const FhevcFrames& fr, const FhevcLayersWeigh
     const int count = total - first < w.chunk ? total - first : w.chunk;
     if (fr.sample_bytes == 2) hipLaunchKernelGGL((fhevc_layers_stage_kernel<int16_t>), dim3(count < 4096 ? count : 4096), dim3(256), 0, stream, fr, first, count, w.in0);
     else hipLaunchKernelGGL((fhevc_layers_stage_kernel<uint8_t>), dim3(count < 4096 ? count : 4096), dim3(256), 0, stream, fr, first, count, w.in0);
+    if (const hipError_t le = hipGetLastError(); le != hipSuccess) return le;
     const int8_t* in = w.in0;
     // members with two or three convolutions per block: the first convolution is computed inside the second one's LDS staging (FUSE0) where the
     // second one's strips fit LDS and its width is at most 64
-    const bool no_fuse = std::getenv("FHEVC_LAYERS_NO_FUSE") != nullptr;   // (tests: the unfused form of the same member)
+    const bool no_fuse = knobs.layers_no_fuse;   // (tests: the unfused form of the same member)
     const bool fuse0 = !no_fuse && w.num_layers > 3 && w.l[0].kc == 0 && !w.l[0].pool && w.l[1].kc >= 1 && w.l[1].kc <= 2 && w.l[0].cout_pad == w.l[1].kc * 32;
     for (int i = fuse0 ? 1 : 0; i < w.num_layers; ++i) {
       const FhevcLayer& L = w.l[i];
       const FhevcFirstConv first = { w.in0, w.l[0].frag, w.l[0].bias, w.l[0].shift };
       // the input map (or, at 64 x 64, a strip of 32 rows of it) staged in LDS per workgroup item where it fits 80 KB; the first layer reads HBM directly
       int strip = L.H;
-      static const size_t lds_limit = std::getenv("FHEVC_LAYERS_LDS_KB") ? (size_t)std::atoi(std::getenv("FHEVC_LAYERS_LDS_KB")) * 1024 : 80 * 1024;   // (experiments)
+      const size_t lds_limit = knobs.layers_lds_limit;   // (experiments: FHEVC_LAYERS_LDS_KB)
       // maps that come from HBM: two buffers where a strip of at least 16 rows fits twice (the next item streams in behind the current one's MFMAs)
-      const bool no_dbuf = std::getenv("FHEVC_LAYERS_NO_DBUF") != nullptr;   // (tests, experiments: the single-buffered staging)
+      const bool no_dbuf = knobs.layers_no_dbuf;   // (tests, experiments: the single-buffered staging)
       const bool fused_here = fuse0 && i == 1;
       const size_t in_pitch = (size_t)(L.H + 2) * (L.kc * 32) + L.in_pad, extra = fused_here ? 16 + 36 * 66 : 0;
       auto image = [&](int rows) { return (((size_t)(rows + 2) * in_pitch + 255) & ~(size_t)255); };   // a strip's LDS image: whole 256-byte rows (the XOR stays inside one)
@@ -2155,7 +2200,7 @@ hipError_t fhevc_launch_cnn_layers(const FhevcFrames& fr, const FhevcLayersWeigh
       else while (strip > 8 && image(strip) + extra > lds_limit) strip >>= 1;
       const size_t map_bytes = image(strip);
       const bool use_lds = L.kc > 0 && map_bytes + extra <= lds_limit;
-      static const int lcap = std::getenv("FHEVC_LAYERS_GRID") ? std::atoi(std::getenv("FHEVC_LAYERS_GRID")) : 2048;   // (experiments)
+      const int lcap = knobs.layers_grid;   // (experiments: FHEVC_LAYERS_GRID)
       const int litems = count * (L.H / strip), lgrid = litems < lcap ? litems : lcap;
 #define FHEVC_LAYER(KCV, POOLV) do { if (use_lds && fuse0 && i == 1) hipLaunchKernelGGL((fhevc_layer_conv_kernel<KCV, POOLV, KCV != 0, KCV == 1 || KCV == 2>), dim3(lgrid), dim3(256), map_bytes + 16 + 36 * 66, stream, in, L.out, L.frag, L.bias, L.shift, L.H, L.cout_pad, count, strip, first, 0, L.in_pad, L.out_pad, L.swz); \
                                       else if (use_lds) hipLaunchKernelGGL((fhevc_layer_conv_kernel<KCV, POOLV, KCV != 0>), dim3(lgrid), dim3(256), map_bytes << dbuf, stream, in, L.out, L.frag, L.bias, L.shift, L.H, L.cout_pad, count, strip, first, dbuf, L.in_pad, L.out_pad, L.swz); \
@@ -2169,11 +2214,13 @@ hipError_t fhevc_launch_cnn_layers(const FhevcFrames& fr, const FhevcLayersWeigh
         default: return hipErrorInvalidValue;
       }
 #undef FHEVC_LAYER
+      if (const hipError_t le = hipGetLastError(); le != hipSuccess) return le;   // a refused launch must not let the later layers run on stale activations
       in = L.out;
     }
 #define FHEVC_HEADS(CPV) hipLaunchKernelGGL((fhevc_layers_heads_kernel<CPV>), dim3(count < 2 * num_cus ? count : 2 * num_cus), dim3(256), (size_t)18 * 18 * w.c3_pad, stream, fr, in, w.c3, w.c3_pad, w.whead, w.bhead, first, count, d_depth, d_logits, d_flags, d_depth_max, margin_split, margin_stop)
     switch (w.c3_pad >> 5) { case 1: FHEVC_HEADS(1); break; case 2: FHEVC_HEADS(2); break; case 3: FHEVC_HEADS(3); break; case 4: FHEVC_HEADS(4); break; default: return hipErrorInvalidValue; }
 #undef FHEVC_HEADS
+    if (const hipError_t le = hipGetLastError(); le != hipSuccess) return le;
   }
-  return hipGetLastError();
+  return hipSuccess;
 }

@@ -176,3 +176,59 @@ def init_groups(world, rank, device, backend="nccl", timeout_s=120):
     if not agree(ok):  # one rank without RCCL: every rank gathers through the host, and says so
         return False, None
     return group, None
+
+
+# ---- SURVEY 8(e)'s literal form: the 256-byte depth maps themselves on the wire (CTU-row bands), kept for the band parity test; bench.py and the
+# library's callers use FlagGather above (4 B per CTU) ----
+def band(ctu_rows, rank, world):
+    """rows [begin, end) of rank `rank`: same arithmetic as fhevc_band (fasthevc_amd/csrc/fhevc_api.hip) = span()"""
+    return span(ctu_rows, rank, world)
+
+
+def max_band_rows(ctu_rows, world):
+    return max(band(ctu_rows, r, world)[1] - band(ctu_rows, r, world)[0] for r in range(world))
+
+
+def alloc_gather_buffers(num_frames, ctu_rows, ctus_x, world, device):
+    """(gathered, local_view): gathered is [world, frames, max_band_rows, ctus_x, 256] uint8; every rank's slice has
+    the same (padded) size, as all_gather_into_tensor requires."""
+    mb = max_band_rows(ctu_rows, world)
+    gathered = torch.zeros((world, num_frames, mb, ctus_x, 256), dtype=torch.uint8, device=device)
+    return gathered
+
+
+def all_gather_depth(gathered, rank, group=None):
+    """In-place all-gather: every rank has written gathered[rank]; afterwards all slices are filled everywhere."""
+    world = gathered.shape[0]
+    if world == 1:
+        return gathered
+    flat = gathered.view(world, -1)
+    dist.all_gather_into_tensor(flat.view(-1), flat[rank].clone() if flat.device.type == "cpu" else flat[rank], group=group)
+    return gathered
+
+
+def assemble(gathered, ctu_rows):
+    """[world, frames, max_band_rows, ctus_x, 256] -> [frames, ctu_rows * ctus_x, 256] in CTU raster order."""
+    world, frames, _, ctus_x, _ = gathered.shape
+    parts = []
+    for r in range(world):
+        b, e = band(ctu_rows, r, world)
+        parts.append(gathered[r, :, : e - b])
+    full = torch.cat(parts, dim=1)
+    return full.reshape(frames, ctu_rows * ctus_x, 256)
+
+
+def alloc_flag_buffers(num_frames, num_ctus, world, device):
+    """[world, frames, numCtus] int32 split-flag words (frames dealt to ranks): 4 B per CTU on the wire instead of the
+    256 B depth map; every rank expands the gathered words with fhevc_expand_depth_flags_device."""
+    return torch.zeros((world, num_frames, num_ctus), dtype=torch.int32, device=device)
+
+
+def all_gather_flags(gathered, rank, group=None):
+    world = gathered.shape[0]
+    if world == 1:
+        return gathered
+    flat = gathered.view(world, -1)
+    src = flat[rank].clone() if flat.device.type == "cpu" else flat[rank]
+    dist.all_gather_into_tensor(flat.view(-1), src, group=group)
+    return gathered

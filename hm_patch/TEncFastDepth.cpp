@@ -60,8 +60,12 @@ void TEncFastDepth::readKnobs()
   // aligned to the CU grid and decides worse than the co-located one even under a global pan of 32 samples per picture
   const char* pc = std::getenv("FHEVC_P_MC");
   m_pMotionCompensated = pc != NULL && std::atoi(pc) != 0;
+  // The wide rule (fhevc_p_rule_default_wide) was fitted -- and measured, profiles/r03_p_slice_wide_*.json -- on SAD features of the +-64 search WITH the
+  // reference picture's depths taken at the displaced position: FHEVC_P_RANGE > 8 therefore turns the displaced depths on unless FHEVC_P_MC says
+  // otherwise, and with FHEVC_P_MC=0 the wide search feeds the DEFAULT rule (fitted on co-located depths) instead of a rule it was not fitted for
+  if (m_pRange > 8 && pc == NULL) m_pMotionCompensated = true;
 #ifndef FHEVC_HOOK_NO_GPU
-  if (m_pRange > 8) fhevc_p_rule_default_wide(P_RULE); else fhevc_p_rule_default(P_RULE);
+  if (m_pRange > 8 && m_pMotionCompensated) fhevc_p_rule_default_wide(P_RULE); else fhevc_p_rule_default(P_RULE);
   const char* pt = std::getenv("FHEVC_P_THRESH");   // "split64,split32,split16,stop64,stop32,stop16" in score units (1.0 = 2^18)
   if (pt != NULL)
   {

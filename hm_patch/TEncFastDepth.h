@@ -19,7 +19,7 @@
  *   FHEVC_P_MODE=window|motion  P/B pictures whose first reference picture was inter coded (default: off = stock RDO):
  *                             window = co-located depth of that picture +- FHEVC_P_WINDOW levels (host logic only, independent of
  *                             FHEVC_ENABLE); motion = GPU motion search of every CU node in the reference's ORIGINAL picture
- *                             (FHEVC_P_RANGE = window radius 1..64, default 4; above 8: SAD search + FHEVC_P_MC depths at the motion-compensated position) + fhevc_p_depth_range (needs FHEVC_ENABLE=1);
+ *                             (FHEVC_P_RANGE = window radius 1..64, default 4; above 8: SAD search, and the displaced depths of FHEVC_P_MC come on with it -- the combination the wide rule was fitted and measured on; FHEVC_P_MC=0 keeps co-located depths and the default rule) + fhevc_p_depth_range (needs FHEVC_ENABLE=1);
  *                             FHEVC_P_THRESH overrides the six thresholds of the rule, FHEVC_P_WINDOW adds the +- clip to it
  *   FHEVC_FIRST_PASS=1        intra pictures: the candidate list of TEncSearch::estIntraPredLumaQT (the numModesForFullRD modes its 35-mode
  *                             Hadamard pass would pick) comes from the GPU's first pass over the ORIGINAL picture for PUs of 8x8 and larger

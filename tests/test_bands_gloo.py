@@ -8,7 +8,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from fasthevc_amd import bands, frames, weights
+from fasthevc_amd import frames, weights
+from fasthevc_amd import gather as bands
 
 
 def _free_port():

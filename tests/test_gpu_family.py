@@ -180,3 +180,45 @@ def test_the_shipped_family_blobs_equal_the_oracle(oracle, blob, bd, qp):
         assert np.array_equal(depth[f].cpu().numpy(), refs[f][3]), f
     assert len(np.unique(depth.cpu().numpy())) >= 3
     ctx.close()
+
+
+def test_a_rejected_blob_leaves_the_weights_in_use_untouched(oracle):
+    """fhevc_set_weights validates and builds before it flips the dispatch: a blob that is rejected -- of the same kind or of another kind than the
+    one in use -- must leave the context predicting exactly as before (round-3 advice: a bad FHW3 after a layered member used to leave a fused-family
+    dispatch with null weight pointers)."""
+    W, H, QP = 200, 136, 30
+    luma = frames.hetero_luma(W, H, seed=77)
+    buf, org, stride = frames.to_pel_plane(luma, 8)
+    base = weights.random_weights(21)
+    lay = weights.random_family((23, 46, 92), 2, seed=5)
+    fus = weights.random_family((32, 64, 128), 1, seed=6)
+
+    def fresh(w):
+        c = capi.Context(W, H, 8, w)
+        d, _ = c.predict_frame(buf, org, stride, qp=QP)
+        c.close()
+        return d
+
+    want = {"base": fresh(base), "lay": fresh(lay), "fus": fresh(fus)}
+
+    def broken(w, family):
+        b = bytearray(weights.pack_family(w) if family else weights.pack(w))
+        off = 24 if family else 8          # the first requant shift of either layout
+        b[off:off + 4] = np.int32(15).tobytes()
+        return bytes(b)
+
+    bad = {"base": broken(base, False), "lay": broken(lay, True), "fus": broken(fus, True)}
+    good = {"base": base, "lay": lay, "fus": fus}
+    ctx = capi.Context(W, H, 8, base)
+    for cur in ("base", "lay", "fus", "lay", "base", "fus", "base"):
+        ctx.set_weights(good[cur])
+        d, _ = ctx.predict_frame(buf, org, stride, qp=QP)
+        assert np.array_equal(d, want[cur]), cur
+        for other in ("base", "lay", "fus"):
+            with pytest.raises(capi.FastHevcError):
+                ctx.set_weights(bad[other])
+            with pytest.raises(capi.FastHevcError):
+                ctx.set_weights(bad[other][:-3])
+            d, _ = ctx.predict_frame(buf, org, stride, qp=QP)
+            assert np.array_equal(d, want[cur]), (cur, other)
+    ctx.close()

@@ -8,7 +8,8 @@ import numpy as np
 import pytest
 
 from oracle import oracle_py as op
-from fasthevc_amd import bands, capi, frames, weights
+from fasthevc_amd import capi, frames, weights
+from fasthevc_amd import gather as bands
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -127,4 +128,115 @@ def test_bench_gop_64_frames_properties(oracle, cnn_arith):
     # panning permutes columns: the source Hadamard total over interior CTU rows changes, the map is not constant
     assert len({int(hh[f].sum()) for f in range(NF)}) > 1
     assert len(np.unique(dh)) == 4
+    ctx.close()
+
+
+FAMILY_BLOBS = ["depthnet_family_d1.fhw", "depthnet_family_d2.fhw", "depthnet_family_d3.fhw"]
+
+
+def _oracle_family_ctus(oracle, fam, plane, org, stride, W, H, bd, qp, ctus):
+    """the oracle's logits and depth map of the listed CTUs of one picture (per-CTU calls: a whole 1080p picture of a two-convolution member
+    would take the plain loops minutes)"""
+    import ctypes as C
+    f = op.family_from_arrays(fam)
+    cw = (W + 63) // 64
+    out = {}
+    for c in ctus:
+        cx, cy = c % cw, c // cw
+        ctu = np.zeros(64 * 64, np.int8)
+        oracle.fho_load_ctu(op.ptr(plane.reshape(-1), org), stride, W, H, cx, cy, bd, ctu)
+        logits = np.zeros(42, np.int32)
+        oracle.fho_cnn_ctu_family(C.byref(f), ctu.ctypes.data, qp, logits.ctypes.data)
+        depth = np.zeros(256, np.uint8)
+        oracle.fho_depth_from_logits(logits, min(64, W - cx * 64), min(64, H - cy * 64), depth)
+        out[c] = (logits, depth)
+    return out
+
+
+@pytest.mark.parametrize("blob", FAMILY_BLOBS)
+def test_family_blobs_on_the_bench_gop(oracle, blob):
+    """The three shipped members of the reference's network family at the size bench.py runs them: 64 panned 1080p pictures as HM-layout
+    planes in HBM (32 640 CTUs: four 8 192-CTU chunks on the layer path).  Sampled CTUs of sampled pictures -- corners, the 56-row bottom
+    edge, interior, both ends of every chunk -- against the oracle's logits and maps; batch == single picture; flag words carry the map."""
+    import torch
+    dev = torch.device("cuda:0")
+    W, H, NF, QP = 1920, 1080, 64, 32
+    fam = weights.load_any(os.path.join(ROOT, "fasthevc_amd", "weights", blob))
+    base = frames.hetero_luma(W, H)
+    planes = np.stack([frames.to_pel_plane(np.roll(base, 3 * f, axis=1), 8)[0] for f in range(NF)])
+    _, org, stride = frames.to_pel_plane(base, 8)
+    ctx = capi.Context(W, H, 8, fam, max_frames=NF)
+    n = ctx.num_ctus
+    d16 = torch.from_numpy(planes).to(dev)
+    fs = planes.shape[1] * planes.shape[2]
+    depth = torch.zeros((NF, n, 256), dtype=torch.uint8, device=dev)
+    logits = torch.zeros((NF, n, 42), dtype=torch.int32, device=dev)
+    flags = torch.zeros((NF, n), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ctx.predict_frames_device(d16.data_ptr() + 2 * org, 2, stride, fs, NF, depth.data_ptr(), None, logits.data_ptr(), qp=QP, d_flags=flags.data_ptr())
+    expanded = torch.zeros_like(depth)
+    ctx.expand_depth_flags_device(flags.data_ptr(), NF, expanded.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(expanded, depth)
+    dh, lh = depth.cpu().numpy(), logits.cpu().numpy()
+    # 8 192-CTU chunks of the layer path end inside pictures 16, 32, 48: sample around those seams as well
+    picks = {0: [0, 29, 255, 480, 509], 16: [30, 31, 32, 33, 300], 31: [7, 200, 495], 48: [90, 91, 92, 93], 63: [0, 264, 479, 508, 509]}
+    for f, ctus in picks.items():
+        ref = _oracle_family_ctus(oracle, fam, planes[f], org, stride, W, H, 8, QP, ctus)
+        for c, (lg, dp) in ref.items():
+            assert np.array_equal(lh[f, c], lg), (blob, f, c)
+            assert np.array_equal(dh[f, c], dp), (blob, f, c)
+    for f in (1, 40):   # batch == the single-picture host entry point
+        d1, _ = ctx.predict_frame(planes[f], org, stride, qp=QP)
+        assert np.array_equal(dh[f], d1), f
+    assert len(np.unique(dh)) == 4
+    ctx.close()
+
+
+@pytest.mark.parametrize("blob,max_frames", [("depthnet_family_d2.fhw", 1), ("depthnet_family_d3.fhw", 2), ("depthnet_family_d1.fhw", 2)])
+def test_host_batch_with_family_members(oracle, blob, max_frames):
+    """fhevc_predict_frames (pinned ring, two streams that alternate per chunk) with members whose activations live in ONE set of scratch tensors
+    per context: chunk k + 1 must not overwrite what chunk k's kernels still read.  Five pictures, chunks of max_frames, against the oracle."""
+    W, H, NF, QP = 416, 240, 5, 27
+    fam = weights.load_any(os.path.join(ROOT, "fasthevc_amd", "weights", blob))
+    lumas = [frames.hetero_luma(W, H, seed=300 + f) for f in range(NF)]
+    planes = np.stack([frames.to_pel_plane(y, 8)[0] for y in lumas])
+    _, org, stride = frames.to_pel_plane(lumas[0], 8)
+    ctx = capi.Context(W, H, 8, fam, max_frames=max_frames)
+    n = ctx.num_ctus
+    for rep in range(2):
+        depth, had = ctx.predict_frames(planes, qp=QP, origin=org, stride=stride, frame_stride=planes.shape[1] * planes.shape[2])
+        for f in range(NF):
+            ref = _oracle_family_ctus(oracle, fam, planes[f], org, stride, W, H, 8, QP, range(n))
+            for c in range(n):
+                assert np.array_equal(depth[f, c], ref[c][1]), (blob, rep, f, c)
+    ctx.close()
+
+
+def test_config3_4k_bands_through_the_layer_path(oracle):
+    """config 3's geometry (3840 x 2160, last CTU row 48 samples tall) with the two-convolutions-per-block member: the 8 CTU-row bands of an
+    8-rank node one after the other, flag words assembled, sampled CTUs against the oracle."""
+    import torch
+    dev = torch.device("cuda:0")
+    W, H, QP = 3840, 2160, 32
+    fam = weights.load_any(os.path.join(ROOT, "fasthevc_amd", "weights", "depthnet_family_d2.fhw"))
+    buf, org, stride = frames.to_pel_plane(frames.hetero_luma(W, H), 8)
+    ctx = capi.Context(W, H, 8, fam)
+    d16 = torch.from_numpy(buf).to(dev)
+    flags = torch.zeros(ctx.num_ctus, dtype=torch.int32, device=dev)
+    whole = torch.zeros((ctx.num_ctus, 256), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    for rank in range(8):
+        rb, re = bands.band(ctx.ctus_y, rank, 8)
+        ctx.predict_frames_device(d16.data_ptr() + 2 * org, 2, stride, 0, 1, whole[rb * ctx.ctus_x:].data_ptr(), None, None, rows=(rb, re), qp=QP,
+                                  d_flags=flags[rb * ctx.ctus_x:].data_ptr())
+    full = torch.zeros_like(whole)
+    ctx.expand_depth_flags_device(flags.data_ptr(), 1, full.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(full, whole)
+    dh = whole.cpu().numpy()
+    picks = [0, 59, 60 * 4 - 1, 60 * 4, 60 * 17 + 30, 60 * 29 + 59, 60 * 30, 60 * 33, 60 * 33 + 31, 60 * 34 - 1]   # band seams, corners, the 48-row bottom edge
+    ref = _oracle_family_ctus(oracle, fam, buf, org, stride, W, H, 8, QP, picks)
+    for c, (_, dp) in ref.items():
+        assert np.array_equal(dh[c], dp), c
     ctx.close()

@@ -7,7 +7,8 @@ import subprocess
 import numpy as np
 import pytest
 
-from fasthevc_amd import bands, capi, frames, weights
+from fasthevc_amd import capi, frames, weights
+from fasthevc_amd import gather as bands
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
