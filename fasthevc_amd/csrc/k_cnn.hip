@@ -79,11 +79,15 @@ constexpr int IN_PITCH = 68;                      // dwords per input row PAIR (
 #endif                         // 0.5199 at 0x0122, 0.5093 at 0x0123 (0x0133 0.5124, 0x0022 0.5216, 0x0112 0.5251); the i8 form measures equal across these
 // phase: 0 conv1, 1 conv2, 2 conv3, 3 heads
 #define FHEVC_PRIO_OF(phase) (((I8 ? FHEVC_I8_PRIO : FHEVC_F16_PRIO) >> (4 * (phase))) & 3)
-// (round-4 experiment, FHEVC_SLOT_PRIO = 1 / 2 / 3: the priority also depends on WHICH of the CU's workgroups the wave belongs to -- slot = blockIdx /
-// number of CUs under round-robin dispatch -- so that waves of different workgroups in the same phase do not tie: 1 = static slot priority, no phase
-// levels; 2 = conv phases at 1 + slot, the rest at 0; 3 = conv phases at 1 + slot, the rest at slot.  Measured: see HISTORY.md)
+// Round 4: the conv phases' level also depends on WHICH of the CU's three workgroups the wave belongs to (FHEVC_SLOT_PRIO = 2, the default of the i8
+// form: conv phases at 1 + slot = 1 / 2 / 3, everything else at 0).  With one level for all, two waves of a SIMD that are both in a conv phase tie and
+// the arbiter falls back to age; with the levels apart the matrix pipe goes to one of them outright and the other's chain runs in the gaps: same-box
+// A/B 0.3801 -> 0.3706 ms (-2.5 %, twice: profiles/r04_ab_slot_priority.log).  slot = the workgroup's LDS base / its LDS size (HW_REG_LDS_ALLOC): 0, 1, 2
+// whatever order the dispatcher fills the CUs in (tools/probes/probe_wg_slot.hip: under round-robin dispatch it equals blockIdx / 256).  Measured and
+// dropped: 1 = static slot level without phase levels (+4.6 %), 3 = conv phases at 1 + slot and the rest at slot (+2.8 %), 4 = tables: conv1 held at
+// 1 (-1.0 %) or at 0 (+1.9 %), heads at 1 for slots 1, 2 (-1.0 %), levels by phase only 1 / 2 / 3 (-1.6 %).
 #ifndef FHEVC_SLOT_PRIO
-#define FHEVC_SLOT_PRIO 0
+#define FHEVC_SLOT_PRIO 2
 #endif
 #define FHEVC_SETPRIO_DYN(p) { const int p_ = (p); if (p_ == 1) __builtin_amdgcn_s_setprio(1); else if (p_ == 2) __builtin_amdgcn_s_setprio(2); else if (p_ >= 3) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); }
 #if FHEVC_SLOT_PRIO == 0
@@ -93,7 +97,7 @@ constexpr int IN_PITCH = 68;                      // dwords per input row PAIR (
 #define FHEVC_PRIO_ON(phase)
 #define FHEVC_PRIO_OFF(phase)
 #elif FHEVC_SLOT_PRIO == 2
-#define FHEVC_PRIO_ON(phase)  if (FHEVC_PRIO_OF(phase)) FHEVC_SETPRIO_DYN(1 + prio_slot)
+#define FHEVC_PRIO_ON(phase)  if (FHEVC_PRIO_OF(phase)) { if (I8) FHEVC_SETPRIO_DYN(1 + prio_slot) else __builtin_amdgcn_s_setprio(FHEVC_PRIO_OF(phase)); }
 #define FHEVC_PRIO_OFF(phase) if (FHEVC_PRIO_OF(phase)) __builtin_amdgcn_s_setprio(0);
 #elif FHEVC_SLOT_PRIO == 3
 #define FHEVC_PRIO_ON(phase)  if (FHEVC_PRIO_OF(phase)) FHEVC_SETPRIO_DYN(1 + prio_slot)
@@ -924,7 +928,12 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   constexpr bool I8 = ARITH != 0, FASTRQ = ARITH == 2;
-  const int prio_slot = (FHEVC_SLOT_PRIO && I8 && gridDim.x % 3 == 0) ? (int)(blockIdx.x / (gridDim.x / 3)) : 0;   // (experiment: see FHEVC_SLOT_PRIO)
+  int prio_slot = 0;   // which of the CU's workgroups this is, from where its LDS allocation starts (see FHEVC_SLOT_PRIO)
+  if (FHEVC_SLOT_PRIO && I8) {
+    const unsigned la = __builtin_amdgcn_s_getreg((31 << 11) | 6);   // HW_REG_LDS_ALLOC: base [11:0], size [20:12], both in 256-byte granules
+    const unsigned base = la & 0xFFFu, sz = (la >> 12) & 0x1FFu;
+    prio_slot = base >= 2 * sz && sz ? 2 : (base >= sz && sz ? 1 : 0);
+  }
   (void)prio_slot;
   if (FHEVC_SLOT_PRIO == 1 || FHEVC_SLOT_PRIO == 3) FHEVC_SETPRIO_DYN(prio_slot)
   constexpr bool MFMA_HEADS = FHEVC_MFMA_HEADS_F16 || I8;  // the two smaller FC heads as an i8 MFMA GEMM (P4)
