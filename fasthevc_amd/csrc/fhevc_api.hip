@@ -32,7 +32,8 @@ struct fhevc_ctx {
   uint4* d_frag_i8 = nullptr; int32_t* d_bias_i8 = nullptr;  // the i8 variant of conv2 / conv3 (k_cnn.hip)
   // a member of the reference's Bayesian-optimisation network family (FHW3 blob; k_cnn_family.inc): set instead of the arrays above
   bool family = false;
-  bool fam_layers = false;            // ... run layer by layer through HBM (k_cnn_layers.inc): every member the two fused kernels do not cover
+  bool fam_layers = false;            // ... run layer by layer through HBM (k_cnn_layers.inc): every member the fused kernels do not cover
+  bool fam_d2 = false;                // ... of those, the members k_cnn_d2.inc runs as one LDS-resident kernel (the layer images are the same; no HBM scratch)
   FhevcLayersWeights lw = {};
   std::vector<void*> lw_bufs;         // everything lw points to (freed with the context / the next blob)
   // the layer path's activation tensors are ONE set per context: a launch on another stream than the previous one waits for that one's last kernel
@@ -355,7 +356,11 @@ int build_layers_image(fhevc_ctx* c, const uint8_t* blob, size_t bytes, int C1, 
   lw.chunk = std::min(c->num_ctus * std::max(1, c->cfg.max_frames), 8192);
   if (lw.chunk < 64) lw.chunk = 64;
   auto dev = [&](size_t n, int fill) -> void* { void* q = nullptr; if (hipMalloc(&q, n) != hipSuccess) return nullptr; c->lw_bufs.push_back(q); (void)hipMemset(q, fill, n); return q; };
-  if (!(lw.in0 = static_cast<int8_t*>(dev((size_t)lw.chunk * 66 * 66, 0)))) return fail(c, FHEVC_E_HIP, "layer buffers");
+  // two convolutions per block at padded widths 32 / 64 / 96 (the reference's 23 / 46 / 92 x 2): k_cnn_d2.inc keeps a CTU's activations in LDS -- the same weight
+  // images, no activation tensors in HBM (FHEVC_FUSED_D2=0 / FHEVC_FAMILY_LAYERS keep the layer-by-layer path: tests, A/B)
+  auto pad32 = [](int v) { return 32 * ((v + 31) / 32); };
+  const bool d2 = depth == 2 && pad32(C1) == 32 && pad32(C2) == 64 && pad32(C3) == 96 && c->knobs.fused_d2 && !c->knobs.family_layers;
+  if (!d2 && !(lw.in0 = static_cast<int8_t*>(dev((size_t)lw.chunk * 66 * 66, 0)))) return fail(c, FHEVC_E_HIP, "layer buffers");
   int H = 64, cin = 1, li = 0;
   for (int b = 0; b < 3; ++b)
     for (int j = 0; j < depth; ++j, ++li) {
@@ -397,8 +402,8 @@ int build_layers_image(fhevc_ctx* c, const uint8_t* blob, size_t bytes, int C1, 
       if (!first) fhevc_layer_lds_image(kc, pool, H, &in_pad, &swz);
       if (ni < 3 * depth) fhevc_layer_lds_image(cout_pad / 32, (nj == depth - 1) && nb < 2, Ho, &out_pad, &unused);
       L.in_pad = in_pad; L.out_pad = out_pad; L.swz = swz;
-      L.out = static_cast<int8_t*>(dev((size_t)lw.chunk * (Ho + 2) * ((size_t)(Ho + 2) * cout_pad + out_pad), 0x80));   // halo = "activation 0", written here once
-      if (!dfrag || !dbias || !L.out) return fail(c, FHEVC_E_HIP, "layer buffers");
+      L.out = d2 ? nullptr : static_cast<int8_t*>(dev((size_t)lw.chunk * (Ho + 2) * ((size_t)(Ho + 2) * cout_pad + out_pad), 0x80));   // halo = "activation 0", written here once
+      if (!dfrag || !dbias || (!d2 && !L.out)) return fail(c, FHEVC_E_HIP, "layer buffers");
       HIP_TRY(c, hipMemcpy(dfrag, frag.data(), frag.size(), hipMemcpyHostToDevice));
       HIP_TRY(c, hipMemcpy(dbias, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
       L.frag = static_cast<const uint4*>(dfrag); L.bias = static_cast<const int32_t*>(dbias);
@@ -433,9 +438,10 @@ int build_layers_image(fhevc_ctx* c, const uint8_t* blob, size_t bytes, int C1, 
   HIP_TRY(c, hipMemcpy(dwh, whead.data(), whead.size(), hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemcpy(dbh, bhead, sizeof bhead, hipMemcpyHostToDevice));
   lw.whead = static_cast<const uint8_t*>(dwh); lw.bhead = static_cast<const int32_t*>(dbh);
+  if (d2 && !fhevc_cnn_d2_supported(lw)) return fail(c, FHEVC_E_STATE, "layer images do not match the fused two-convolution kernel");
   c->lw = lw;
   c->fam_c[0] = C1; c->fam_c[1] = C2; c->fam_c[2] = C3;
-  c->family = true; c->fam_layers = true; c->have_weights = true;
+  c->family = true; c->fam_layers = true; c->fam_d2 = d2; c->have_weights = true;
   return FHEVC_OK;
 }
 
@@ -846,7 +852,10 @@ int fhevc_predict_frames_device_range(fhevc_ctx* c, const void* d_luma, int samp
     c->stats.kernels_launched++;
   }
   time_begin(c, s, 0);
-  if (c->family && c->fam_layers) {
+  if (c->family && c->fam_layers && c->fam_d2) {
+    HIP_TRY(c, fhevc_launch_cnn_d2(fr, c->lw, d_depth_map, d_logits, d_flags, d_depth_max, margin_split, margin_stop, c->num_cus, s));
+  }
+  else if (c->family && c->fam_layers) {
     if (!c->lw_done) HIP_TRY(c, hipEventCreateWithFlags(&c->lw_done, hipEventDisableTiming));
     if (c->lw_in_flight && c->lw_last_stream != s) HIP_TRY(c, hipStreamWaitEvent(s, c->lw_done, 0));   // the scratch tensors are still being read there
     const hipError_t le = fhevc_launch_cnn_layers(fr, c->lw, d_depth_map, d_logits, d_flags, d_depth_max, margin_split, margin_stop, c->num_cus, c->knobs, s);

@@ -111,6 +111,11 @@ struct FhevcLayersWeights {
 hipError_t fhevc_launch_cnn_layers(const FhevcFrames& fr, const FhevcLayersWeights& w, uint8_t* d_depth, int32_t* d_logits, uint32_t* d_flags,
                                    uint8_t* d_depth_max, int margin_split, int margin_stop, int num_cus, const FhevcKnobs& knobs, hipStream_t stream);
 
+// the same members with two convolutions per block and padded widths 32 / 64 / 96 (23 / 46 / 92 x 2) as one LDS-resident kernel (k_cnn_d2.inc)
+bool fhevc_cnn_d2_supported(const FhevcLayersWeights& w);
+hipError_t fhevc_launch_cnn_d2(const FhevcFrames& fr, const FhevcLayersWeights& w, uint8_t* d_depth, int32_t* d_logits, uint32_t* d_flags,
+                               uint8_t* d_depth_max, int margin_split, int margin_stop, int num_cus, hipStream_t stream);
+
 hipError_t fhevc_cnn_prepare_device();  // LDS opt-in of the depth kernel on the current device (once per context)
 // d_depth_max / margins: soft decisions (nullptr / 0, 0 = the plain map only)
 // d_had != nullptr: the per-CTU source Hadamard is computed inside the depth kernel from the samples it loads anyway (one

@@ -1975,6 +1975,7 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_pipe_kernel(FhevcFrame
 
 #include "k_cnn_family.inc"
 #include "k_cnn_layers.inc"
+#include "k_cnn_d2.inc"
 
 // split-flag words -> depth maps (whole pictures, CTU raster order): one thread per row of 16 units = one 16-byte store,
 // 16 threads per CTU, 16 CTUs per workgroup and sweep (HBM-write-bound: 256 B per CTU)
@@ -2038,6 +2039,7 @@ hipError_t fhevc_cnn_prepare_device()
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_layer_conv_kernel<KCV, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
   FHEVC_LAYER_FUSE(1) FHEVC_LAYER_FUSE(2)
 #undef FHEVC_LAYER_FUSE
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_d2_kernel<1, 2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, LdsD2<1, 2, 3>::LDS_BYTES);
   return e;
 }
 
@@ -2157,6 +2159,28 @@ hipError_t fhevc_launch_cnn_family(const FhevcFrames& fr, const FhevcFamilyWeigh
   else if (w.c[0] == 16 && w.c[1] == 32 && w.c[2] == 64)
     hipLaunchKernelGGL((fhevc_cnn_family_kernel<16, 32, 64>), dim3(grid), dim3(256), (LdsFam<16, 32, 64>::LDS_BYTES), stream, fr, w, d_depth, d_logits, d_flags, d_depth_max, margin_split, margin_stop);
   else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+// ---- the members with two convolutions per block as ONE kernel (k_cnn_d2.inc): padded widths 32 / 64 / 96 = the reference's 23 / 46 / 92 x 2 ----
+bool fhevc_cnn_d2_supported(const FhevcLayersWeights& w)
+{
+  static const int cp[6] = { 32, 32, 64, 64, 96, 96 }, pool[6] = { 0, 1, 0, 1, 0, 0 }, hh[6] = { 64, 64, 32, 32, 16, 16 };
+  if (w.num_layers != 6 || w.c3_pad != 96) return false;
+  for (int i = 0; i < 6; ++i)
+    if (w.l[i].cout_pad != cp[i] || (w.l[i].pool != 0) != (pool[i] != 0) || w.l[i].H != hh[i] || w.l[i].kc != (i == 0 ? 0 : cp[i - 1] / 32)) return false;
+  return true;
+}
+
+hipError_t fhevc_launch_cnn_d2(const FhevcFrames& fr, const FhevcLayersWeights& w, uint8_t* d_depth, int32_t* d_logits, uint32_t* d_flags,
+                               uint8_t* d_depth_max, int margin_split, int margin_stop, int num_cus, hipStream_t stream)
+{
+  const long long total = (long long)(fr.row_end - fr.row_begin) * fr.ctus_x * fr.num_frames;
+  if (total <= 0) return hipSuccess;
+  if (!fhevc_cnn_d2_supported(w)) return hipErrorInvalidValue;
+  int grid = num_cus;   // one 512-thread workgroup per CU (119 KB of LDS)
+  if (total < grid) grid = (int)total;
+  hipLaunchKernelGGL((fhevc_cnn_d2_kernel<1, 2, 3>), dim3(grid), dim3(512), (LdsD2<1, 2, 3>::LDS_BYTES), stream, fr, w, d_depth, d_logits, d_flags, d_depth_max, margin_split, margin_stop);
   return hipGetLastError();
 }
 

@@ -222,3 +222,45 @@ def test_a_rejected_blob_leaves_the_weights_in_use_untouched(oracle):
             d, _ = ctx.predict_frame(buf, org, stride, qp=QP)
             assert np.array_equal(d, want[cur]), (cur, other)
     ctx.close()
+
+
+@pytest.mark.parametrize("widths,W,H,bd,seed", [((23, 46, 92), 416, 240, 8, 0), ((23, 46, 92), 200, 136, 10, 1), ((20, 44, 88), 256, 192, 12, 2), ((32, 64, 96), 320, 256, 8, 3),
+                                                ((1, 33, 68), 200, 136, 8, 4), ((23, 46, 92), 832, 480, 8, 5)])
+def test_two_convolutions_per_block_as_one_kernel(oracle, widths, W, H, bd, seed):
+    """The NetworkDepth-2 members at padded widths 32 / 64 / 96 -- the reference's 23 / 46 / 92 x 2 and its neighbours -- through the library's default
+    dispatch = k_cnn_d2.inc (a CTU's activations never leave LDS): depth maps, logits, soft ranges and flag words against the oracle's plain loops; ragged
+    pictures (the 32-wide last column, 48- and 8-row bottom edges), 8 / 10 / 12 bit; the same context's layer-by-layer twin must agree as well."""
+    import torch
+    fam = weights.random_family(widths, 2, seed=seed)
+    if seed % 2:
+        fam["shift"] = np.random.default_rng(seed).integers(4, 11, size=(3, 3)).astype(np.int32)
+    qp = 22 + 5 * (seed % 4)
+    lumas = [frames.hetero_luma(W, H, seed=180 + seed), frames.texture16_luma(W, H, seed=190 + seed), frames.fractal_luma(W + 8, H + 8, seed=seed)[:H, :W].copy()]
+    refs = [_oracle_family(oracle, fam, y, bd, qp) for y in lumas]
+    ctx = capi.Context(W, H, bd, fam, max_frames=3)
+    st = ctx.stats()
+    for y, (buf, org, stride, depth_ref, logits_ref, had_ref) in zip(lumas, refs):
+        d, had = ctx.predict_frame(buf, org, stride, qp=qp)
+        bad = np.nonzero((d != depth_ref).any(axis=1))[0]
+        assert bad.size == 0, f"CTUs with a differing depth map: {bad[:10]}"
+        assert np.array_equal(had, had_ref)
+    # one launch per picture (+ the stand-alone source Hadamard): the layer path would need nine
+    assert ctx.stats()["kernels_launched"] - st["kernels_launched"] == 2 * len(lumas)
+    dev = torch.device("cuda:0")
+    planes = np.stack([r[0] for r in refs])
+    d16 = torch.from_numpy(planes).to(dev)
+    org, stride, n = refs[0][1], refs[0][2], ctx.num_ctus
+    depth = torch.zeros((3, n, 256), dtype=torch.uint8, device=dev)
+    dmax = torch.zeros((3, n, 256), dtype=torch.uint8, device=dev)
+    logits = torch.zeros((3, n, 42), dtype=torch.int32, device=dev)
+    flags = torch.zeros((3, n), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ctx.predict_frames_device(d16.data_ptr() + 2 * org, 2, stride, planes.shape[1] * planes.shape[2], 3, depth.data_ptr(), None, logits.data_ptr(), qp=qp, d_flags=flags.data_ptr())
+    expanded = torch.zeros_like(depth)
+    ctx.expand_depth_flags_device(flags.data_ptr(), 3, expanded.data_ptr())
+    torch.cuda.synchronize()
+    for f in range(3):
+        assert np.array_equal(logits[f].cpu().numpy(), refs[f][4]), f
+        assert np.array_equal(depth[f].cpu().numpy(), refs[f][3]), f
+        assert np.array_equal(expanded[f].cpu().numpy(), refs[f][3]), f
+    ctx.close()

@@ -21,8 +21,9 @@ else:
     widths = tuple(int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "23,46,92").split(","))
     depth = int(sys.argv[2]) if len(sys.argv) > 2 else 2
     fam = weights.random_family(widths, depth, seed=0)
-W, H, NF = 1920, 1080, 16
-os.environ["FHEVC_FAMILY_LAYERS"] = "1"
+W, H, NF = 1920, 1080, int(os.environ.get("FHEVC_LAYERS_BENCH_FRAMES", "16"))
+if os.environ.get("FHEVC_LAYERS_BENCH_FUSED", "0") == "0":   # 1: the library's default dispatch (k_cnn_d2.inc for the x 2 members at 32 / 64 / 96)
+    os.environ["FHEVC_FAMILY_LAYERS"] = "1"
 base = frames.hetero_luma(W, H)
 d8 = torch.from_numpy(np.stack([np.roll(base, 3 * f, axis=1) for f in range(NF)])).cuda()
 ctx = capi.Context(W, H, 8, fam, max_frames=NF)
