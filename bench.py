@@ -509,8 +509,8 @@ def main():
         FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) -- only for the workload they were taken on."""
         if not (NF == 64 and args.sample_bytes == 2 and (W, H) == (1920, 1080) and mode == "frames"):
             return None, None
-        for rnd in ("r03", "r02", "r01"):
-            path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_bench_frames64_int16.json")
+        for rnd, stem in [(r, st) for r in ("r04", "r03", "r02", "r01") for st in ("pmc_bench_frames64_int16", "pmc_kernels")]:   # newest round first
+            path = os.path.join(ROOT, "profiles", f"{rnd}_{stem}.json")
             if os.path.exists(path):
                 d = json.load(open(path))
                 for k, v in d.items():
@@ -520,7 +520,7 @@ def main():
                         if (arith == "i8") != (len(targs) == 3 and targs[2].strip() in ("1", "2")):
                             continue
                     if k.startswith(kernel) and isinstance(v, dict) and "hbm_read_bytes_corrected" in v and "hbm_write_bytes" in v:
-                        return v["hbm_read_bytes_corrected"] + v["hbm_write_bytes"], f"profiles/{rnd}_pmc_bench_frames64_int16.json (commit {d.get('commit', 'of that round')})"
+                        return v["hbm_read_bytes_corrected"] + v["hbm_write_bytes"], f"profiles/{rnd}_{stem}.json (commit {d.get('commit', 'of that round')})"
         return None, None
 
     def measured_mfma_busy():
@@ -528,7 +528,7 @@ def main():
         pipes were busy, at the 2.4 GHz the peak is quoted at and at the clock the chip held (GRBM_GUI_ACTIVE / 8 / time, where the pass has it)"""
         if not (NF == 64 and args.sample_bytes == 2 and (W, H) == (1920, 1080) and mode == "frames"):
             return None
-        for rnd in ("r03", "r02"):
+        for rnd in ("r04", "r03", "r02"):
             path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_bench_frames64_int16.json")
             if not os.path.exists(path):
                 continue
@@ -578,10 +578,11 @@ def main():
                        "roofline": {"bound": "mfma", "kernel": "fhevc_cnn_family_kernel<32, 64, 128>", "achieved": fach, "peak": PEAK_I8_TOPS, "unit": "TOP/s (2 per MAC)",
                                     "frac": fach / PEAK_I8_TOPS if fach else None, "avg_launch_ms": f_ms, "launches": f_n}}
 
-        # the deeper members (no fused kernel: layer by layer through HBM, k_cnn_layers.inc), random weights, the first 16 pictures of the GOP
+        # the deeper members: 23 / 46 / 92 x 2 through ONE LDS-resident kernel (k_cnn_d2.inc, round 4) on the whole GOP; 18 / 36 / 72 x 3 layer by layer through
+        # HBM (k_cnn_layers.inc) on the first 16 pictures
         deeper = {}
-        nfd = min(nf_local, 16)
         for widths, depth in (((23, 46, 92), 2), ((18, 36, 72), 3)):
+          nfd = nf_local if depth == 2 else min(nf_local, 16)
           try:   # (a secondary line: a failure here is reported in place, it never takes the headline down)
             dblob = os.path.join(ROOT, "fasthevc_amd", "weights", f"depthnet_family_d{depth}.fhw")
             dw = weights.load_any(dblob) if os.path.exists(dblob) else None
@@ -608,14 +609,18 @@ def main():
                     n //= 2
             mac += (64 * 4 + 4 * 64 + 16 * 16) * widths[2] * 2
             ach = 2 * mac * nfd * n_ctus / (d_ms * 1e-3) / 1e12
+            kernels = "fhevc_cnn_d2_kernel<1, 2, 3> (one launch, activations in LDS)" if depth == 2 else \
+                f"{3 * depth - 1} x fhevc_layer_conv_kernel (the first convolution inside the second) + stage + heads"
+            d_traffic, d_src = measured_traffic("fhevc_cnn_d2_kernel") if depth == 2 else (None, None)
             deeper[f"{widths[0]}/{widths[1]}/{widths[2]} x {depth}"] = {
                 "weights": "trained (" + os.path.basename(dblob) + ")" if trained else "random-init",
-                "value": nfd * n_ctus / (d_ms * 1e-3), "unit": "CTU/s", "ms_per_16_pictures": d_ms, "op_per_ctu": 2 * mac,
-                "roofline": {"bound": "mfma", "kernels": f"{3 * depth - 1} x fhevc_layer_conv_kernel (the first convolution inside the second) + stage + heads", "achieved": ach, "peak": PEAK_I8_TOPS,
-                             "unit": "TOP/s (2 per MAC, unpadded)", "frac": ach / PEAK_I8_TOPS}}
+                "value": nfd * n_ctus / (d_ms * 1e-3), "unit": "CTU/s", "pictures": nfd, "ms_per_launch": d_ms, "op_per_ctu": 2 * mac,
+                "roofline": {"bound": "mfma", "kernels": kernels, "achieved": ach, "peak": PEAK_I8_TOPS,
+                             "unit": "TOP/s (2 per MAC, unpadded)", "frac": ach / PEAK_I8_TOPS,
+                             "algorithmic_bytes": nfd * (W * H * args.sample_bytes + n_ctus * 256), "traffic": d_traffic, "traffic_source": d_src}}
           except Exception as exc:   # noqa: BLE001
             deeper[f"{widths[0]}/{widths[1]}/{widths[2]} x {depth}"] = {"error": repr(exc)}
-        family_line["deeper_members_layer_by_layer"] = deeper
+        family_line["deeper_members"] = deeper
 
     if rank == 0:
         ctus_per_step = total_frames * n_ctus
