@@ -22,7 +22,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# algorithmic work per CTU: MACs of the three conv layers + the three FC heads
+# algorithmic work per CTU (HISTORY.md section 6): MACs of the three conv layers + the three FC heads
 MAC_PER_CTU = 4096 * 9 * 16 + 1024 * 144 * 32 + 256 * 288 * 64 + (4096 + 4 * 4096 + 16 * 1024) * 2
 FLOP_PER_CTU = 2 * MAC_PER_CTU
 PEAK_BF16_TFLOPS = 2500.0   # dense 16-bit (bf16 = f16) MFMA, MI355X_MICROARCH.md

@@ -6,7 +6,7 @@
 //   run convolutionally over the CTU, with three FC heads (64-, 32- and 16-level split decisions) and the
 //   top-down assembly of the 16x16 depth map that TEncCu::xCompressCU consumes (TEncCu.cpp:496-1058).
 //
-// How (DESIGN.md sections 5.1 - 5.1c, 5.6).  One template, fhevc_cnn_depth_kernel<STAMPS, HAD, ARITH>, in two arithmetic forms that
+// How (HISTORY.md sections 5.1 - 5.1c, 5.6).  One template, fhevc_cnn_depth_kernel<STAMPS, HAD, ARITH>, in two arithmetic forms that
 // deliver the same integers (every GPU parity test runs both):
 //   ARITH = 0, the 16-bit form (round 1): conv1 v_mfma_f32_32x32x16_bf16, conv2 v_mfma_f32_32x32x16_f16, conv3 v_mfma_f32_16x16x32_f16;
 //     activations between the convs as f16 in 8-channel LDS planes; weights carry 2^-shift, biases are the C operand, fp32 rounding toward

@@ -196,6 +196,66 @@ def deadleaves_luma(width, height, seed=777, leaves=900):
     return np.clip(np.rint(_box_blur(y, 3)), 0, 255).astype(np.uint8)
 
 
+def glyphs_luma(width, height, seed=777):
+    """HELD-OUT evaluation family (round 4; never part of any training label): screen-like content -- flat panels, rows of small glyph-like marks
+    (strokes of 1-3 samples in cells of 6-14), thin rules and boxes, one smooth gradient panel, hardly any noise."""
+    rng = np.random.default_rng(seed)
+    y = np.full((height, width), float(rng.uniform(180, 240)))
+    for _ in range(int(rng.integers(3, 7))):                      # panels
+        w, h = int(rng.integers(width // 6, width // 2)), int(rng.integers(height // 6, height // 2))
+        x0, y0 = int(rng.integers(0, width - w)), int(rng.integers(0, height - h))
+        bg = float(rng.uniform(20, 245))
+        y[y0:y0 + h, x0:x0 + w] = bg
+        if rng.random() < 0.3:                                    # a gradient panel
+            y[y0:y0 + h, x0:x0 + w] += np.linspace(-30, 30, w)[None, :]
+            continue
+        fg = bg - 120.0 if bg > 128 else bg + 120.0
+        cell = int(rng.integers(6, 15))
+        for ry in range(y0 + 4, y0 + h - cell, cell + int(rng.integers(2, 6))):
+            x = x0 + 4
+            while x < x0 + w - cell:
+                if rng.random() < 0.85:                           # a glyph: two or three strokes inside its cell
+                    for _ in range(int(rng.integers(2, 4))):
+                        t = int(rng.integers(1, 3))
+                        if rng.random() < 0.5:
+                            yy0 = ry + int(rng.integers(0, cell - t))
+                            y[yy0:yy0 + t, x:x + int(rng.integers(cell // 2, cell))] = fg
+                        else:
+                            xx0 = x + int(rng.integers(0, cell - t))
+                            y[ry:ry + int(rng.integers(cell // 2, cell)), xx0:xx0 + t] = fg
+                x += cell + int(rng.integers(1, 4)) if rng.random() < 0.85 else 3 * cell   # word gaps
+    for _ in range(int(rng.integers(4, 12))):                     # rules and boxes
+        x0, y0 = int(rng.integers(0, width - 64)), int(rng.integers(0, height - 64))
+        w, h, v = int(rng.integers(16, 300)), int(rng.integers(16, 200)), float(rng.uniform(0, 120))
+        y[y0:y0 + 1, x0:x0 + w] = v
+        if rng.random() < 0.5:
+            y[y0:y0 + h, x0:x0 + 1] = v
+            y[min(height - 1, y0 + h):min(height, y0 + h + 1), x0:x0 + w] = v
+            y[y0:y0 + h, min(width - 1, x0 + w):min(width, x0 + w + 1)] = v
+    y += rng.normal(0, float(rng.uniform(0.0, 0.8)), size=y.shape)
+    return np.clip(np.rint(y), 0, 255).astype(np.uint8)
+
+
+def waves_luma(width, height, seed=777):
+    """HELD-OUT evaluation family (round 4; never part of any training label): a few superposed plane waves whose amplitude and wavelength drift across the
+    picture, soft-edged blobs of other mean level, and grain in patches -- smooth, anisotropic content without hard edges."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:height, 0:width].astype(np.float64)
+    y = np.full((height, width), float(rng.uniform(90, 160)))
+    for _ in range(int(rng.integers(2, 6))):
+        th, lam = rng.uniform(0, np.pi), rng.uniform(6, 120)
+        drift = 1.0 + rng.uniform(-0.5, 0.5) * (xx / width) + rng.uniform(-0.5, 0.5) * (yy / height)
+        amp = rng.uniform(4, 45) * (0.3 + 0.7 * np.abs(np.sin(xx / rng.uniform(150, 600) + rng.uniform(0, 6)) * np.cos(yy / rng.uniform(150, 600))))
+        y += amp * np.sin(2 * np.pi * (np.cos(th) * xx + np.sin(th) * yy) / (lam * drift) + rng.uniform(0, 6))
+    for _ in range(int(rng.integers(3, 14))):
+        cx, cy, r = rng.uniform(0, width), rng.uniform(0, height), rng.uniform(15, 140)
+        y += rng.uniform(-60, 60) / (1.0 + np.exp((np.sqrt((xx - cx) ** 2 + (yy - cy) ** 2) - r) / rng.uniform(1.5, 12)))
+    grain = rng.normal(0, 1.0, size=y.shape)
+    patch = _box_blur((rng.random((height, width)) < 0.0006).astype(np.float64), 65) * 65 * 65
+    y += grain * np.minimum(patch, 1.0) * rng.uniform(3, 14) + grain * rng.uniform(0.3, 1.5)
+    return np.clip(np.rint(y), 0, 255).astype(np.uint8)
+
+
 def pan_clip(width, height, nframes=4, seed=1234, v_structure=3, v_noise=3):
     """SURVEY Appendix B's config-4 clip (texture16 content): texture mask and noise drawn once; base and edges move
     v_structure px per frame one way, the noise v_noise px per frame the other way (two overlaid motions), flat chroma.

@@ -2,7 +2,7 @@
 """Trainer for the integer-valued depth classifier -- replaces the reference's MATLAB
 scripts (matlab/dataExtraction/Train...Example.m:75-96, 195-205; labels detectAndClassify32Cu.m:11-62).
 
-The network is trained directly in the fixed-point domain the HIP kernel runs in: latent float
+The network is trained directly in the fixed-point domain the HIP kernel runs in (HISTORY.md section 4): latent float
 weights are rounded to int8 in the forward pass (straight-through gradients), activations are
 clamp(floor((acc + b) >> s), 0, 255).  What the trainer evaluates is therefore bit-for-bit what
 fasthevc_amd/csrc/k_cnn.hip and oracle/fhevc_oracle.c compute from the exported FHW1 blob.

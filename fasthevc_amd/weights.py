@@ -1,5 +1,5 @@
 """Depth-classifier weight blob ("FHW1"): fixed-point integer weights of the three conv layers and the three
-FC heads.  The same bytes feed the HIP library (fhevc_cfg.weights_path) and, in tests,
+FC heads (HISTORY.md section 4).  The same bytes feed the HIP library (fhevc_cfg.weights_path) and, in tests,
 the CPU oracle.
 
 Layout after the 8-byte header (magic "FHW1", uint32 version = 2), all little-endian, no padding:

@@ -30,7 +30,7 @@ void TEncFastDepth::readKnobs()
   const char* mg = std::getenv("FHEVC_MARGIN");
   const char* ms = std::getenv("FHEVC_MARGIN_SPLIT");
   const char* mt = std::getenv("FHEVC_MARGIN_STOP");
-  // defaults: the calibration that keeps EVERY content family within 1 % BD-rate with the shipped blob depthnet_v2.fhw (DESIGN.md section 4,
+  // defaults: the calibration that keeps EVERY content family within 1 % BD-rate with the shipped blob depthnet_v2.fhw (HISTORY.md section 4,
   // profiles/r03_bdrate_generalization.json): splits are forced only above +100000, forbidden only below -64000, HM's own search decides in
   // between (the round-2 blob depthnet_v1.fhw: 100000 / 48000).  On content like the classifier's training set FHEVC_MARGIN_SPLIT=48000
   // FHEVC_MARGIN_STOP=16000 keeps the loss at or below 0.2 % at 1.5-3.7x less decision time.
@@ -56,7 +56,7 @@ void TEncFastDepth::readKnobs()
   if (m_pRange < 1) m_pRange = 1;
   if (m_pRange > 64) m_pRange = 64;   // above 8: HM's own integer search (SAD, xPatternSearch) over the window, 8-bit content (fasthevc.h)
   // FHEVC_P_MC=1: the reference picture's depths are taken where the motion search says the content came from
-  // (fhevc_p_motion_compensated_depth) instead of co-located.  Off by default: measured, a displaced map is no longer
+  // (fhevc_p_motion_compensated_depth) instead of co-located.  Off by default: measured (HISTORY.md section 4b), a displaced map is no longer
   // aligned to the CU grid and decides worse than the co-located one even under a global pan of 32 samples per picture
   const char* pc = std::getenv("FHEVC_P_MC");
   m_pMotionCompensated = pc != NULL && std::atoi(pc) != 0;

@@ -138,7 +138,7 @@ void fho_p_depth_range(const fho_motion_node nodes[85], const uint8_t prev_depth
 /* Architecture follows matlab/dataExtraction/Train...Example.m:75-96 run convolutionally on the
  * 64x64 CTU: conv3x3x16 pad1 -> ReLU -> maxpool2 -> conv3x3x32 pad1 -> ReLU -> maxpool2 ->
  * conv3x3x64 pad1 -> ReLU -> FC(2) heads.  BN is folded; values are fixed-point integers so that
- * fp32 accumulation of bf16 operands on the GPU is exact.  See DESIGN.md section 4. */
+ * fp32 accumulation of bf16 operands on the GPU is exact.  See HISTORY.md section 4. */
 typedef struct {
   int32_t shift[3];
   int8_t  w1[16 * 9];          /* [oc][ky][kx]            */
@@ -190,7 +190,7 @@ void fho_depth_from_logits(const int32_t logits[21][2], int valid_w, int valid_h
  * -margin_stop -> depth_max */
 void fho_depth_range_from_logits(const int32_t logits[21][2], int valid_w, int valid_h, int margin_split, int margin_stop,
                                  uint8_t depth_min[256], uint8_t depth_max[256]);
-/* one margin pair per split level (64, 32, 16): the calibration of DESIGN.md section 4 */
+/* one margin pair per split level (64, 32, 16): the calibration of HISTORY.md section 4 */
 void fho_depth_range_from_logits_levels(const int32_t logits[21][2], int valid_w, int valid_h, const int32_t margin_split[3],
                                         const int32_t margin_stop[3], uint8_t depth_min[256], uint8_t depth_max[256]);
 /* The same decisions as one 21-bit word per CTU: bit 0 = 64x64 split, bits 1..4 = 32x32 quadrants (raster),

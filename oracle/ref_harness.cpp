@@ -4,7 +4,7 @@
 // objects compiled from the reference's own sources where they lie under /root/reference
 // (TLibCommon/*.cpp, TLibEncoder/*.cpp except TEncGOP.cpp, libmd5).  No reference source is copied,
 // patched or stubbed: TEncGOP.cpp / TAppEncoder need OpenCV, which this image lacks, so the full
-// encoder is unbuildable here and is not built.
+// encoder is unbuildable here and is not built (see HISTORY.md section 3).
 //
 // This file only CALLS reference code; it contains none of it.  It is used by oracle/gen_golden.py
 // to produce tests/golden/ref_*.npz and by tests/test_reference_rdo.py when oracle/_ref exists.

@@ -27,7 +27,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from fasthevc_amd import frames, weights  # noqa: E402
 
 QPS = (22, 27, 32, 37)
-FAMILIES = ("hetero", "texture16", "fractal", "gratings", "polygon", "chirp", "deadleaves", "ood")
+FAMILIES = ("hetero", "texture16", "fractal", "gratings", "polygon", "chirp", "deadleaves", "ood", "glyphs", "waves")   # the last three: never in any training label
 
 
 def picture(family, k, W, H):
@@ -35,7 +35,8 @@ def picture(family, k, W, H):
     import eval_rd
     seed = 900_000 + 1000 * FAMILIES.index(family) + k
     gen = {"hetero": frames.hetero_luma, "texture16": frames.texture16_luma, "fractal": frames.fractal_luma, "gratings": frames.gratings_luma,
-           "polygon": frames.polygon_luma, "chirp": frames.chirp_luma, "deadleaves": frames.deadleaves_luma, "ood": eval_rd.ood_luma}[family]
+           "polygon": frames.polygon_luma, "chirp": frames.chirp_luma, "deadleaves": frames.deadleaves_luma, "ood": eval_rd.ood_luma,
+           "glyphs": frames.glyphs_luma, "waves": frames.waves_luma}[family]
     return gen(W, H, seed=seed)
 
 

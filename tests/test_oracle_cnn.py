@@ -65,7 +65,7 @@ def test_oracle_cnn_matches_torch_float64(oracle):
 
 
 def test_exactness_bound_for_fp32_accumulation():
-    # |bias| <= 2^22 and K*255*127 keep every conv accumulator below 2^24,
+    # HISTORY.md section 4: |bias| <= 2^22 and K*255*127 keep every conv accumulator below 2^24,
     # so fp32 accumulation of the bf16 products on the GPU is exact in any order
     assert 9 * 128 * 127 + weights.BIAS_LIMIT < 1 << 24
     assert 144 * 255 * 127 + weights.BIAS_LIMIT < 1 << 24

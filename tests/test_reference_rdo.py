@@ -191,7 +191,7 @@ def test_trained_weights_follow_the_reference_decisions(oracle, blob):
     err = np.abs(pred.astype(int) - ref.astype(int))
     mean_err = float(err.mean())  # compareSplitMode / units (TComSysuCuMDTools.cpp:48-77)
     # Full RDO's 64-vs-32 choices are often near-ties in RD cost, so exact agreement is moderate (the BD-rate in
-    # DESIGN.md section 4 is the quality measure); what must hold: rarely off by more than one level, and clearly
+    # HISTORY.md section 4 is the quality measure); what must hold: rarely off by more than one level, and clearly
     # closer to HM's map than any constant map.
     assert agree > 0.55 and mean_err < 0.55 and float((err <= 1).mean()) > 0.90, (agree, mean_err)
     const_agree = max(float((ref == c).mean()) for c in range(4))
