@@ -1429,8 +1429,9 @@ int fhevc_motion_search_device(fhevc_ctx* c, const void* d_luma, int sample_byte
       ctu_row_begin < 0 || ctu_row_end > c->ctus_y || ctu_row_begin > ctu_row_end || search_range < 1 || search_range > FHEVC_MOTION_WIDE_MAX_RANGE)
     return fail(c, FHEVC_E_INVALID, "bad motion-search arguments");
   const bool wide = search_range > FHEVC_MOTION_MAX_RANGE;
-  if (wide && !(c->motion_sad && c->cfg.bit_depth == 8))
-    return fail(c, FHEVC_E_INVALID, "search ranges above 8 need the SAD distortion (fhevc_set_motion_distortion) and 8-bit content");
+  if (wide && !c->motion_sad) return fail(c, FHEVC_E_INVALID, "search ranges above 8 need the SAD distortion (fhevc_set_motion_distortion)");
+  if (wide && c->cfg.bit_depth > 8 && sample_bytes != 2) return fail(c, FHEVC_E_INVALID, "bad motion-search arguments");
+  const bool big = wide && c->cfg.bit_depth > 8;   // above 8 bit: the generic kernel laid out for the wide window (round 4); 8 bit: the byte-SAD kernel
   if (sample_bytes == 1 && c->cfg.bit_depth != 8) return fail(c, FHEVC_E_INVALID, "uint8 samples need bit depth 8");
   if (frame_stride_samples < (long long)stride_samples * (c->cfg.height - 1) + c->cfg.width) return fail(c, FHEVC_E_INVALID, "frames overlap");
   if (ctu_row_begin == ctu_row_end) return FHEVC_OK;
@@ -1453,7 +1454,8 @@ int fhevc_motion_search_device(fhevc_ctx* c, const void* d_luma, int sample_byte
   }
   time_begin(c, st, 4);
   if (wide) {
-    HIP_TRY(c, fhevc_launch_motion_wide(fr, search_range, c->d_mvtab, reinterpret_cast<FhevcMotionNode*>(d_out), c->num_cus, st));
+    if (big) HIP_TRY(c, fhevc_launch_motion_big(fr, search_range, c->d_mvtab, reinterpret_cast<FhevcMotionNode*>(d_out), c->num_cus, st));
+    else HIP_TRY(c, fhevc_launch_motion_wide(fr, search_range, c->d_mvtab, reinterpret_cast<FhevcMotionNode*>(d_out), c->num_cus, st));
     if (!c->mvtab_used) HIP_TRY(c, hipEventCreateWithFlags(&c->mvtab_used, hipEventDisableTiming));
     HIP_TRY(c, hipEventRecord(c->mvtab_used, st));
   }

@@ -154,6 +154,8 @@ hipError_t fhevc_launch_motion(const FhevcFrames& fr, int range, const FhevcMvCo
 // vector costs in raster order, in HBM
 #define FHEVC_MOTION_WIDE_MAX_RANGE 64
 hipError_t fhevc_launch_motion_wide(const FhevcFrames& fr, int range, const uint32_t* d_mvtab, FhevcMotionNode* d_out, int num_cus, hipStream_t stream);
+// ... and for content ABOVE 8 bit (16-bit planes; round 4): fhevc_motion_kernel itself laid out for the +-64 window (k_motion.hip), the same d_mvtab
+hipError_t fhevc_launch_motion_big(const FhevcFrames& fr, int range, const uint32_t* d_mvtab, FhevcMotionNode* d_out, int num_cus, hipStream_t stream);
 
 // the shipped P-picture rule (fhevc_p_rule_default): see fasthevc.h; regenerate with tests/quality/fit_p_rule.py
 #define FHEVC_P_RULE_WEIGHTS { { 3101, 188, -94, 80, 1149, 1149, 3174, -138, 15748, -351620 }, \

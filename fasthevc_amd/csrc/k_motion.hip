@@ -25,9 +25,14 @@
 
 namespace {
 
-constexpr int MAXR = FHEVC_MOTION_MAX_RANGE;
-constexpr int RP = 64 + 2 * MAXR + 8;  // LDS row pitch of the reference window in samples (multiple of 8: 16-byte row starts)
-constexpr int WIN_ROWS = 64 + 2 * MAXR;
+// MR = the largest search range an instantiation is laid out for: FHEVC_MOTION_MAX_RANGE (8: the window in 15 KB of static LDS, the vector costs in the
+// kernel arguments) or FHEVC_MOTION_WIDE_MAX_RANGE (64, round 4: HM's own SearchRange for content ABOVE 8 bit, where k_motion_wide.hip's byte SADs do
+// not apply -- the window in 76.8 KB of dynamic LDS, the (2 R + 1)^2 vector costs in HBM).  Same code, same raster order, same first-found minimum.
+template <int MR> struct MotionGeom {
+  static constexpr int RP = 64 + 2 * MR + 8;  // LDS row pitch of the reference window in samples (multiple of 8: 16-byte row starts)
+  static constexpr int WIN_ROWS = 64 + 2 * MR;
+  static constexpr int REF_SAMPLES = WIN_ROWS * RP + 8;
+};
 
 typedef __attribute__((ext_vector_type(2))) short i16x2;
 __device__ __forceinline__ unsigned pk_add(unsigned a, unsigned b)
@@ -111,10 +116,14 @@ template <typename T>
 __device__ __forceinline__ int sample_at(const T* plane, long long off) { return (int)plane[off]; }
 
 // T = int16_t (HM Pel planes) or uint8_t; PACKED = bit depth <= 10; SAD: see the header
-template <typename T, bool PACKED, bool SAD>
-__global__ __launch_bounds__(256) void fhevc_motion_kernel(FhevcFrames F, int range, FhevcMvCost mvc, FhevcMotionNode* __restrict__ out)
+template <typename T, bool PACKED, bool SAD, int MR>
+__global__ __launch_bounds__(256) void fhevc_motion_kernel(FhevcFrames F, int range, FhevcMvCost mvc, const uint32_t* __restrict__ mvtab, FhevcMotionNode* __restrict__ out)
 {
-  __shared__ __attribute__((aligned(16))) short s_ref[WIN_ROWS * RP + 8];
+  constexpr int RP = MotionGeom<MR>::RP;
+  constexpr bool BIG = MR > FHEVC_MOTION_MAX_RANGE;
+  extern __shared__ __attribute__((aligned(16))) short s_dyn[];
+  __shared__ __attribute__((aligned(16))) short s_small[BIG ? 8 : MotionGeom<MR>::REF_SAMPLES];
+  short* const s_ref = BIG ? s_dyn : s_small;
   __shared__ unsigned s_cost[4][4][64], s_satd[4][4][64], s_idx[4][4][64], s_zero[4][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tx = lane & 7, ty = lane >> 3;
@@ -245,7 +254,7 @@ __global__ __launch_bounds__(256) void fhevc_motion_kernel(FhevcFrames F, int ra
       s[1] = a + __shfl_xor(a, 16);
       a = s[1] + __shfl_xor(s[1], 4);
       s[0] = a + __shfl_xor(a, 32);
-      const unsigned vc = mvc.c[m];
+      const unsigned vc = BIG ? mvtab[m] : mvc.c[m];
 #pragma unroll
       for (int l = 0; l < 4; ++l) {
         const unsigned sd = s[l] >> shift;  // DISTORTION_PRECISION_ADJUSTMENT on the block's sum (TComRdCost.cpp:1823)
@@ -292,11 +301,34 @@ hipError_t fhevc_launch_motion(const FhevcFrames& fr, int range, const FhevcMvCo
   const long long total = (long long)(fr.row_end - fr.row_begin) * fr.ctus_x * (fr.num_frames - 1);
   if (total <= 0) return hipSuccess;
   const int grid = (int)(total < 4LL * num_cus ? total : 4LL * num_cus);
-#define FHEVC_MOTION(T, P) do { if (sad) hipLaunchKernelGGL((fhevc_motion_kernel<T, P, true>), dim3(grid), dim3(256), 0, stream, fr, range, mvc, d_out); \
-                                else hipLaunchKernelGGL((fhevc_motion_kernel<T, P, false>), dim3(grid), dim3(256), 0, stream, fr, range, mvc, d_out); } while (0)
+#define FHEVC_MOTION(T, P) do { if (sad) hipLaunchKernelGGL((fhevc_motion_kernel<T, P, true, FHEVC_MOTION_MAX_RANGE>), dim3(grid), dim3(256), 0, stream, fr, range, mvc, nullptr, d_out); \
+                                else hipLaunchKernelGGL((fhevc_motion_kernel<T, P, false, FHEVC_MOTION_MAX_RANGE>), dim3(grid), dim3(256), 0, stream, fr, range, mvc, nullptr, d_out); } while (0)
   if (fr.sample_bytes == 2 && fr.bit_depth <= 10) FHEVC_MOTION(int16_t, true);
   else if (fr.sample_bytes == 2) FHEVC_MOTION(int16_t, false);
   else FHEVC_MOTION(uint8_t, true);
 #undef FHEVC_MOTION
+  return hipGetLastError();
+}
+
+// ranges 9 .. 64 on 16-bit planes above 8 bit (SAD, HM's integer-search distortion): the same kernel laid out for a window of up to 192 x 192 samples
+hipError_t fhevc_launch_motion_big(const FhevcFrames& fr, int range, const uint32_t* d_mvtab, FhevcMotionNode* d_out, int num_cus, hipStream_t stream)
+{
+  const long long total = (long long)(fr.row_end - fr.row_begin) * fr.ctus_x * (fr.num_frames - 1);
+  if (total <= 0) return hipSuccess;
+  if (fr.sample_bytes != 2 || range > FHEVC_MOTION_WIDE_MAX_RANGE) return hipErrorInvalidValue;
+  constexpr int MRB = FHEVC_MOTION_WIDE_MAX_RANGE;
+  const size_t lds = (size_t)MotionGeom<MRB>::REF_SAMPLES * sizeof(short);   // 76 816 B: two workgroups per CU
+  const int grid = (int)(total < 2LL * num_cus ? total : 2LL * num_cus);
+  const FhevcMvCost none = {};
+  hipError_t e;
+  if (fr.bit_depth <= 10) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_motion_kernel<int16_t, true, true, MRB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((fhevc_motion_kernel<int16_t, true, true, MRB>), dim3(grid), dim3(256), lds, stream, fr, range, none, d_mvtab, d_out);
+  } else {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_motion_kernel<int16_t, false, true, MRB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((fhevc_motion_kernel<int16_t, false, true, MRB>), dim3(grid), dim3(256), lds, stream, fr, range, none, d_mvtab, d_out);
+  }
   return hipGetLastError();
 }

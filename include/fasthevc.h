@@ -216,14 +216,18 @@ int  fhevc_preanalyze_frames_device(fhevc_ctx* ctx, const void* d_luma, int samp
  *                      refinement only (HadamardME, TEncSearch.cpp:836): this is the library's own choice, the one the P-picture
  *                      rule of fhevc_p_depth_range was fitted on.
  * HM's own search runs on reconstructed references inside its serial CTU loop; this is its source-only twin, available for
- * the whole picture before that loop starts.  search_range 1..8 in either mode; 9..64 (HM's cfg: SearchRange 64) in the SAD mode on
- * 8-bit content: the same full search, same result as xPatternSearch over that window, on a kernel laid out for 16 641 vectors per node
- * (k_motion_wide.hip); FHEVC_E_INVALID otherwise. */
+ * the whole picture before that loop starts.  search_range 1..8 in either mode; 9..64 (HM's cfg: SearchRange 64; xPatternSearch,
+ * TEncSearch.cpp:3786-3848, is bit-depth agnostic) in the SAD mode: the same full search, same result as xPatternSearch over that
+ * window -- 8-bit content on a kernel laid out for 16 641 vectors per node around v_qsad_pk_u16_u8 (k_motion_wide.hip), content above
+ * 8 bit (16-bit planes; cfg/encoder_lowdelay_P_main10.cfg) on the 16-bit SAD kernel laid out for the wide window (k_motion.hip, round 4;
+ * ~20 x slower than the byte kernel, still ~100 x HM's own search per core); 9..64 in the SATD mode: FHEVC_E_INVALID.
+ * (HM's P configuration itself runs the TZ search, cfg/encoder_lowdelay_P_main.cfg:34 FastSearch 1 -> xPatternSearchFast,
+ * TEncSearch.cpp:3850: the exhaustive twin is a superset of what TZ visits and serves as a source-only feature.) */
 #define FHEVC_MOTION_SATD 0
 #define FHEVC_MOTION_SAD  1
 int  fhevc_set_motion_distortion(fhevc_ctx* ctx, int mode);
-#define FHEVC_MOTION_MAX_RANGE 8        /* SATD mode, and content above 8 bit */
-#define FHEVC_MOTION_SAD_MAX_RANGE 64   /* SAD mode, 8-bit content */
+#define FHEVC_MOTION_MAX_RANGE 8        /* SATD mode */
+#define FHEVC_MOTION_SAD_MAX_RANGE 64   /* SAD mode, any bit depth */
 typedef struct {
   uint32_t satd_zero;       /* distortion (SATD or SAD) at vector (0, 0) */
   uint32_t satd_best;       /* distortion at the cheapest vector */

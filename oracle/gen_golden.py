@@ -115,6 +115,7 @@ def main():
     intra_lines_golden(ref)
     pattern_search_golden(ref)
     pattern_search_golden(ref, PATTERN_SEARCH_WIDE_CASES, "ref_pattern_search_wide.npz")
+    pattern_search_golden(ref, PATTERN_SEARCH_WIDE10_CASES, "ref_pattern_search_wide10.npz")
 
 
 PREANALYZE_CASES = (("texture16", 416, 240, 8, 3), ("hetero", 1000, 568, 10, 4), ("hetero", 64, 64, 8, 1))
@@ -207,6 +208,12 @@ PATTERN_SEARCH_WIDE_CASES = (  # the same at HM's own SearchRange and two odd on
     (8, 32, 64, 31, (0, 9, 27), (21, -37)),
     (8, 27, 24, 32, (3, 13), (13, 9)),
     (8, 37, 33, 33, (6, 17, 24), (-30, 5)))
+
+
+PATTERN_SEARCH_WIDE10_CASES = (  # round 4: the wide window ABOVE 8 bit (16-bit SAD kernel laid out for +-64, k_motion.hip): 10 and 12 bit, low bits populated
+    (10, 32, 64, 41, (0, 13), (17, -29)),
+    (10, 27, 20, 42, (6, 27), (11, 7)),
+    (12, 37, 40, 43, (24,), (-26, 12)))
 
 
 def pattern_search_golden(ref, cases=None, name="ref_pattern_search.npz"):

@@ -121,7 +121,7 @@ def test_motion_search_1080p_device_batch(oracle):
     ctx.close()
 
 
-@pytest.mark.parametrize("name,nodes", [("ref_pattern_search.npz", 706), ("ref_pattern_search_wide.npz", 517)])
+@pytest.mark.parametrize("name,nodes", [("ref_pattern_search.npz", 706), ("ref_pattern_search_wide.npz", 517), ("ref_pattern_search_wide10.npz", 262)])
 def test_sad_mode_reproduces_the_references_xPatternSearch(name, nodes):
     """The HIP kernels in the SAD mode, through the C ABI, against what the reference's OWN TEncSearch::xPatternSearch returned
     (tests/golden/ref_pattern_search.npz: 706 nodes of whole CTUs incl. picture corners and edges, 8 / 10 bit, ranges 3 / 4 / 8;
@@ -148,17 +148,22 @@ def test_sad_mode_reproduces_the_references_xPatternSearch(name, nodes):
     assert checked == nodes
 
 
-@pytest.mark.parametrize("rng,qp,speeds", [(64, 32, (21, -37)), (16, 22, (9, 14)), (33, 40, (-30, 5)), (9, 51, (3, 3)), (47, 27, (40, -44))])
-def test_wide_sad_search_vs_oracle(oracle, rng, qp, speeds):
-    """Ranges above 8 (k_motion_wide.hip: 8 dy x 4 dx vectors per lane on v_qsad_pk_u16_u8, keys merged by LDS atomic minima) against the oracle's
-    plain loops, every node of every CTU of a ragged picture (last column 32 wide, last row 48 tall): zero-vector SAD, vector, SAD, cost."""
+@pytest.mark.parametrize("rng,qp,speeds,bd", [(64, 32, (21, -37), 8), (16, 22, (9, 14), 8), (33, 40, (-30, 5), 8), (9, 51, (3, 3), 8), (47, 27, (40, -44), 8),
+                                              (64, 30, (19, -33), 10), (21, 37, (-12, 16), 10), (40, 25, (28, 9), 12)])
+def test_wide_sad_search_vs_oracle(oracle, rng, qp, speeds, bd):
+    """Ranges above 8 (8 bit: k_motion_wide.hip, 8 dy x 4 dx vectors per lane on v_qsad_pk_u16_u8, keys merged by LDS atomic minima; above 8 bit:
+    k_motion.hip's 16-bit SAD kernel laid out for the +-64 window, round 4) against the oracle's plain loops, every node of every CTU of a ragged
+    picture (last column 32 wide, last row 48 tall): zero-vector SAD, vector, SAD, cost.  Above 8 bit the low bits are populated."""
     W, H = 416, 240
     ys = frames.pan_clip(W, H, 2, seed=100 + rng, v_structure=speeds[0], v_noise=speeds[1])
-    (rb, org, stride), (cb, _, _) = [frames.to_pel_plane(y, 8) for y in ys]
-    ctx = capi.Context(W, H, 8)
+    (rb, org, stride), (cb, _, _) = [frames.to_pel_plane(y, bd) for y in ys]
+    if bd > 8:
+        cb = (cb + np.random.default_rng(bd).integers(0, 1 << (bd - 8), size=cb.shape, dtype=np.int16)).astype(np.int16)
+        rb = (rb + np.random.default_rng(bd + 1).integers(0, 1 << (bd - 8), size=rb.shape, dtype=np.int16)).astype(np.int16)
+    ctx = capi.Context(W, H, bd)
     ctx.set_motion_distortion("sad")
     got = ctx.motion_search(cb, rb, org, stride, qp=qp, search_range=rng)
-    exp = oracle_motion(oracle, cb, rb, org, stride, W, H, 8, qp, rng, sad=True)
+    exp = oracle_motion(oracle, cb, rb, org, stride, W, H, bd, qp, rng, sad=True)
     for k in capi.MOTION_DTYPE.names:
         assert np.array_equal(got[k], exp[k]), (k, np.argwhere(got[k] != exp[k])[:5])
     if min(abs(v) for v in speeds) > 8:
