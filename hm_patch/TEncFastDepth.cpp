@@ -30,10 +30,11 @@ void TEncFastDepth::readKnobs()
   const char* mg = std::getenv("FHEVC_MARGIN");
   const char* ms = std::getenv("FHEVC_MARGIN_SPLIT");
   const char* mt = std::getenv("FHEVC_MARGIN_STOP");
-  // defaults: the calibration that keeps EVERY content family within 1 % BD-rate with the shipped blob depthnet_v2.fhw (HISTORY.md section 4,
-  // profiles/r03_bdrate_generalization.json): splits are forced only above +100000, forbidden only below -64000, HM's own search decides in
-  // between (the round-2 blob depthnet_v1.fhw: 100000 / 48000).  On content like the classifier's training set FHEVC_MARGIN_SPLIT=48000
-  // FHEVC_MARGIN_STOP=16000 keeps the loss at or below 0.2 % at 1.5-3.7x less decision time.
+  // defaults: the calibration that keeps EVERY content family within 1 % BD-rate: splits are forced only above +100000, forbidden only below
+  // -64000, HM's own search decides in between.  With the recommended blob depthnet_family_d2.fhw: ten families, three never in a training
+  // label, -0.26 .. +0.47 % at 1.2-2.1x less decision time (profiles/r04_bdrate_family_d2_ten_families.json); with depthnet_v2.fhw <= +0.83 %
+  // (profiles/r03_bdrate_generalization.json).  On content like the classifier's training set FHEVC_MARGIN_SPLIT=64000 FHEVC_MARGIN_STOP=32000
+  // keeps nine of the ten families at or below +0.91 % at 1.4-3.8x.
   m_marginSplit = ms ? std::atoi(ms) : (mg ? std::atoi(mg) : 100000);
   m_marginStop  = mt ? std::atoi(mt) : (mg ? std::atoi(mg) : 64000);
   if (m_marginSplit < 0) m_marginSplit = 0;

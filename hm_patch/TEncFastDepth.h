@@ -8,13 +8,13 @@
  * Knobs arrive through the environment so that TAppEncCfg stays untouched:
  *   FHEVC_ENABLE=1            turn the path on
  *   FHEVC_WEIGHTS=<file>      weight blob: FHW1 (the 16 / 32 / 64 network) or FHW3 (any member of the reference's network family, e.g.
- *                             depthnet_family_d2.fhw = 23 / 46 / 92 x 2, the best classifier shipped)
+ *                             depthnet_family_d2.fhw = 23 / 46 / 92 x 2, the best classifier shipped and the recommended one)
  *   FHEVC_DEVICE=<ordinal>    HIP device (default 0)
  *   FHEVC_MARGIN=<int>        soft decisions: logit margin inside which a split decision is left to HM's RDO;
  *   FHEVC_MARGIN_SPLIT / FHEVC_MARGIN_STOP set the two sides separately (not forcing unsure splits is almost free,
  *                             not forbidding unsure ones costs the recursion it allows).  Defaults: split 100000, stop 64000 (every content
- *                             family measured stays within 1 % BD-rate with depthnet_v2.fhw); split 48000, stop 16000 for content like the
- *                             training set;
+ *                             family measured stays within 1 % BD-rate: <= +0.47 % with depthnet_family_d2.fhw); split 64000, stop 32000 for
+ *                             content like the training set;
  *                             FHEVC_MARGIN=0 gives hard decisions
  *   FHEVC_P_MODE=window|motion  P/B pictures whose first reference picture was inter coded (default: off = stock RDO):
  *                             window = co-located depth of that picture +- FHEVC_P_WINDOW levels (host logic only, independent of
