@@ -228,18 +228,19 @@ int build_weight_image(fhevc_ctx* c, const BlobView& b)
         }
       }
   // the i8 variant (v_mfma_i32_32x32x32_i8: a lane holds 16 signed bytes of K; lanes 0-31 K 0-15, lanes 32-63 K 16-31):
-  //   conv2 fragment (q, kx): row = output channel lane & 31, K byte j of lane half h = input channel j at tap (ky = 2 q + h, kx)
-  //                           (ky = 3: the phantom row, zero);
+  //   conv2 fragments (k_cnn.hip, conv2_half_i8): row = output channel lane & 31, K byte j of lane half h = input channel j at tap
+  //                           0-2: (ky = h, kx = 0..2); 3: (2, kx = 2 h); 4: (2, 1) for h = 0, zero for h = 1; 5: zero | (2, 1);
   //   conv3 fragment (tile, tap): row = output channel 32 tile + (lane & 31), K byte j of lane half h = input channel 16 h + j
   std::vector<int8_t> frag8((size_t)FHEVC_FRAGI8_TOTAL * 16, 0);
   for (int lane = 0; lane < 64; ++lane) {
     const int r = lane & 31, h = lane >> 5;
     for (int j = 0; j < 16; ++j) {
-      for (int q = 0; q < 2; ++q)
-        for (int kx = 0; kx < 3; ++kx) {
-          const int ky = 2 * q + h;
-          if (ky <= 2) frag8[((size_t)FHEVC_FRAGI8_CONV2 + (q * 3 + kx) * 64 + lane) * 16 + j] = b.w2[(r * 16 + j) * 9 + ky * 3 + kx];
-        }
+      auto w2 = [&](int ky, int kx) { return b.w2[(r * 16 + j) * 9 + ky * 3 + kx]; };
+      int8_t* f2 = &frag8[((size_t)FHEVC_FRAGI8_CONV2 + lane) * 16 + j];   // fragment s at f2[s * 64 * 16]
+      for (int kx = 0; kx < 3; ++kx) f2[(size_t)kx * 1024] = w2(h, kx);
+      f2[3 * 1024] = w2(2, 2 * h);              // [(2, 0) | (2, 2)]
+      f2[4 * 1024] = h == 0 ? w2(2, 1) : 0;     // [(2, 1) | 0]
+      f2[5 * 1024] = h == 1 ? w2(2, 1) : 0;     // [0 | (2, 1)]
       for (int t = 0; t < 2; ++t)
         for (int tap = 0; tap < 9; ++tap)
           frag8[((size_t)FHEVC_FRAGI8_CONV3 + (t * 9 + tap) * 64 + lane) * 16 + j] = b.w3[((32 * t + r) * 32 + 16 * h + j) * 9 + tap];

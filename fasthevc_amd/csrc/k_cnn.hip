@@ -511,16 +511,22 @@ __device__ __forceinline__ i32x16 mfma_i8(const bf16x8& a, const bf16x8& b, cons
 {
   return __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, a), __builtin_bit_cast(i32x4, b), c, 0, 0, 0);
 }
-// conv2: K = one column of taps over TWO input rows (ky = 2 q + lane half) x 16 channels: q = 0 -> taps (0, kx), (1, kx);
-// q = 1 -> (2, kx) and a phantom row whose weights are zero.  The lane halves read rows one A1_ROW apart (the lane's base
-// pointer carries it), so fragment (q, column c) is ONE ds_read_b128 at a compile-time offset: 8 fragments, 12 MFMAs per
-// half-chain (c = 1, 2 feed both accumulators) where the 16-bit form needs 12 and 18
-__device__ __forceinline__ const unsigned char* conv2_frag_i8(const unsigned char* base, int f)
+// conv2 (round 4: 4.5 K steps of 32 instead of 6): rows ky = 0, 1 of the taps pair up along ky -- fragment c = input column c of the lane's pooled position,
+// the lane halves read rows one A1_ROW apart (the lane's base pointer carries it) --, row ky = 2 pairs up along kx with the lane halves TWO columns apart (same
+// parity plane, next slot): fragment 4 = columns (0, 2), fragment 5 = columns (1, 3) of row 2 (`d2`: the lane's offset to them; conflict-free like the others).
+// A fragments: 0-2 = taps (ky = h, kx), 3 = [(2, 0) | (2, 2)], 4 = [(2, 1) | 0], 5 = [0 | (2, 1)]: dx = 0 multiplies fragment 4 by A3 and fragment 5 by A4,
+// dx = 1 (one column on) fragment 5 by A3 and fragment 4 by A5.  Per half-chain 6 ds_read_b128 and 10 MFMAs for the two accumulators where the row-pair form (rounds 2-3: K rows 2 and a
+// phantom row 3) needed 8 and 12; measured -3.1 % of the launch as a sensitivity build before it was written (profiles/r04_ab_conv2_k_steps.log).
+__device__ __forceinline__ int conv2_lane_i8(int h) { return h ? A1_ROW + 16 : 2 * A1_ROW; }
+__device__ __forceinline__ const unsigned char* conv2_frag_i8(const unsigned char* base, int d2, int f)
 {
-  return base + 2 * (f / 4) * A1_ROW + (((f % 4) & 1) ? 0 : A1_EVEN) + ((f % 4) >> 1) * 16;
+  if (f < 4) return base + ((f & 1) ? 0 : A1_EVEN) + (f >> 1) * 16;
+  return base + d2 + (f == 4 ? A1_EVEN : 0);
 }
-template <bool FIRST, bool LAST>
-__device__ __forceinline__ void conv2_half_i8(const unsigned char* base, const unsigned char* next, const bf16x8 (&wA2)[9], bf16x8 (&ring)[RINGI],
+constexpr int C2F = 6;  // fragments per half-chain
+// R0: the ring slot of this half-chain's fragment 0
+template <bool FIRST, bool LAST, int R0>
+__device__ __forceinline__ void conv2_half_i8(const unsigned char* base, const unsigned char* next, int d2, const bf16x8 (&wA2)[9], bf16x8 (&ring)[RINGI],
                                               const int* bias, int h, i32x16& acc0, i32x16& acc1)
 {
   const i32x16 binit = bias_tile_i8(bias, h);  // read per half-chain, not held across the phase (168 registers)
@@ -528,19 +534,19 @@ __device__ __forceinline__ void conv2_half_i8(const unsigned char* base, const u
   acc1 = binit;
   if (FIRST) {
 #pragma unroll
-    for (int f = 0; f < RINGI; ++f) ring[f] = lds_frag(conv2_frag_i8(base, f));
+    for (int f = 0; f < RINGI; ++f) ring[(R0 + f) % RINGI] = lds_frag(conv2_frag_i8(base, d2, f));
   }
 #pragma unroll
-  for (int f = 0; f < 8; ++f) {
-    const int q = f / 4, c = f % 4;
-    const bf16x8 b = ring[f % RINGI];
-    if (c < 3) acc0 = mfma_i8(wA2[q * 3 + c], b, acc0);
-    if (c > 0) acc1 = mfma_i8(wA2[q * 3 + c - 1], b, acc1);
-    if (f + RINGI < 8) ring[f % RINGI] = lds_frag(conv2_frag_i8(base, f + RINGI));
-    else if (!LAST) ring[f % RINGI] = lds_frag(conv2_frag_i8(next, f + RINGI - 8));
+  for (int f = 0; f < C2F; ++f) {
+    const bf16x8 b = ring[(R0 + f) % RINGI];
+    if (f < 3) acc0 = mfma_i8(wA2[f], b, acc0);                    // rows 0, 1: columns 0 .. 2 for dx = 0
+    if (f >= 1 && f < 4) acc1 = mfma_i8(wA2[f - 1], b, acc1);      //            columns 1 .. 3 for dx = 1
+    if (f == 4) { acc0 = mfma_i8(wA2[3], b, acc0); acc1 = mfma_i8(wA2[5], b, acc1); }  // row 2, columns (0, 2): taps kx = 0, 2 of dx = 0; tap kx = 1 of dx = 1
+    if (f == 5) { acc0 = mfma_i8(wA2[4], b, acc0); acc1 = mfma_i8(wA2[3], b, acc1); }  //        columns (1, 3): tap kx = 1 of dx = 0; taps kx = 0, 2 of dx = 1
+    if (f + RINGI < C2F) ring[(R0 + f) % RINGI] = lds_frag(conv2_frag_i8(base, d2, f + RINGI));
+    else if (!LAST) ring[(R0 + f) % RINGI] = lds_frag(conv2_frag_i8(next, d2, f + RINGI - C2F));
   }
 }
-static_assert(8 % RINGI == 0, "the i8 conv2 hands its ring slots from half-chain to half-chain unchanged");
 template <int VALU_PER_GROUP>
 __device__ __forceinline__ void sched_chain12_i8()
 {
@@ -548,7 +554,7 @@ __device__ __forceinline__ void sched_chain12_i8()
   __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);                                        \
   __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                         \
   if (VALU_PER_GROUP > 0) __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_GROUP, 0);
-  FHEVC_G(1) FHEVC_G(2) FHEVC_G(2) FHEVC_G(1) FHEVC_G(1) FHEVC_G(2) FHEVC_G(2) FHEVC_G(1)  // fragments c = 0 .. 3 of q = 0, 1
+  FHEVC_G(1) FHEVC_G(2) FHEVC_G(2) FHEVC_G(1) FHEVC_G(2) FHEVC_G(2)  // fragments 0 .. 5
 #undef FHEVC_G
 }
 // conv3: one MFMA = one tap x all 32 input channels (lane half = activation plane) x the wave's 32 output channels x TWO output
@@ -1190,19 +1196,20 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
       const int* b2t = reinterpret_cast<const int*>(biasL) + 16;
       i32x16 t0, t1, a0, a1;
       bf16x8 ring[RINGI];
-      conv2_half_i8<true, false>(h00, h00 + A1_ROW, wA2, ring, b2t, h, t0, t1);
+      const int c2l = conv2_lane_i8(h);
+      conv2_half_i8<true, false, 0>(h00, h00 + A1_ROW, c2l, wA2, ring, b2t, h, t0, t1);
       if (FHEVC_I8_C2_SCHED) __builtin_amdgcn_sched_group_barrier(0x100, RINGI + 4, 0);  // bias tile + the ring's first fragments go out together
       if (FHEVC_I8_C2_SCHED) sched_chain12_i8<0>();
-      conv2_half_i8<false, false>(h00 + A1_ROW, h10, wA2, ring, b2t, h, a0, a1);
+      conv2_half_i8<false, false, C2F % RINGI>(h00 + A1_ROW, h10, c2l, wA2, ring, b2t, h, a0, a1);
       pool_h_i8(t0, t1);
       if (FHEVC_I8_C2_SCHED) sched_chain12_i8<FHEVC_I8_C2_FILL_POOL>();
       if (FHEVC_I8_C2_FENCE) __builtin_amdgcn_sched_barrier(0);
       pool_v_i8(t0, a0, a1);
       if (FHEVC_I8_C2_FENCE) __builtin_amdgcn_sched_barrier(0);
-      conv2_half_i8<false, false>(h10, h10 + A1_ROW, wA2, ring, b2t, h, t1, a0);
+      conv2_half_i8<false, false, (2 * C2F) % RINGI>(h10, h10 + A1_ROW, c2l, wA2, ring, b2t, h, t1, a0);
       conv2_requant_store_i8m<FASTRQ ? 1 : 0>(t0, a2dst + (2 * u0) * A2_PITCH * 16, shift2);
       if (FHEVC_I8_C2_SCHED) sched_chain12_i8<FHEVC_I8_C2_FILL_REQUANT>();
-      conv2_half_i8<false, true>(h10 + A1_ROW, h10 + A1_ROW, wA2, ring, b2t, h, a1, t0);
+      conv2_half_i8<false, true, (3 * C2F) % RINGI>(h10 + A1_ROW, h10 + A1_ROW, c2l, wA2, ring, b2t, h, a1, t0);
       pool_h_i8(t1, a0);
       if (FHEVC_I8_C2_SCHED) sched_chain12_i8<FHEVC_I8_C2_FILL_POOL>();
       if (FHEVC_I8_C2_FENCE) __builtin_amdgcn_sched_barrier(0);
@@ -1826,17 +1833,18 @@ __global__ __launch_bounds__(256, 2) void fhevc_cnn_depth_pipe_kernel(FhevcFrame
       const unsigned char* h10 = a1p + (4 * u1) * A1_ROW;
       i32x16 t0, t1, a0, a1;
       bf16x8 ring[RINGI];
-      conv2_half_i8<true, false>(h00, h00 + A1_ROW, wA2, ring, b2t, h, t0, t1);
+      const int c2l = conv2_lane_i8(h);
+      conv2_half_i8<true, false, 0>(h00, h00 + A1_ROW, c2l, wA2, ring, b2t, h, t0, t1);
       __builtin_amdgcn_sched_group_barrier(0x100, RINGI + 4, 0);
       sched_chain12_i8<FHEVC_PIPE_SCHED_X>();
-      conv2_half_i8<false, false>(h00 + A1_ROW, h10, wA2, ring, b2t, h, a0, a1);
+      conv2_half_i8<false, false, C2F % RINGI>(h00 + A1_ROW, h10, c2l, wA2, ring, b2t, h, a0, a1);
       pool_h_i8(t0, t1);
       sched_chain12_i8<FHEVC_PIPE_SCHED_X>();
       pool_v_i8(t0, a0, a1);
-      conv2_half_i8<false, false>(h10, h10 + A1_ROW, wA2, ring, b2t, h, t1, a0);
+      conv2_half_i8<false, false, (2 * C2F) % RINGI>(h10, h10 + A1_ROW, c2l, wA2, ring, b2t, h, t1, a0);
       conv2_requant_store_i8m<FASTRQ ? 1 : 0>(t0, a2dst + (2 * u0) * A2_PITCH * 16, shift2);
       sched_chain12_i8<FHEVC_PIPE_SCHED_X>();
-      conv2_half_i8<false, true>(h10 + A1_ROW, h10 + A1_ROW, wA2, ring, b2t, h, a1, t0);
+      conv2_half_i8<false, true, (3 * C2F) % RINGI>(h10 + A1_ROW, h10 + A1_ROW, c2l, wA2, ring, b2t, h, a1, t0);
       pool_h_i8(t1, a0);
       sched_chain12_i8<FHEVC_PIPE_SCHED_X>();
       pool_v_i8(t1, a1, t0);
