@@ -1597,27 +1597,51 @@ int fhevc_p_depth_range(const fhevc_motion_node* nodes, const uint8_t* prev_dept
 
 // Diagnostic (not part of include/fasthevc.h): run the stamped instantiation of the depth kernel over a
 // device-resident batch and return per-phase cycle sums averaged over workgroups (slots 0..7: prologue, conv1, conv2, conv3,
-// barrier wait after staging, depth, heads, staging), CTUs per workgroup (8) and the grid (9).
+// barrier wait after staging, depth, heads, staging), CTUs per workgroup (8), the grid (9), and the in-kernel clock in MHz
+// (10: median over the workgroups, 11: the slowest; s_memtime span / s_memrealtime span of the whole CTU loop).
 int fhevc_debug_cnn_phase_cycles(fhevc_ctx* c, const void* d_luma, int sample_bytes, int stride_samples,
-                                 long long frame_stride_samples, int num_frames, uint8_t* d_depth_map, double* out10)
+                                 long long frame_stride_samples, int num_frames, uint8_t* d_depth_map, double* out12)
 {
-  if (!c || !d_luma || !d_depth_map || !out10 || !c->have_weights) return FHEVC_E_INVALID;
+  if (!c || !d_luma || !d_depth_map || !out12 || !c->have_weights) return FHEVC_E_INVALID;
   (void)hipSetDevice(c->device);
   const FhevcFrames fr = frames_of(c, d_luma, sample_bytes, stride_samples, frame_stride_samples, num_frames, 0, c->ctus_y);
   unsigned long long* d_st = nullptr;
   const int max_grid = 4 * c->num_cus;  // fhevc_launch_cnn_stamped runs at most four workgroups per CU
-  HIP_TRY(c, hipMalloc(&d_st, (size_t)max_grid * 8 * sizeof(unsigned long long)));
-  HIP_TRY(c, hipMemset(d_st, 0, (size_t)max_grid * 8 * sizeof(unsigned long long)));
+  const size_t slots = (size_t)max_grid * FHEVC_STAMP_SLOTS;
+  HIP_TRY(c, hipMalloc(&d_st, slots * sizeof(unsigned long long)));
+  HIP_TRY(c, hipMemset(d_st, 0, slots * sizeof(unsigned long long)));
   int grid = 0;
-  HIP_TRY(c, fhevc_launch_cnn_stamped(fr, cnn_weights(c), d_depth_map, c->num_cus, c->knobs, d_st, &grid, c->stream));
-  std::vector<unsigned long long> h((size_t)max_grid * 8);
+  int32_t* d_had = nullptr;  // the fused source Hadamard's output, as in the timed launch (FHEVC_DEBUG_STAMPS_NO_HADAMARD=1: without it)
+  if (!std::getenv("FHEVC_DEBUG_STAMPS_NO_HADAMARD")) HIP_TRY(c, hipMalloc(&d_had, (size_t)num_frames * c->num_ctus * sizeof(int32_t)));
+  HIP_TRY(c, fhevc_launch_cnn_stamped(fr, cnn_weights(c), d_depth_map, d_had, c->num_cus, c->knobs, d_st, &grid, c->stream));
+  std::vector<unsigned long long> h(slots);
   HIP_TRY(c, hipMemcpyAsync(h.data(), d_st, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   (void)hipFree(d_st);
-  for (int k = 0; k < 10; ++k) out10[k] = 0;
-  for (int b = 0; b < grid; ++b) for (int k = 0; k < 8; ++k) out10[k] += (double)h[(size_t)b * 8 + k] / grid;
-  out10[8] = (double)num_frames * c->num_ctus / grid;
-  out10[9] = grid;
+  if (d_had) (void)hipFree(d_had);
+  for (int k = 0; k < 12; ++k) out12[k] = 0;
+  for (int b = 0; b < grid; ++b) for (int k = 0; k < 8; ++k) out12[k] += (double)h[(size_t)b * FHEVC_STAMP_SLOTS + k] / grid;
+  out12[8] = (double)num_frames * c->num_ctus / grid;
+  out12[9] = grid;
+  // the in-kernel clock: shader cycles per 100 MHz tick over each workgroup's whole CTU loop, median over the workgroups (MHz)
+  std::vector<double> mhz;
+  for (int b = 0; b < grid; ++b)
+    if (h[(size_t)b * FHEVC_STAMP_SLOTS + 9]) mhz.push_back(100.0 * (double)h[(size_t)b * FHEVC_STAMP_SLOTS + 8] / (double)h[(size_t)b * FHEVC_STAMP_SLOTS + 9]);
+  std::sort(mhz.begin(), mhz.end());
+  out12[10] = mhz.empty() ? 0.0 : mhz[mhz.size() / 2];
+  out12[11] = mhz.empty() ? 0.0 : mhz.front();
+  // [12 + 9 * slot + k]: the same eight phase sums averaged over the workgroups of CU slot 0 / 1 / 2 (k = 8: how many workgroups that is) -- the caller's
+  // array holds 39 doubles (FHEVC_DEBUG_STAMPS_BY_SLOT=1; the i8 form's conv-phase priority differs by slot, k_cnn.hip FHEVC_SLOT_PRIO)
+  if (std::getenv("FHEVC_DEBUG_STAMPS_BY_SLOT")) {
+    for (int k = 12; k < 39; ++k) out12[k] = 0;
+    for (int b = 0; b < grid; ++b) {
+      const int sl = (int)std::min<unsigned long long>(h[(size_t)b * FHEVC_STAMP_SLOTS + 10], 2);
+      for (int k = 0; k < 8; ++k) out12[12 + 9 * sl + k] += (double)h[(size_t)b * FHEVC_STAMP_SLOTS + k];
+      out12[12 + 9 * sl + 8] += 1;
+    }
+    for (int sl = 0; sl < 3; ++sl)
+      for (int k = 0; k < 8; ++k) if (out12[12 + 9 * sl + 8] > 0) out12[12 + 9 * sl + k] /= out12[12 + 9 * sl + 8];
+  }
   return FHEVC_OK;
 }
 

@@ -24,6 +24,7 @@
 #define FHEVC_F16_CONV3_32 0  // measured equal (0.5624 against 0.5659 ms on one box, parity green): the 16x16x32 form stays
 #endif
 // the i8 variant's fragments (one uint4 = 16 signed bytes per lane): conv2 [2 row pairs][3 columns of taps][64], conv3 [2 tiles][9 taps][64]
+#define FHEVC_STAMP_SLOTS 11   // per workgroup of the stamped diagnostic kernel: 8 phase sums, the CTU loop's s_memtime and s_memrealtime spans, the workgroup's slot on its CU
 #define FHEVC_FRAGI8_CONV2 0
 #define FHEVC_FRAGI8_CONV3 (6 * 64)
 #define FHEVC_FRAGI8_TOTAL (6 * 64 + 2 * 9 * 64)
@@ -125,7 +126,7 @@ hipError_t fhevc_launch_cnn(const FhevcFrames& fr, const FhevcCnnWeights& w, uin
                             uint32_t* d_flags, uint8_t* d_depth_max, int margin_split, int margin_stop, int num_cus, const FhevcKnobs& knobs, hipStream_t stream);
 hipError_t fhevc_launch_expand_flags(const FhevcFrames& fr, const uint32_t* d_flags, uint8_t* d_depth, hipStream_t stream);
 
-hipError_t fhevc_launch_cnn_stamped(const FhevcFrames& fr, const FhevcCnnWeights& w, uint8_t* d_depth, int num_cus, const FhevcKnobs& knobs,
+hipError_t fhevc_launch_cnn_stamped(const FhevcFrames& fr, const FhevcCnnWeights& w, uint8_t* d_depth, int32_t* d_had /* null: without the fused Hadamard */, int num_cus, const FhevcKnobs& knobs,
                                     unsigned long long* d_stamps, int* grid_out, hipStream_t stream);
 
 // ---- source Hadamard + SATD (k_hadamard.hip) ---------------------------------------------------------------

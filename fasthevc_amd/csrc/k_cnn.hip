@@ -913,7 +913,7 @@ __device__ __forceinline__ unsigned long long stamp()
   (void)r; (void)h; (void)wave;
 
 // STAMPS = true is a separate diagnostic instantiation (fhevc_debug_cnn_phase_cycles): wave 0 of every workgroup
-// adds the cycles of each phase (incl. the barrier that ends it) into d_stamps[blockIdx.x * 8 + phase].
+// adds the cycles of each phase (incl. the barrier that ends it) into d_stamps[blockIdx.x * FHEVC_STAMP_SLOTS + phase].
 // HAD: also write the per-CTU source Hadamard (d_had), computed from the samples the kernel loads anyway (one pass over the frame):
 //      1 = on packed 16-bit VALU from the prefetched samples (up to 10 bit: wave_src_hadamard), 2 = on the bf16 MFMA from the staged
 //      tile (8-bit content only: the tile holds the samples rounded to 8 bits; src_hadamard_mfma)
@@ -1019,7 +1019,14 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
     tsum[k] += tn - tprev;                                 \
     tprev = tn;                                            \
   }
-  if (STAMPS) tprev = stamp();
+  // the in-kernel clock (MI355X_MICROARCH.md, 'DVFS give-back' item 6): shader cycles (s_memtime) over the constant 100 MHz counter (s_memrealtime),
+  // stamped once around the workgroup's whole CTU loop -> d_stamps[.. + 8], [.. + 9]
+  unsigned long long tclk0 = 0, treal0 = 0;
+  if (STAMPS) {
+    tprev = stamp();
+    tclk0 = tprev;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(treal0)::"memory");
+  }
 
   // this thread's 16 samples of a CTU: picture row (tid >> 2), columns 16 * (tid & 3) ..
   const int ld_row = tid >> 2, ld_seg = tid & 3;
@@ -1544,8 +1551,16 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
     // no barrier here: the next P1 reads R2 (staged before the P4 barrier) and writes the A1 interior (R1, last read
     // before the P4 barrier, halo rewritten above by disjoint addresses); the logits are re-initialised in P2.
   }
-  if (STAMPS && tid == 0) {
-    for (int k = 0; k < 8; ++k) d_stamps[blockIdx.x * 8 + k] = tsum[k];
+  if (STAMPS) {
+    unsigned long long treal1;
+    const unsigned long long tclk1 = stamp();
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(treal1)::"memory");
+    if (tid == 0) {
+      for (int k = 0; k < 8; ++k) d_stamps[blockIdx.x * FHEVC_STAMP_SLOTS + k] = tsum[k];
+      d_stamps[blockIdx.x * FHEVC_STAMP_SLOTS + 8] = tclk1 - tclk0;
+      d_stamps[blockIdx.x * FHEVC_STAMP_SLOTS + 9] = treal1 - treal0;
+      d_stamps[blockIdx.x * FHEVC_STAMP_SLOTS + 10] = (unsigned long long)prio_slot;
+    }
   }
 #undef FHEVC_STAMP
 #undef FHEVC_CONV1_EARLY_READS
@@ -2132,8 +2147,8 @@ hipError_t fhevc_launch_cnn(const FhevcFrames& fr, const FhevcCnnWeights& w, uin
   return hipGetLastError();
 }
 
-// diagnostic build of the same kernel with s_memtime stamps; d_stamps: grid * 8 cycle sums (phases P0..P5)
-hipError_t fhevc_launch_cnn_stamped(const FhevcFrames& fr, const FhevcCnnWeights& w, uint8_t* d_depth, int num_cus, const FhevcKnobs& knobs,
+// diagnostic build of the same kernel with s_memtime stamps; d_stamps: grid * FHEVC_STAMP_SLOTS (8 phase cycle sums, then the loop's shader cycles and 100 MHz ticks)
+hipError_t fhevc_launch_cnn_stamped(const FhevcFrames& fr, const FhevcCnnWeights& w, uint8_t* d_depth, int32_t* d_had, int num_cus, const FhevcKnobs& knobs,
                                     unsigned long long* d_stamps, int* grid_out, hipStream_t stream)
 {
   const long long total = (long long)(fr.row_end - fr.row_begin) * fr.ctus_x * fr.num_frames;
@@ -2148,6 +2163,7 @@ hipError_t fhevc_launch_cnn_stamped(const FhevcFrames& fr, const FhevcCnnWeights
     if (e != hipSuccess) return e;
     launch_depth_kernel<true, 0, 0>(grid, stream, fr, w, d_depth, nullptr, nullptr, nullptr, d_stamps, nullptr, 0, 0);
   } else if (arith == 1) launch_depth_kernel<true, 0, 1>(grid, stream, fr, w, d_depth, nullptr, nullptr, nullptr, d_stamps, nullptr, 0, 0);
+  else if (d_had) launch_depth_kernel<true, 1, 2>(grid, stream, fr, w, d_depth, d_had, nullptr, nullptr, d_stamps, nullptr, 0, 0);  // as bench.py times it: with the fused source Hadamard
   else launch_depth_kernel<true, 0, 2>(grid, stream, fr, w, d_depth, nullptr, nullptr, nullptr, d_stamps, nullptr, 0, 0);
   return hipGetLastError();
 }
