@@ -37,6 +37,7 @@ struct FhevcKnobs {
   int debug_wg_per_cu = 0;      // FHEVC_DEBUG_WG_PER_CU=1..4: the same for the stamped diagnostic build only
   bool requant_general = false; // FHEVC_CNN_REQUANT=general: the i8 form's general requant instead of the short forms
   bool family_layers = false;   // FHEVC_FAMILY_LAYERS: a member with a fused kernel runs layer by layer all the same (tests)
+  bool trio = false;            // FHEVC_CNN_TRIO=1: the i8 depth kernel as ONE 768-thread workgroup per CU, three groups one barrier interval apart (k_cnn.hip, TRIO)
   bool fused_d2 = true;         // FHEVC_FUSED_D2=0: the two-convolutions-per-block members run layer by layer instead of through k_cnn_d2.inc (tests, A/B)
   bool layers_no_fuse = false;  // FHEVC_LAYERS_NO_FUSE: the layer path without the first convolution fused into the second (tests)
   bool layers_no_dbuf = false;  // FHEVC_LAYERS_NO_DBUF: the layer path's single-buffered staging (tests)

@@ -908,30 +908,41 @@ __device__ __forceinline__ unsigned long long stamp()
 #define FHEVC_PHASE_IDS                                   \
   int tid = (int)threadIdx.x;                             \
   asm volatile("" : "+v"(tid));                           \
+  if (TRIO) tid &= 255;                                   \
   const int lane = tid & 63, wave = tid >> 6;             \
   const int r = lane & 31, h = lane >> 5;                 \
   (void)r; (void)h; (void)wave;
 
 // STAMPS = true is a separate diagnostic instantiation (fhevc_debug_cnn_phase_cycles): wave 0 of every workgroup
-// adds the cycles of each phase (incl. the barrier that ends it) into d_stamps[blockIdx.x * FHEVC_STAMP_SLOTS + phase].
+// adds the cycles of each phase (incl. the barrier that ends it) into d_stamps[vbidx * FHEVC_STAMP_SLOTS + phase].
 // HAD: also write the per-CTU source Hadamard (d_had), computed from the samples the kernel loads anyway (one pass over the frame):
 //      1 = on packed 16-bit VALU from the prefetched samples (up to 10 bit: wave_src_hadamard), 2 = on the bf16 MFMA from the staged
 //      tile (8-bit content only: the tile holds the samples rounded to 8 bits; src_hadamard_mfma)
 // I8: conv2 and conv3 on v_mfma_i32_32x32x32_i8 with the activations as signed bytes (see Lds); the same integers come out.
 // I8 = 2: the same with the short requant forms (requant4_i8: conv2 mode 1, conv3 mode 2), where the host found them valid
-template <bool STAMPS, int HAD, int ARITH>
-__global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn_depth_kernel(FhevcFrames F, FhevcCnnWeights W,
+// TRIO = 1 (round 4): the CU's three workgroups as ONE workgroup of 768 threads = three groups of four waves, each group a "workgroup" of the form above with its own
+// third of the LDS and its own CTUs, but behind COMMON barriers and one barrier interval apart: at any time the three groups are in three different
+// intervals of the four (conv1 | conv2 | conv3 | heads + staging), so the intervals that load the matrix pipe never coincide -- three independent workgroups fall
+// into step and run them together (profiles/r04_depth_kernel_intervals.md).  Every group executes the same number of barriers: g empty ones before its first
+// CTU, 2 - g after its last, and four in an iteration that has no CTU left.
+template <bool STAMPS, int HAD, int ARITH, int TRIO = 0>
+__global__ __launch_bounds__(TRIO ? 768 : 256, TRIO ? 1 : (ARITH ? FHEVC_I8_WG_PER_CU : 2)) void fhevc_cnn_depth_kernel(FhevcFrames F, FhevcCnnWeights W,
                                                                   uint8_t* __restrict__ d_depth, int32_t* __restrict__ d_had,
                                                                   int32_t* __restrict__ d_logits,
                                                                   uint32_t* __restrict__ d_flags,
                                                                   unsigned long long* __restrict__ d_stamps,
                                                                   uint8_t* __restrict__ d_depth_max, int margin_split, int margin_stop)
 {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_all[];
+  const int group = TRIO ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;
+  unsigned char* const lds = lds_all + (TRIO ? group * Lds<ARITH != 0>::LDS_BYTES : 0);
+  // the grid as the CTU walk sees it: three virtual workgroups per real one in the TRIO form
+  const int vgrid = TRIO ? 3 * (int)gridDim.x : (int)gridDim.x;
+  const int vbidx = TRIO ? group * (int)gridDim.x + (int)blockIdx.x : (int)blockIdx.x;
   // fp32 rounding mode of this wave: toward -inf (MODE.fp_round, hwreg id 1, bits 1:0 <- 2).  Every fp32 operation of
   // the kernel is exact (integers scaled by powers of two), so only v_cvt_pk_u8_f32 notices: it becomes floor + clamp
   __builtin_amdgcn_s_setreg((1 << 11) | 1, 2);
-  const int tid = threadIdx.x;
+  const int tid = TRIO ? (int)(threadIdx.x & 255) : (int)threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   constexpr bool I8 = ARITH != 0, FASTRQ = ARITH == 2;
   int prio_slot = 0;   // which of the CU's workgroups this is, from where its LDS allocation starts (see FHEVC_SLOT_PRIO)
@@ -939,6 +950,7 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
     const unsigned la = __builtin_amdgcn_s_getreg((31 << 11) | 6);   // HW_REG_LDS_ALLOC: base [11:0], size [20:12], both in 256-byte granules
     const unsigned base = la & 0xFFFu, sz = (la >> 12) & 0x1FFu;
     prio_slot = base >= 2 * sz && sz ? 2 : (base >= sz && sz ? 1 : 0);
+    if (TRIO) prio_slot = group;
   }
   (void)prio_slot;
   if (FHEVC_SLOT_PRIO == 1 || FHEVC_SLOT_PRIO == 3) FHEVC_SETPRIO_DYN(prio_slot)
@@ -1032,10 +1044,10 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
   const int ld_row = tid >> 2, ld_seg = tid & 3;
   // XCD-aware order (speed only): blockIdx % 8 share an L2, give each XCD a contiguous run of CTUs per sweep so that the
   // 128-byte lines shared by horizontally adjacent CTUs (HM's unaligned margins) are fetched into one L2, not two
-  const int vblock = (gridDim.x & 7) ? (int)blockIdx.x : (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));
+  const int vblock = (vgrid & 7) ? vbidx : ((vbidx & 7) * (vgrid >> 3) + (vbidx >> 3));
   CtuPos pos, step;  // this workgroup's current item and its stride (the only divisions of the kernel)
   {
-    const int vb = min(vblock, total - 1), g = (int)gridDim.x;
+    const int vb = min(vblock, total - 1), g = vgrid;
     pos.f = vb / per_frame; pos.ry = (vb - pos.f * per_frame) / F.ctus_x; pos.cx = (vb - pos.f * per_frame) - pos.ry * F.ctus_x;
     step.f = g / per_frame; step.ry = (g - step.f * per_frame) / F.ctus_x; step.cx = (g - step.f * per_frame) - step.ry * F.ctus_x;
   }
@@ -1102,7 +1114,15 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
 
   // Per CTU: P1 conv1 | P2 conv2 | P3 conv3 (next CTU's samples are requested) | P4 heads + next CTU staged into LDS |
   // P5 depth map + conv1 halo re-zeroed -- four barriers; P5 runs into the next P1 without one (disjoint LDS).
-  for (int work = vblock; work < total; work += gridDim.x) {
+  if (TRIO) {
+    for (int i = 0; i < group; ++i) __syncthreads();  // one barrier interval behind the group before
+  }
+  const int trio_iters = TRIO ? (total + vgrid - 1) / vgrid : 0;  // the same for all three groups: the barriers must pair up
+  for (int work = vblock, it = 0; TRIO ? it < trio_iters : work < total; work += vgrid, ++it) {
+    if (TRIO && work >= total) {  // (only ever the last iteration) no CTU left for this group: keep the others' barriers company
+      __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads();
+      continue;
+    }
     const int f = pos.f, cy = F.row_begin + pos.ry, cx = pos.cx;
     const CtuPos next = advance(pos, step, band_rows, F.ctus_x);
 
@@ -1269,7 +1289,7 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
     FHEVC_STAMP(2)
 
     // ================= P3: conv3 (32 -> 64), K = 9 taps x 32 ch, requant to u8 =================
-    pre = prefetch_ctu<HAD == 1>(F, work + (int)gridDim.x < total, next, ld_row, ld_seg);  // next CTU's samples travel under conv3 and the heads
+    pre = prefetch_ctu<HAD == 1>(F, work + vgrid < total, next, ld_row, ld_seg);  // next CTU's samples travel under conv3 and the heads
     if constexpr (I8) {
       FHEVC_PHASE_IDS
       FHEVC_PRIO_ON(2)
@@ -1472,7 +1492,7 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
     }
     // the A2/input region (R2) is free since the P3 barrier: stage the next CTU now, its P1 needs no extra barrier
     FHEVC_STAMP(6)  // heads only
-    if (work + (int)gridDim.x < total) {
+    if (work + vgrid < total) {
       FHEVC_PHASE_IDS  // the staging addresses are re-derived per CTU: hoisted, they were spilled to scratch in the 168-register form
       stage_ctu(lds, L::R2_OFF, pre, F, next, tid, tid >> 2, tid & 3, shift_in, hc.in);
     }
@@ -1551,15 +1571,18 @@ __global__ __launch_bounds__(256, ARITH ? FHEVC_I8_WG_PER_CU : 2) void fhevc_cnn
     // no barrier here: the next P1 reads R2 (staged before the P4 barrier) and writes the A1 interior (R1, last read
     // before the P4 barrier, halo rewritten above by disjoint addresses); the logits are re-initialised in P2.
   }
+  if (TRIO) {
+    for (int i = group; i < 2; ++i) __syncthreads();
+  }
   if (STAMPS) {
     unsigned long long treal1;
     const unsigned long long tclk1 = stamp();
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(treal1)::"memory");
     if (tid == 0) {
-      for (int k = 0; k < 8; ++k) d_stamps[blockIdx.x * FHEVC_STAMP_SLOTS + k] = tsum[k];
-      d_stamps[blockIdx.x * FHEVC_STAMP_SLOTS + 8] = tclk1 - tclk0;
-      d_stamps[blockIdx.x * FHEVC_STAMP_SLOTS + 9] = treal1 - treal0;
-      d_stamps[blockIdx.x * FHEVC_STAMP_SLOTS + 10] = (unsigned long long)prio_slot;
+      for (int k = 0; k < 8; ++k) d_stamps[vbidx * FHEVC_STAMP_SLOTS + k] = tsum[k];
+      d_stamps[vbidx * FHEVC_STAMP_SLOTS + 8] = tclk1 - tclk0;
+      d_stamps[vbidx * FHEVC_STAMP_SLOTS + 9] = treal1 - treal0;
+      d_stamps[vbidx * FHEVC_STAMP_SLOTS + 10] = (unsigned long long)prio_slot;
     }
   }
 #undef FHEVC_STAMP
@@ -2063,6 +2086,10 @@ hipError_t fhevc_cnn_prepare_device()
   FHEVC_LAYER_FUSE(1) FHEVC_LAYER_FUSE(2)
 #undef FHEVC_LAYER_FUSE
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_d2_kernel<1, 2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, LdsD2<1, 2, 3>::LDS_BYTES);
+  // the i8 depth kernel as one 768-thread workgroup per CU: three groups x 50 048 B
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_kernel<false, 0, 2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * Lds<true>::LDS_BYTES);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_kernel<false, 1, 2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * Lds<true>::LDS_BYTES);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_kernel<true, 1, 2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * Lds<true>::LDS_BYTES);
   return e;
 }
 
@@ -2104,6 +2131,7 @@ FhevcKnobs fhevc_read_knobs()
   k.layers_no_dbuf = std::getenv("FHEVC_LAYERS_NO_DBUF") != nullptr;
   if (const char* kb = std::getenv("FHEVC_LAYERS_LDS_KB")) k.layers_lds_limit = (size_t)std::min(80, std::max(8, std::atoi(kb))) * 1024;   // <= the opt-in of fhevc_cnn_prepare_device
   if (const char* lg = std::getenv("FHEVC_LAYERS_GRID")) k.layers_grid = std::atoi(lg);
+  if (const char* tr = std::getenv("FHEVC_CNN_TRIO")) k.trio = tr[0] != '0';
   return k;
 }
 
@@ -2125,6 +2153,14 @@ hipError_t fhevc_launch_cnn(const FhevcFrames& fr, const FhevcCnnWeights& w, uin
   // the fused source Hadamard's form: on the MFMA from the staged tile for 8-bit content (the tile IS the samples), on packed
   // 16-bit VALU from the prefetched samples otherwise (the tile is rounded to 8 bits); w.had_valu forces the latter (A/B, tests)
   const int had = d_had == nullptr ? 0 : (fr.bit_depth == 8 && !w.had_valu) ? 2 : 1;
+  if (knobs.trio && !knobs.wg_per_cu && !w.pipe && cnn_arith(w) == 2 && had != 2) {  // three groups behind common barriers, one interval apart: one workgroup per CU
+    const int tgrid = (int)std::min<long long>(num_cus, (total + 2) / 3);
+#define FHEVC_LAUNCH_TRIO(HAD) hipLaunchKernelGGL((fhevc_cnn_depth_kernel<false, HAD, 2, 1>), dim3(tgrid), dim3(768), 3 * Lds<true>::LDS_BYTES, stream, fr, w, d_depth, d_had, \
+                                                  d_logits, d_flags, nullptr, d_depth_max, margin_split, margin_stop)
+    if (had) FHEVC_LAUNCH_TRIO(1); else FHEVC_LAUNCH_TRIO(0);
+#undef FHEVC_LAUNCH_TRIO
+    return hipGetLastError();
+  }
   if (w.i8 && w.pipe && had != 2) {  // the software-pipelined form of the i8 kernel: two workgroups per CU
     int pgrid = 2 * num_cus;
     if (knobs.wg_per_cu == 1) pgrid = num_cus;
@@ -2163,7 +2199,11 @@ hipError_t fhevc_launch_cnn_stamped(const FhevcFrames& fr, const FhevcCnnWeights
     if (e != hipSuccess) return e;
     launch_depth_kernel<true, 0, 0>(grid, stream, fr, w, d_depth, nullptr, nullptr, nullptr, d_stamps, nullptr, 0, 0);
   } else if (arith == 1) launch_depth_kernel<true, 0, 1>(grid, stream, fr, w, d_depth, nullptr, nullptr, nullptr, d_stamps, nullptr, 0, 0);
-  else if (d_had) launch_depth_kernel<true, 1, 2>(grid, stream, fr, w, d_depth, d_had, nullptr, nullptr, d_stamps, nullptr, 0, 0);  // as bench.py times it: with the fused source Hadamard
+  else if (d_had && knobs.trio && !knobs.debug_wg_per_cu && !knobs.wg_per_cu) {
+    const int tgrid = (int)std::min<long long>(num_cus, (total + 2) / 3);
+    *grid_out = 3 * tgrid;
+    hipLaunchKernelGGL((fhevc_cnn_depth_kernel<true, 1, 2, 1>), dim3(tgrid), dim3(768), 3 * Lds<true>::LDS_BYTES, stream, fr, w, d_depth, d_had, nullptr, nullptr, d_stamps, nullptr, 0, 0);
+  } else if (d_had) launch_depth_kernel<true, 1, 2>(grid, stream, fr, w, d_depth, d_had, nullptr, nullptr, d_stamps, nullptr, 0, 0);  // as bench.py times it: with the fused source Hadamard
   else launch_depth_kernel<true, 0, 2>(grid, stream, fr, w, d_depth, nullptr, nullptr, nullptr, d_stamps, nullptr, 0, 0);
   return hipGetLastError();
 }

@@ -203,7 +203,7 @@ def _run_qp(job):
         if v["kind"] == "window":
             seq = encode_seq(lib, ys, qp, window=tuple(v["window"]))
         else:  # the shipped rule (fhevc_p_rule_default) with optional overrides of its thresholds / window
-            rule = op.PRule.from_buffer_copy(bytes(capi.p_rule_default()))
+            rule = op.PRule.from_buffer_copy(bytes(capi.p_rule_default_wide() if v.get("wide") else capi.p_rule_default()))
             for l in range(3):
                 if "t_split" in v:
                     rule.t_split[l] = int(v["t_split"][l] * (1 << 18))
