@@ -164,7 +164,9 @@ struct Lds {
                                                             // Hadamard sums (the set of the CTU in flight and the set of the next one)
   static constexpr int HEADW_OFF = LOGIT_OFF + 64 * 4;      // int8 head weights: wh64, wh32, wh16 = 18432 B
   static constexpr int HADP_OFF = HEADW_OFF + 18432;        // MFMA form of the source Hadamard: float partial sums [set 2][M tile 2][block 64]
-  static constexpr int LDS_BYTES = HADP_OFF + 1024;         // 80832 -> two workgroups per CU (157.9 of 160 KiB) / 51072 -> three
+  static constexpr int HEADX_OFF = HADP_OFF + 1024;         // the MFMA heads' scatter table: per lane four 16-bit LDS addresses (its four partial sums' logits, or
+                                                            // the lane's own dummy dword at HEADX_OFF + 512 + 4 lane for a sum that joins nothing): 512 + 256 B
+  static constexpr int LDS_BYTES = HEADX_OFF + 768;         // 81600 -> two workgroups per CU (159.4 of 160 KiB) / 51840 -> three
   static constexpr unsigned HALO_FILL = I8 ? 0x80808080u : 0u;  // "activation 0" in the halos of A1 and A2
   static_assert(A2_PLANE % 256 == 0, "conv3 reads lane groups of a ds_read_b128 from different planes");
   static_assert(33 * IN_PITCH * 4 + 4 * IN_PITCH * 4 <= R2_BYTES, "input tile (and conv1's one fragment read past it) must fit the A2 region");
@@ -1019,6 +1021,19 @@ __global__ __launch_bounds__(TRIO ? 768 : 256, TRIO ? 1 : (ARITH ? FHEVC_I8_WG_P
     }
   }
 
+  if (MFMA_HEADS && tid < 64) {
+    // the MFMA heads' scatter table (P4): lane (n = column, rg = row group) holds the partial sums of blocks (by = rg, bx = 0..3) for weight column n.  Columns
+    // 0, 1: every block's 16-level logit; column 2 + 2 sub + class: the 32-level logit of the block's quadrant, only from the blocks at sub-position sub
+    const int n = tid & 15, rg = tid >> 4, subn = (n - 2) >> 1;
+    const bool is16 = n < 2, is32 = n >= 2 && n < 10 && ((rg & 1) == (subn >> 1));
+    unsigned a[4];
+    for (int i = 0; i < 4; ++i) {
+      const bool act = is16 || (is32 && ((i & 1) == (subn & 1)));
+      const int idx = is16 ? 2 * (5 + 4 * rg + i) + n : 2 * (1 + (rg >> 1) * 2 + (i >> 1)) + (n & 1);
+      a[i] = act ? (unsigned)(L::LOGIT_OFF + 4 * idx) : (unsigned)(L::HEADX_OFF + 512 + 4 * tid);
+    }
+    *reinterpret_cast<uint2*>(lds + L::HEADX_OFF + tid * 8) = make_uint2(a[0] | (a[1] << 16), a[2] | (a[3] << 16));
+  }
   const int band_rows = F.row_end - F.row_begin;
   const int per_frame = band_rows * F.ctus_x;
   const int total = per_frame * F.num_frames;
@@ -1426,15 +1441,14 @@ __global__ __launch_bounds__(TRIO ? 768 : 256, TRIO ? 1 : (ARITH ? FHEVC_I8_WG_P
       }
       // the MFMA's partial sums join the logits (initialised to the head biases in P3) by LDS atomic adds: columns 0, 1 every block's
       // 16-level logit, column 2 + 2 sub + class the 32-level logit of the quadrant -- only from the blocks that sit at sub-position sub
+      // (where each of the lane's four sums goes was worked out once per kernel: the scatter table in LDS -- four unconditional ds_add_u32 instead of four
+      // predicated ones behind ~45 VALU / 30 SALU of lane classification per CTU)
       {
-        const int n = lane & 15, rg = lane >> 4, subn = (n - 2) >> 1;
-        const bool is16 = n < 2, is32 = n >= 2 && n < 10 && ((rg & 1) == (subn >> 1));
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const bool act = is16 || (is32 && ((i & 1) == (subn & 1)));
-          const int idx = is16 ? 2 * (5 + 4 * rg + i) + n : 2 * (1 + (rg >> 1) * 2 + (i >> 1)) + (n & 1);
-          if (act) atomicAdd(logitL + idx, hacc[i]);
-        }
+        const uint2 hx = *reinterpret_cast<const uint2*>(lds + L::HEADX_OFF + lane * 8);
+        atomicAdd(reinterpret_cast<int*>(lds + (hx.x & 0xFFFFu)), hacc[0]);
+        atomicAdd(reinterpret_cast<int*>(lds + (hx.x >> 16)), hacc[1]);
+        atomicAdd(reinterpret_cast<int*>(lds + (hx.y & 0xFFFFu)), hacc[2]);
+        atomicAdd(reinterpret_cast<int*>(lds + (hx.y >> 16)), hacc[3]);
       }
       const int r64a = dpp_row_sum(s64a), r64b = dpp_row_sum(s64b);
       const int q64a = __builtin_amdgcn_readlane(r64a, 0) + __builtin_amdgcn_readlane(r64a, 16) +

@@ -124,7 +124,7 @@ def mc_node_depth(nodes, prev, W, H):
     return out.reshape(n, 256)
 
 
-def motion_ranges(oracle, rule, cur, ref, prev_depth, qp, search_range=4, dist=0, mc=False, window_only=None):
+def motion_ranges(oracle, rule, cur, ref, prev_depth, qp, search_range=4, dist=0, mc=False, window_only=None, hybrid=None):
     """depth range of a P picture from the source-only motion search (oracle twin of k_motion.hip) and the previous picture's
     depths, through the oracle twin of fhevc_p_depth_range (the GPU path is bit-exact with both)"""
     import p_features
@@ -148,6 +148,10 @@ def motion_ranges(oracle, rule, cur, ref, prev_depth, qp, search_range=4, dist=0
     for c in range(n):
         vw, vh = min(64, W - (c % cw) * 64), min(64, H - (c // cw) * 64)
         oracle.fho_p_depth_range(nodes[c].ctypes.data, prev[c].ctypes.data, vw, vh, qp, C.byref(rule), dmin[c].ctypes.data, dmax[c].ctypes.data)
+    if hybrid is not None:  # round-4 prototype: [p - lo, p] everywhere, one level DEEPER than the reference depth p only where the rule (run without its window,
+        p = prev.astype(int)   # t_stop = -t_deeper) still allows the split beyond p
+        hi = np.where(dmax.astype(int) > p, p + 1, p)
+        return np.clip(p - hybrid, 0, 3).astype(np.uint8), np.clip(hi, 0, 3).astype(np.uint8)
     return dmin, dmax
 
 
@@ -215,7 +219,7 @@ def _run_qp(job):
                     for i in range(10):
                         rule.w[l][i] = int(v["w"][l][i])
             opts = {"search_range": v.get("search_range", 4), "dist": 1 if v.get("dist") == "sad" else 0, "mc": v.get("mc", False),
-                    "window_only": tuple(v["mc_window"]) if "mc_window" in v else None}
+                    "window_only": tuple(v["mc_window"]) if "mc_window" in v else None, "hybrid": v.get("hybrid")}
             seq = encode_seq(lib, ys, qp, motion=(oracle, rule, opts))
         out[name] = tail(seq)
         out[name + ":agreement"] = [float((seq[f][0] == anchor[f][0]).mean()) for f in range(2, nframes)]
