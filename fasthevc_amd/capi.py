@@ -24,7 +24,7 @@ SYMBOLS = [
     "fhevc_enable_kernel_timing", "fhevc_get_stats", "fhevc_last_error", "fhevc_version",
     "fhevc_expand_depth_flags_device", "fhevc_aq_parts", "fhevc_preanalyze", "fhevc_preanalyze_frames_device", "fhevc_aq_qp", "fhevc_intra_first_pass_device",
     "fhevc_predict_frame_range", "fhevc_predict_frames_device_range",
-    "fhevc_motion_search", "fhevc_motion_search_device", "fhevc_intra_first_pass_all", "fhevc_intra_first_pass_candidates", "fhevc_p_rule_default", "fhevc_p_rule_default_wide", "fhevc_p_depth_range", "fhevc_p_motion_compensated_depth",
+    "fhevc_motion_search", "fhevc_motion_search_device", "fhevc_intra_first_pass_all", "fhevc_intra_first_pass_candidates", "fhevc_p_rule_default", "fhevc_p_rule_default_wide", "fhevc_p_depth_range", "fhevc_p_motion_compensated_depth", "fhevc_p_node_depth",
     "fhevc_predict_frames", "fhevc_alloc_host", "fhevc_free_host", "fhevc_set_cnn_arith", "fhevc_get_cnn_arith", "fhevc_set_motion_distortion", "fhevc_read_yuv_luma",
 ]
 CNN_ARITH = {"i8": 8, "f16": 16}
@@ -132,6 +132,7 @@ def load_library(path=None):
     lib.fhevc_p_rule_default_wide.restype = None
     lib.fhevc_p_depth_range.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(PRule), vp, vp]
     lib.fhevc_p_motion_compensated_depth.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
+    lib.fhevc_p_node_depth.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
     lib.fhevc_predict_frames.argtypes = [vp, vp, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int, vp, vp]
     lib.fhevc_alloc_host.argtypes = [vp, C.c_size_t]
     lib.fhevc_alloc_host.restype = vp
@@ -203,6 +204,20 @@ def p_motion_compensated_depth(nodes, prev_map, width, height):
         rc = lib.fhevc_p_motion_compensated_depth(nodes[c].ctypes.data, prev.ctypes.data, width, height, c, out[c].ctypes.data)
         if rc != OK:
             raise FastHevcError(rc, "fhevc_p_motion_compensated_depth")
+    return out
+
+
+def p_node_depth(nodes, prev_map, width, height):
+    """config 4, host side: the reference picture's depths seen through the motion, asked per CU node of the current picture's grid (a partition of
+    every CTU: fhevc_p_node_depth)"""
+    lib = load_library()
+    nodes = np.ascontiguousarray(nodes)
+    prev = np.ascontiguousarray(prev_map, np.uint8)
+    out = np.zeros((nodes.shape[0], 256), np.uint8)
+    for c in range(nodes.shape[0]):
+        rc = lib.fhevc_p_node_depth(nodes[c].ctypes.data, prev.ctypes.data, width, height, c, out[c].ctypes.data)
+        if rc != OK:
+            raise FastHevcError(rc, "fhevc_p_node_depth")
     return out
 
 

@@ -1678,6 +1678,36 @@ int fhevc_p_motion_compensated_depth(const fhevc_motion_node* nodes, const uint8
   return FHEVC_OK;
 }
 
+int fhevc_p_node_depth(const fhevc_motion_node* nodes, const uint8_t* prev_map, int width, int height, int ctu, uint8_t* out)
+{
+  if (!nodes || !prev_map || !out || width < 8 || height < 8 || ctu < 0) return FHEVC_E_INVALID;
+  const int cw = (width + 63) / 64, chh = (height + 63) / 64;
+  if (ctu >= cw * chh) return FHEVC_E_INVALID;
+  const int x0 = (ctu % cw) * 64, y0 = (ctu / cw) * 64;
+  auto ref_depth = [&](int x, int y) {
+    x = std::min(std::max(x, 0), width - 1); y = std::min(std::max(y, 0), height - 1);
+    return (int)prev_map[(size_t)((y >> 6) * cw + (x >> 6)) * 256 + ((y & 63) >> 2) * 16 + ((x & 63) >> 2)];
+  };
+  auto fill = [&](int ux, int uy, int units, int depth) {
+    for (int y = uy; y < uy + units; ++y) std::memset(out + y * 16 + ux, depth, (size_t)units);
+  };
+  struct Mv { int x, y; };
+  auto vector_of = [](const fhevc_motion_node& n, Mv parent) { return n.cost_best != 0xFFFFFFFFu ? Mv{ n.mvx, n.mvy } : parent; };
+  const Mv v0 = vector_of(nodes[0], Mv{ 0, 0 });
+  if (ref_depth(x0 + 32 + v0.x, y0 + 32 + v0.y) == 0) { fill(0, 0, 16, 0); return FHEVC_OK; }
+  for (int q = 0; q < 4; ++q) {
+    const int qx = q & 1, qy = q >> 1;
+    const Mv v1 = vector_of(nodes[1 + q], v0);
+    if (ref_depth(x0 + qx * 32 + 16 + v1.x, y0 + qy * 32 + 16 + v1.y) <= 1) { fill(qx * 8, qy * 8, 8, 1); continue; }
+    for (int b = 0; b < 4; ++b) {
+      const int bx = 2 * qx + (b & 1), by = 2 * qy + (b >> 1);
+      const Mv v2 = vector_of(nodes[5 + by * 4 + bx], v1);
+      fill(bx * 4, by * 4, 4, ref_depth(x0 + bx * 16 + 8 + v2.x, y0 + by * 16 + 8 + v2.y) <= 2 ? 2 : 3);
+    }
+  }
+  return FHEVC_OK;
+}
+
 int fhevc_set_motion_distortion(fhevc_ctx* c, int mode)
 {
   if (!c) return FHEVC_E_INVALID;

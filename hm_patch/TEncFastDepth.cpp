@@ -18,7 +18,7 @@ static_assert(sizeof(fhevc_p_rule) == 37 * sizeof(int), "TEncFastDepth::m_pRule 
 
 TEncFastDepth::TEncFastDepth()
   : m_enabled(false), m_valid(false), m_external(false), m_cachePic(NULL), m_cachePoc(-1), m_cacheQp(-1), m_cacheType(-1), m_cacheFp(0), m_ctx(NULL), m_width(0), m_height(0), m_bitDepth(0), m_marginSplit(0), m_marginStop(0), m_pWindow(1), m_pMode(P_OFF), m_pRange(4),
-    m_pMotionCompensated(false), m_firstPassExtra(0), m_firstPass(false), m_candValid(false), m_candExternal(false)
+    m_pMotionCompensated(false), m_pNodeForm(false), m_firstPassExtra(0), m_firstPass(false), m_candValid(false), m_candExternal(false)
 {
   readKnobs();
 }
@@ -56,15 +56,19 @@ void TEncFastDepth::readKnobs()
   m_pRange = pr ? std::atoi(pr) : 4;
   if (m_pRange < 1) m_pRange = 1;
   if (m_pRange > 64) m_pRange = 64;   // above 8: HM's own integer search (SAD, xPatternSearch) over the window, 8-bit content (fasthevc.h)
-  // FHEVC_P_MC=1: the reference picture's depths are taken where the motion search says the content came from
-  // (fhevc_p_motion_compensated_depth) instead of co-located.  Off by default: measured (HISTORY.md section 4b), a displaced map is no longer
-  // aligned to the CU grid and decides worse than the co-located one even under a global pan of 32 samples per picture
+  // FHEVC_P_MC: the reference picture's depths are taken where the motion search says the content came from instead of co-located.
+  //   node (or 2): per CU node of the CURRENT grid, at the node's displaced centre (fhevc_p_node_depth, round 4): a partition on this picture's grid; under a
+  //                global pan of 32 samples per picture -0.26 % where the co-located map gives -0.10 % and the per-unit form +1.76 %, elsewhere equal to
+  //                the co-located map (profiles/r04_p_slice_node_*.json);
+  //   1:           per 4x4 unit (fhevc_p_motion_compensated_depth, round 3): not aligned to the CU grid, decides worse than the co-located map;
+  //   0 / unset:   co-located.
   const char* pc = std::getenv("FHEVC_P_MC");
-  m_pMotionCompensated = pc != NULL && std::atoi(pc) != 0;
+  m_pMotionCompensated = pc != NULL && (std::atoi(pc) != 0 || pc[0] == 'n');
+  m_pNodeForm = pc != NULL && (pc[0] == 'n' || std::atoi(pc) == 2);
   // The wide rule (fhevc_p_rule_default_wide) was fitted -- and measured, profiles/r03_p_slice_wide_*.json -- on SAD features of the +-64 search WITH the
   // reference picture's depths taken at the displaced position: FHEVC_P_RANGE > 8 therefore turns the displaced depths on unless FHEVC_P_MC says
   // otherwise, and with FHEVC_P_MC=0 the wide search feeds the DEFAULT rule (fitted on co-located depths) instead of a rule it was not fitted for
-  if (m_pRange > 8 && pc == NULL) m_pMotionCompensated = true;
+  if (m_pRange > 8 && pc == NULL) { m_pMotionCompensated = true; m_pNodeForm = true; }
 #ifndef FHEVC_HOOK_NO_GPU
   if (m_pRange > 8 && m_pMotionCompensated) fhevc_p_rule_default_wide(P_RULE); else fhevc_p_rule_default(P_RULE);
   const char* pt = std::getenv("FHEVC_P_THRESH");   // "split64,split32,split16,stop64,stop32,stop16" in score units (1.0 = 2^18)
@@ -212,7 +216,8 @@ bool TEncFastDepth::predictPicture(TComPic* pcPic, int sliceQp, int sliceType)
       const unsigned char* prevCtu = &prev[(size_t)c * 256];
       if (m_pMotionCompensated)
       {
-        if (fhevc_p_motion_compensated_depth(&nodes[(size_t)c * FHEVC_NODES_PER_CTU], &prev[0], w, h, c, seen) != FHEVC_OK) return false;
+        if ((m_pNodeForm ? fhevc_p_node_depth(&nodes[(size_t)c * FHEVC_NODES_PER_CTU], &prev[0], w, h, c, seen)
+                         : fhevc_p_motion_compensated_depth(&nodes[(size_t)c * FHEVC_NODES_PER_CTU], &prev[0], w, h, c, seen)) != FHEVC_OK) return false;
         prevCtu = seen;
       }
       if (fhevc_p_depth_range(&nodes[(size_t)c * FHEVC_NODES_PER_CTU], prevCtu, vw, vh, sliceQp, P_RULE,

@@ -19,7 +19,7 @@
  *   FHEVC_P_MODE=window|motion  P/B pictures whose first reference picture was inter coded (default: off = stock RDO):
  *                             window = co-located depth of that picture +- FHEVC_P_WINDOW levels (host logic only, independent of
  *                             FHEVC_ENABLE); motion = GPU motion search of every CU node in the reference's ORIGINAL picture
- *                             (FHEVC_P_RANGE = window radius 1..64, default 4; above 8: SAD search, and the displaced depths of FHEVC_P_MC come on with it -- the combination the wide rule was fitted and measured on; FHEVC_P_MC=0 keeps co-located depths and the default rule) + fhevc_p_depth_range (needs FHEVC_ENABLE=1);
+ *                             (FHEVC_P_RANGE = window radius 1..64, default 4; above 8: SAD search, and the displaced depths of FHEVC_P_MC=node come on with it; FHEVC_P_MC=1: the per-unit form of round 3; FHEVC_P_MC=0 keeps co-located depths and the default rule) + fhevc_p_depth_range (needs FHEVC_ENABLE=1);
  *                             FHEVC_P_THRESH overrides the six thresholds of the rule, FHEVC_P_WINDOW adds the +- clip to it
  *   FHEVC_FIRST_PASS=1        intra pictures: the candidate list of TEncSearch::estIntraPredLumaQT (the numModesForFullRD modes its 35-mode
  *                             Hadamard pass would pick) comes from the GPU's first pass over the ORIGINAL picture for PUs of 8x8 and larger
@@ -69,6 +69,7 @@ private:
   enum PMode { P_OFF, P_WINDOW, P_MOTION };
   int        m_pMode, m_pRange;
   bool       m_pMotionCompensated;  ///< reference depths taken at the motion-compensated position (FHEVC_P_MC)
+  bool       m_pNodeForm;           ///< ... per CU node of the current grid (FHEVC_P_MC=node: fhevc_p_node_depth) instead of per 4x4 unit
   int        m_firstPassExtra;
   bool       m_firstPass, m_candValid, m_candExternal;   ///< FHEVC_FIRST_PASS; m_cand holds this picture's lists; lists fed by a harness
   std::vector<unsigned char> m_cand;    // numCtus * 85 * 8: the eight cheapest modes per node, best first (255: node crosses the picture edge)

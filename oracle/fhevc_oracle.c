@@ -612,6 +612,33 @@ void fho_p_motion_compensated_depth(const fho_motion_node nodes[85], const uint8
   }
 }
 
+/* ... through the CU nodes of the current picture (include/fasthevc.h: fhevc_p_node_depth): recursive restatement */
+static void p_node_rec(const fho_motion_node nodes[85], const uint8_t* prev_map, int width, int height, int cw, int x0, int y0, int level, int idx, int ux, int uy,
+                       int pmvx, int pmvy, uint8_t out[256])
+{
+  const int size = 64 >> level, units = size / 4;
+  const fho_motion_node* n = &nodes[idx];
+  const int mvx = n->cost_best == 0xFFFFFFFFu ? pmvx : n->mvx, mvy = n->cost_best == 0xFFFFFFFFu ? pmvy : n->mvy;
+  const int px = clip3(0, width - 1, x0 + ux * 4 + size / 2 + mvx), py = clip3(0, height - 1, y0 + uy * 4 + size / 2 + mvy);
+  const int d = prev_map[(size_t)((py >> 6) * cw + (px >> 6)) * 256 + ((py & 63) >> 2) * 16 + ((px & 63) >> 2)];
+  if (d <= level || level == 2) {
+    const int depth = d <= level ? level : 3;
+    for (int y = 0; y < units; y++)
+      for (int x = 0; x < units; x++) out[(uy + y) * 16 + ux + x] = (uint8_t)depth;
+    return;
+  }
+  for (int k = 0; k < 4; k++) {
+    const int cux = ux + (k & 1) * units / 2, cuy = uy + (k >> 1) * units / 2;
+    const int cidx = level == 0 ? 1 + (cuy / 8) * 2 + cux / 8 : 5 + (cuy / 4) * 4 + cux / 4;
+    p_node_rec(nodes, prev_map, width, height, cw, x0, y0, level + 1, cidx, cux, cuy, mvx, mvy, out);
+  }
+}
+void fho_p_node_depth(const fho_motion_node nodes[85], const uint8_t* prev_map, int width, int height, int ctu, uint8_t out[256])
+{
+  const int cw = (width + 63) / 64;
+  p_node_rec(nodes, prev_map, width, height, cw, (ctu % cw) * 64, (ctu / cw) * 64, 0, 0, 0, 0, 0, 0, out);
+}
+
 /* P-picture depth range (include/fasthevc.h: fhevc_p_depth_range) */
 int32_t fho_ilog2_q8(uint32_t x)
 {

@@ -131,6 +131,7 @@ void fho_motion_ctu(const int16_t* cur, int cur_stride, const int16_t* ref, int 
 typedef struct { int32_t w[3][10]; int32_t t_split[3], t_stop[3]; int32_t window; } fho_p_rule;
 int32_t fho_ilog2_q8(uint32_t x);   /* floor(256 log2 x) by integer squaring, x >= 1 */
 void fho_p_motion_compensated_depth(const fho_motion_node nodes[85], const uint8_t* prev_map, int width, int height, int ctu, uint8_t out[256]);
+void fho_p_node_depth(const fho_motion_node nodes[85], const uint8_t* prev_map, int width, int height, int ctu, uint8_t out[256]);
 void fho_p_depth_range(const fho_motion_node nodes[85], const uint8_t prev_depth[256], int valid_w, int valid_h,
                        int qp, const fho_p_rule* rule, uint8_t depth_min[256], uint8_t depth_max[256]);
 

@@ -88,40 +88,16 @@ def mc_depth(oracle, nodes, prev_depth, W, H):
     return out
 
 
-def mc_node_depth(nodes, prev, W, H):
-    """round 4 (the review's form of "inter-CU depth reuse through the motion"): per CU NODE of the current picture's grid, the reference picture's depth
-    at the displaced CENTRE of the node; top-down: a node whose reference depth is not deeper than its own level becomes one CU, otherwise its four
-    children are asked -> a quadtree-consistent partition aligned to the CURRENT grid (prototype of fhevc_p_motion_compensated_depth's node form)"""
+def mc_node_depth(oracle, nodes, prev, W, H):
+    """the reference picture's depths asked per CU node of the current grid (oracle twin of fhevc_p_node_depth; the round-4 numbers under profiles/ were
+    produced by a Python prototype of the same walk, checked equal to the library's function on random nodes)"""
     n = nodes.shape[0]
-    cw = (W + 63) // 64
-    out = np.zeros((n, 16, 16), np.uint8)
-
-    def ref_depth(x, y):
-        x, y = min(max(x, 0), W - 1), min(max(y, 0), H - 1)
-        return int(prev[(y >> 6) * cw + (x >> 6), ((y & 63) >> 2) * 16 + ((x & 63) >> 2)])
-
+    prev = np.ascontiguousarray(prev, np.uint8).reshape(n, 256)
+    out = np.zeros((n, 256), np.uint8)
+    oracle.fho_p_node_depth.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     for c in range(n):
-        x0, y0 = (c % cw) * 64, (c // cw) * 64
-
-        def rec(level, idx, bx, by, mv):  # bx, by in 4x4 units inside the CTU
-            S = 64 >> level
-            nd = nodes[c, idx]
-            if nd["cost_best"] != 0xFFFFFFFF:
-                mv = (int(nd["mvx"]), int(nd["mvy"]))
-            d = ref_depth(x0 + bx * 4 + S // 2 + mv[0], y0 + by * 4 + S // 2 + mv[1])
-            u = S // 4
-            if d <= level:
-                out[c, by:by + u, bx:bx + u] = level
-            elif level == 2:
-                out[c, by:by + u, bx:bx + u] = 3
-            else:
-                h = u // 2
-                for k in range(4):
-                    cbx, cby = bx + (k & 1) * h, by + (k >> 1) * h
-                    cidx = (1 + (cby // 8) * 2 + (cbx // 8)) if level == 0 else (5 + (cby // 4) * 4 + (cbx // 4))
-                    rec(level + 1, cidx, cbx, cby, mv)
-        rec(0, 0, 0, 0, (0, 0))
-    return out.reshape(n, 256)
+        oracle.fho_p_node_depth(nodes[c].ctypes.data, prev.ctypes.data, W, H, c, out[c].ctypes.data)
+    return out
 
 
 def motion_ranges(oracle, rule, cur, ref, prev_depth, qp, search_range=4, dist=0, mc=False, window_only=None, hybrid=None):
@@ -135,7 +111,7 @@ def motion_ranges(oracle, rule, cur, ref, prev_depth, qp, search_range=4, dist=0
     dmin, dmax = np.zeros((n, 256), np.uint8), np.zeros((n, 256), np.uint8)
     prev = np.ascontiguousarray(prev_depth, np.uint8).reshape(n, 256)
     if mc == "node":  # ... at the displaced centre of each CU node, snapped to the current picture's CU grid
-        prev = mc_node_depth(nodes, prev, W, H)
+        prev = mc_node_depth(oracle, nodes, prev, W, H)
     elif mc:  # "inter-CU depth reuse" through the motion: the depths at the displaced position instead of the co-located ones
         prev = mc_depth(oracle, nodes, prev, W, H)
     if window_only is not None:  # no rule: the (motion-compensated) depths +- a window

@@ -120,6 +120,61 @@ def test_p_motion_compensated_depth_equals_the_oracle(oracle):
     assert np.array_equal(still.reshape(-1, 16, 16)[inside], prev.reshape(-1, 16, 16)[inside])
 
 
+def test_p_node_depth_equals_the_oracle_and_is_a_partition(oracle):
+    """Host-side logic behind the C ABI (no GPU): the reference picture's depths asked per CU NODE of the current grid (fhevc_p_node_depth): equals the
+    oracle's recursive restatement on a ragged picture with vectors up to +-64 and edge-crossing nodes; the result is a quadtree-consistent partition
+    (constant over every CU it declares); zero motion over a map that is a partition gives the map back."""
+    import ctypes as C
+    W, H = 416, 240
+    cw, ch = 7, 4
+    rng = np.random.default_rng(12)
+
+    def random_partition():   # a valid HM depth map per CTU: top-down random splits
+        m = np.zeros((cw * ch, 16, 16), np.uint8)
+        for c in range(cw * ch):
+            if rng.random() < 0.3:
+                continue
+            for q in range(4):
+                qy, qx = 8 * (q >> 1), 8 * (q & 1)
+                if rng.random() < 0.4:
+                    m[c, qy:qy + 8, qx:qx + 8] = 1
+                    continue
+                for b in range(4):
+                    by, bx = qy + 4 * (b >> 1), qx + 4 * (b & 1)
+                    m[c, by:by + 4, bx:bx + 4] = 2 if rng.random() < 0.5 else 3
+        return m.reshape(cw * ch, 256)
+
+    prev = random_partition()
+    nodes = np.zeros((cw * ch, 85), capi.MOTION_DTYPE)
+    nodes["mvx"] = rng.integers(-64, 65, size=nodes.shape)
+    nodes["mvy"] = rng.integers(-64, 65, size=nodes.shape)
+    nodes["cost_best"] = rng.integers(0, 1000, size=nodes.shape)
+    nodes["cost_best"][rng.random(nodes.shape) < 0.2] = 0xFFFFFFFF
+    got = capi.p_node_depth(nodes, prev, W, H)
+    exp = np.zeros_like(got)
+    oracle.fho_p_node_depth.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    for c in range(cw * ch):
+        oracle.fho_p_node_depth(nodes[c].ctypes.data, prev.ctypes.data, W, H, c, exp[c].ctypes.data)
+    assert np.array_equal(got, exp)
+    assert (got != prev).any()
+    g = got.reshape(-1, 16, 16)
+    for c in range(cw * ch):   # every unit's depth d sits in a CU of (64 >> d) samples that is constant
+        for uy in range(16):
+            for ux in range(16):
+                d = int(g[c, uy, ux])
+                u = max(16 >> d, 2) if d < 3 else 2     # depth 3 = 8x8 CUs: 2x2 units; they come four at a time (a 16x16 node)
+                y0, x0 = uy // u * u, ux // u * u
+                assert (g[c, y0:y0 + u, x0:x0 + u] == d).all() or d == 3
+    nodes["mvx"] = 0
+    nodes["mvy"] = 0
+    still = capi.p_node_depth(nodes, prev, W, H)
+    inside = np.zeros((cw * ch, 16, 16), bool)   # CTUs wholly inside the picture (a node that leaves it asks a clamped position)
+    for c in range(cw * ch):
+        if (c % cw) * 64 + 64 <= W and (c // cw) * 64 + 64 <= H:
+            inside[c] = True
+    assert np.array_equal(still.reshape(-1, 16, 16)[inside], prev.reshape(-1, 16, 16)[inside])
+
+
 def test_cost_sensitive_training_utilities():
     """fasthevc_amd/train/train.py: the z-order -> raster mapping of the recorded node costs, and the tree regret (0 for the cheapest tree, the cost
     difference for a single wrong decision)."""
