@@ -518,9 +518,9 @@ def main():
                 d = json.load(open(path))
                 for k, v in d.items():
                     if kernel == "fhevc_cnn_depth_kernel" and k.startswith(kernel + "<"):
-                        # template arguments <STAMPS, HAD, ARITH>: ARITH 0 = the 16-bit form, 1 / 2 = the i8 form (files of before the i8 form: two arguments)
+                        # template arguments <STAMPS, HAD, ARITH[, TRIO]>: ARITH 0 = the 16-bit form, 1 / 2 = the i8 form (files of before the i8 form: two arguments)
                         targs = k.split("<", 1)[1].split(">", 1)[0].split(",")
-                        if (arith == "i8") != (len(targs) == 3 and targs[2].strip() in ("1", "2")):
+                        if (arith == "i8") != (len(targs) >= 3 and targs[2].strip() in ("1", "2")):
                             continue
                     if k.startswith(kernel) and isinstance(v, dict) and "hbm_read_bytes_corrected" in v and "hbm_write_bytes" in v:
                         return v["hbm_read_bytes_corrected"] + v["hbm_write_bytes"], f"profiles/{rnd}_{stem}.json (commit {d.get('commit', 'of that round')})"
@@ -540,7 +540,7 @@ def main():
                 if not (k.startswith("fhevc_cnn_depth_kernel<") and isinstance(v, dict) and "SQ_VALU_MFMA_BUSY_CYCLES" in v):
                     continue
                 targs = k.split("<", 1)[1].split(">", 1)[0].split(",")
-                if (arith == "i8") != (len(targs) == 3 and targs[2].strip() in ("1", "2")):
+                if (arith == "i8") != (len(targs) >= 3 and targs[2].strip() in ("1", "2")):
                     continue
                 ms = v.get("avg_ms") or v.get("duration_ms") or cnn_ms
                 if not ms:
