@@ -389,10 +389,12 @@ int build_layers_image(fhevc_ctx* c, const uint8_t* blob, size_t bytes, int C1, 
             }
           }
       std::vector<int32_t> bias((size_t)cout_pad, 0);
+      long long bound = 0;   // largest |accumulator| any input can produce: |b'| + 128 * sum |w| (inputs are a - 128 / centred samples: |x| <= 128)
       for (int oc = 0; oc < co; ++oc) {
-        int sw = 0;
-        for (int i = 0; i < cin * 9; ++i) sw += w[(size_t)oc * cin * 9 + i];
+        int sw = 0, sa = 0;
+        for (int i = 0; i < cin * 9; ++i) { sw += w[(size_t)oc * cin * 9 + i]; sa += std::abs((int)w[(size_t)oc * cin * 9 + i]); }
         bias[(size_t)oc] = i32at(bp, oc) + (first ? 0 : 128 * sw);   // activations travel as a - 128; the first layer's input IS centred
+        bound = std::max(bound, std::llabs((long long)bias[(size_t)oc]) + 128LL * sa);
       }
       const int pool = (j == depth - 1) && b < 2, Ho = pool ? H / 2 : H;
       FhevcLayer& L = lw.l[li];
@@ -409,6 +411,9 @@ int build_layers_image(fhevc_ctx* c, const uint8_t* blob, size_t bytes, int C1, 
       HIP_TRY(c, hipMemcpy(dbias, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
       L.frag = static_cast<const uint4*>(dfrag); L.bias = static_cast<const int32_t*>(dbias);
       L.shift = sh; L.kc = kc; L.cout_pad = cout_pad; L.H = H; L.pool = pool;
+      // requant4_i8's short forms: 1 packs to i16 with saturation BEFORE the shift (exact for shifts up to 7: a saturated value still clamps to 255 / 0 behind
+      // it); 2 takes bytes 1-2 of the accumulator (shift 8, exact while the accumulator fits 24 bits)
+      L.rq = sh <= 7 ? 1 : (sh == 8 && bound < (1LL << 23)) ? 2 : 0;
       H = Ho; cin = co;
     }
   lw.num_layers = li; lw.c3 = C3; lw.c3_pad = 32 * ((C3 + 31) / 32);
@@ -440,6 +445,8 @@ int build_layers_image(fhevc_ctx* c, const uint8_t* blob, size_t bytes, int C1, 
   HIP_TRY(c, hipMemcpy(dbh, bhead, sizeof bhead, hipMemcpyHostToDevice));
   lw.whead = static_cast<const uint8_t*>(dwh); lw.bhead = static_cast<const int32_t*>(dbh);
   if (d2 && !fhevc_cnn_d2_supported(lw)) return fail(c, FHEVC_E_STATE, "layer images do not match the fused two-convolution kernel");
+  lw.d2_short = d2 && !c->knobs.d2_requant_general && lw.l[0].rq == 1;
+  for (int i = 1; i < 6 && lw.d2_short; ++i) lw.d2_short = lw.l[i].rq == 2;
   c->lw = lw;
   c->fam_c[0] = C1; c->fam_c[1] = C2; c->fam_c[2] = C3;
   c->family = true; c->fam_layers = true; c->fam_d2 = d2; c->have_weights = true;

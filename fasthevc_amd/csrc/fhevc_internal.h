@@ -38,6 +38,7 @@ struct FhevcKnobs {
   bool requant_general = false; // FHEVC_CNN_REQUANT=general: the i8 form's general requant instead of the short forms
   bool family_layers = false;   // FHEVC_FAMILY_LAYERS: a member with a fused kernel runs layer by layer all the same (tests)
   bool trio = false;            // FHEVC_CNN_TRIO=1: the i8 depth kernel as ONE 768-thread workgroup per CU, three groups one barrier interval apart (k_cnn.hip, TRIO)
+  bool d2_requant_general = false; // FHEVC_D2_REQUANT=general: the fused two-convolution kernel's general requant instantiation whatever the blob allows (tests, A/B)
   bool fused_d2 = true;         // FHEVC_FUSED_D2=0: the two-convolutions-per-block members run layer by layer instead of through k_cnn_d2.inc (tests, A/B)
   bool layers_no_fuse = false;  // FHEVC_LAYERS_NO_FUSE: the layer path without the first convolution fused into the second (tests)
   bool layers_no_dbuf = false;  // FHEVC_LAYERS_NO_DBUF: the layer path's single-buffered staging (tests)
@@ -98,12 +99,14 @@ struct FhevcLayer {
   const int32_t* bias;   // [cout_pad], + 128 * sum of the filter's weights (not for the first layer: its input is centred samples)
   int8_t* out;           // [chunk CTUs][Ho + 2] rows of ([Ho + 2][cout_pad] + out_pad bytes)
   int shift, kc, cout_pad, H, pool;   // kc = Cin_pad / 32 (0: first layer); H = input size (64 / 32 / 16)
+  int rq;                             // the shortest requant form the layer's weights allow (k_cnn_layers.inc: layer_store16): 1 = shift <= 7, 2 = shift 8 and |accumulator| < 2^23, else 0
   int in_pad, out_pad, swz;           // bytes added to the row pitch of the input / output tensor; XOR mask of the LDS image (fhevc_layer_lds_image)
 };
 // the row-pitch padding and XOR mask that make the layer kernel's LDS reads conflict-free for an input of kc x 32 channels at H x H (tools/lds_swizzle_search.py)
 void fhevc_layer_lds_image(int kc, int pool, int H, int* pad, int* mask);
 struct FhevcLayersWeights {
   int num_layers, chunk, c3, c3_pad;
+  int d2_short;            // the fused two-convolution kernel may run its short-requant instantiation (l[0].rq == 1, l[1..5].rq == 2; FHEVC_D2_REQUANT=general: never)
   FhevcLayer l[9];
   int8_t* in0;             // [chunk CTUs][66][66]
   const uint8_t* whead;    // wh64[2][8][8][c3_pad], wh32[2][8][8][c3_pad], wh16[2][4][4][c3_pad] (zeros behind the c3 weights)

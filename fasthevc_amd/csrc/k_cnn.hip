@@ -2099,7 +2099,8 @@ hipError_t fhevc_cnn_prepare_device()
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_layer_conv_kernel<KCV, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
   FHEVC_LAYER_FUSE(1) FHEVC_LAYER_FUSE(2)
 #undef FHEVC_LAYER_FUSE
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_d2_kernel<1, 2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, LdsD2<1, 2, 3>::LDS_BYTES);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_d2_kernel<1, 2, 3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LdsD2<1, 2, 3>::LDS_BYTES);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_d2_kernel<1, 2, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LdsD2<1, 2, 3>::LDS_BYTES);
   // the i8 depth kernel as one 768-thread workgroup per CU: three groups x 50 048 B
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_kernel<false, 0, 2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * Lds<true>::LDS_BYTES);
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fhevc_cnn_depth_kernel<false, 1, 2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * Lds<true>::LDS_BYTES);
@@ -2146,6 +2147,7 @@ FhevcKnobs fhevc_read_knobs()
   if (const char* kb = std::getenv("FHEVC_LAYERS_LDS_KB")) k.layers_lds_limit = (size_t)std::min(80, std::max(8, std::atoi(kb))) * 1024;   // <= the opt-in of fhevc_cnn_prepare_device
   if (const char* lg = std::getenv("FHEVC_LAYERS_GRID")) k.layers_grid = std::atoi(lg);
   if (const char* tr = std::getenv("FHEVC_CNN_TRIO")) k.trio = tr[0] != '0';
+  if (const char* rq = std::getenv("FHEVC_D2_REQUANT")) k.d2_requant_general = std::strcmp(rq, "general") == 0;
   return k;
 }
 
@@ -2258,7 +2260,9 @@ hipError_t fhevc_launch_cnn_d2(const FhevcFrames& fr, const FhevcLayersWeights& 
   if (!fhevc_cnn_d2_supported(w)) return hipErrorInvalidValue;
   int grid = num_cus;   // one 512-thread workgroup per CU (119 KB of LDS)
   if (total < grid) grid = (int)total;
-  hipLaunchKernelGGL((fhevc_cnn_d2_kernel<1, 2, 3>), dim3(grid), dim3(512), (LdsD2<1, 2, 3>::LDS_BYTES), stream, fr, w, d_depth, d_logits, d_flags, d_depth_max, margin_split, margin_stop);
+  // every layer qualifies for its short requant form (conv1a: shift <= 7; the others: shift 8, accumulators inside 24 bits): the instantiation built for that
+  if (w.d2_short) hipLaunchKernelGGL((fhevc_cnn_d2_kernel<1, 2, 3, true>), dim3(grid), dim3(512), (LdsD2<1, 2, 3>::LDS_BYTES), stream, fr, w, d_depth, d_logits, d_flags, d_depth_max, margin_split, margin_stop);
+  else hipLaunchKernelGGL((fhevc_cnn_d2_kernel<1, 2, 3, false>), dim3(grid), dim3(512), (LdsD2<1, 2, 3>::LDS_BYTES), stream, fr, w, d_depth, d_logits, d_flags, d_depth_max, margin_split, margin_stop);
   return hipGetLastError();
 }
 

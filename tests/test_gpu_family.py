@@ -154,13 +154,19 @@ def test_family_members_the_build_cannot_run_are_refused_with_a_status():
     assert e.value.code == capi.E_WEIGHTS
 
 
-@pytest.mark.parametrize("blob,bd,qp", [("depthnet_family_d1.fhw", 8, 32), ("depthnet_family_d2.fhw", 8, 27), ("depthnet_family_d2.fhw", 10, 37), ("depthnet_family_d3.fhw", 8, 32)])
-def test_the_shipped_family_blobs_equal_the_oracle(oracle, blob, bd, qp):
+@pytest.mark.parametrize("blob,bd,qp,requant", [("depthnet_family_d1.fhw", 8, 32, None), ("depthnet_family_d2.fhw", 8, 27, None), ("depthnet_family_d2.fhw", 10, 37, None),
+                                                ("depthnet_family_d2.fhw", 8, 27, "general"), ("depthnet_family_d3.fhw", 8, 32, None)])
+def test_the_shipped_family_blobs_equal_the_oracle(oracle, monkeypatch, blob, bd, qp, requant):
     """The TRAINED members as shipped (fasthevc_amd/weights/): their weight statistics differ from the random members of the other tests (small sums of
     |w| per filter, shifts 6 / 8) -- depth maps and logits of two pictures through the library's default dispatch (fused kernel for 32 / 64 / 128 x 1,
-    the layer path for the x 2 and x 3 members) against the oracle, bit for bit."""
+    the fused two-convolution kernel for the x 2 member -- its short-requant instantiation, which this blob qualifies for, and with FHEVC_D2_REQUANT=general
+    its general one --, the layer path for the x 3 member) against the oracle, bit for bit."""
     import os
     import torch
+    if requant:
+        monkeypatch.setenv("FHEVC_D2_REQUANT", requant)
+    else:
+        monkeypatch.delenv("FHEVC_D2_REQUANT", raising=False)
     fam = weights.load_any(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fasthevc_amd", "weights", blob))
     W, H = 416, 240
     lumas = [frames.hetero_luma(W, H, seed=7), frames.texture16_luma(W, H, seed=8)]
