@@ -699,6 +699,8 @@ def main():
         if world > 1:
             line["gather_verified"] = gather_ok
             line["collective"] = fg.status
+            # no SCALE record of an earlier round exists: the builder has no multi-GPU box, RCCL over xGMI runs for the first time in the driver's own run
+            line["multi_gpu_note"] = "N > 1 unmeasured on hardware by the builder (gloo rehearsals only); this line is the first RCCL measurement"
         if world == 1 and not args.no_cpu_baseline:
             if cpu is None:
                 cpu = cpu_baseline_port(1920, 1080, bd, w)
