@@ -269,4 +269,12 @@ def test_two_convolutions_per_block_as_one_kernel(oracle, widths, W, H, bd, seed
         assert np.array_equal(logits[f].cpu().numpy(), refs[f][4]), f
         assert np.array_equal(depth[f].cpu().numpy(), refs[f][3]), f
         assert np.array_equal(expanded[f].cpu().numpy(), refs[f][3]), f
+    if bd == 8:   # tightly packed uint8 planes: the other sample layout of the LDS-DMA staging (16 bytes per lane instead of 32)
+        d8 = torch.from_numpy(np.stack(lumas)).to(dev)
+        depth8 = torch.zeros((3, n, 256), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        ctx.predict_frames_device(d8.data_ptr(), 1, W, W * H, 3, depth8.data_ptr(), None, None, qp=qp)
+        torch.cuda.synchronize()
+        for f in range(3):
+            assert np.array_equal(depth8[f].cpu().numpy(), refs[f][3]), f
     ctx.close()
