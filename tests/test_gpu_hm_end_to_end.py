@@ -164,20 +164,22 @@ def test_reference_encoder_driven_by_a_family_member_on_the_layer_path(oracle):
     assert not np.array_equal(d_gpu, d_full)
 
 
-@pytest.mark.parametrize("size,rng,speeds", [((640, 448), 4, (3, 3)), ((576, 384), 64, (21, -17))])
+@pytest.mark.parametrize("size,rng,speeds,mc", [((640, 448), 4, (3, 3), "0"), ((576, 384), 64, (21, -17), "1"), ((576, 384), 64, (21, -17), "node")])
 @pytest.mark.skipif(not os.path.exists(PGPU_SO), reason="oracle/_ref/libhmref_pgpu.so is built where /root/reference exists")
-def test_config4_p_pictures_driven_by_the_gpu_motion_search(oracle, size, rng, speeds):
+def test_config4_p_pictures_driven_by_the_gpu_motion_search(oracle, size, rng, speeds, mc):
     """BASELINE config 4 end to end: I P P P through the reference's compressSlice with HM-16.14's inter checks restored.  In the
     GPU build TEncFastDepth::predictPicture asks the MI355X for the motion nodes of every P picture whose reference is a P
     picture (fhevc_motion_search) and turns them into depth ranges (fhevc_p_depth_range); the result must equal the CPU-hook
     build fed with the oracle's ranges (fho_motion_ctu + fho_p_depth_range), picture by picture, and differ from full RDO.
     Second case: FHEVC_P_RANGE=64 on a clip moving 21 / 17 samples per picture -- the hook then asks for HM's own integer search
-    (SAD, k_motion_wide.hip) and takes the reference picture's depths at the motion-compensated position (fhevc_p_motion_compensated_depth)."""
+    (SAD, k_motion_wide.hip) and takes the reference picture's depths at the motion-compensated position, per 4x4 unit (FHEVC_P_MC=1:
+    fhevc_p_motion_compensated_depth) or per CU node of the current grid (FHEVC_P_MC=node, round 4: fhevc_p_node_depth, the hook's default for wide ranges)."""
     from fasthevc_amd import capi
     (W, H), QPI, QPP = size, 32, 38
     wide = rng > 8
     ys = frames.pan_clip(W, H, 4, seed=77, v_structure=speeds[0], v_noise=speeds[1])
     oracle.fho_p_motion_compensated_depth.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    oracle.fho_p_node_depth.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     cpu, gpu = _load_p(P_SO), _load_p(PGPU_SO)
     n, cw = (W // 64) * (H // 64), W // 64
     u = np.full((H // 2, W // 2), 128, np.int16)
@@ -209,7 +211,7 @@ def test_config4_p_pictures_driven_by_the_gpu_motion_search(oracle, size, rng, s
                     for c in range(n):
                         pc = prev[c]
                         if wide:
-                            oracle.fho_p_motion_compensated_depth(nodes[c].ctypes.data, prev.ctypes.data, W, H, c, seen.ctypes.data)
+                            (oracle.fho_p_node_depth if mc == "node" else oracle.fho_p_motion_compensated_depth)(nodes[c].ctypes.data, prev.ctypes.data, W, H, c, seen.ctypes.data)
                             pc = seen
                         oracle.fho_p_depth_range(nodes[c].ctypes.data, pc.ctypes.data, 64, 64, QPP, C.byref(rule), fmin[c].ctypes.data, fmax[c].ctypes.data)
                 d, s = _next_p(lib, ys[f], W, H, QPP, f, fmin, fmax)
@@ -222,7 +224,7 @@ def test_config4_p_pictures_driven_by_the_gpu_motion_search(oracle, size, rng, s
         # TEncFastDepth reads the I-picture knobs when the encoder object of a geometry is built: build it before FHEVC_ENABLE is
         # set, so that POC 0 runs stock RDO in both builds; the P pictures re-read the knobs (href_rdo_encode_next_p)
         op.rdo_encode(gpu, buf, org, stride, W, H, 8, QPI, chroma=(u, u))
-        os.environ.update({"FHEVC_P_MODE": "motion", "FHEVC_ENABLE": "1", "FHEVC_WEIGHTS": BLOB, "FHEVC_P_RANGE": str(rng), "FHEVC_P_MC": "1" if wide else "0"})
+        os.environ.update({"FHEVC_P_MODE": "motion", "FHEVC_ENABLE": "1", "FHEVC_WEIGHTS": BLOB, "FHEVC_P_RANGE": str(rng), "FHEVC_P_MC": mc})
         gpu_maps, gpu_bits = run(gpu, False)
         for f in range(4):
             assert np.array_equal(gpu_maps[f], ref_maps[f]), f
